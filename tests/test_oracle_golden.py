@@ -1,0 +1,268 @@
+"""Pins the CPU oracle against golden vectors captured from the reference's own
+Python (tests/golden/make_golden.py), plus the hand KATs / algebraic properties
+of SURVEY.md section 8c (K1-K7) that the reference has no tests for."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import paro_oracle as po
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---- G1: nibble order of _pack_awq (cli/convert.py:149-155) -------------------
+
+def test_g1_pack_awq_bit_exact(golden_dir):
+    g = _load(golden_dir, "pack_awq.npz")
+    assert np.array_equal(po.pack_awq(g["values"]), g["packed"])
+    assert np.array_equal(po.unpack_awq(g["packed"]), g["values"].astype(np.uint8))
+    # SURVEY a7 KAT: [12,15,5,0,3,11,3,7] -> 0x7b0f335c
+    assert int(g["kat_packed"].view(np.uint32)[0, 0]) == 0x7B0F335C
+    assert int(po.pack_awq(g["kat_values"]).view(np.uint32)[0, 0]) == 0x7B0F335C
+
+
+def test_unpack_inverse_table():
+    # mlx/load.py:18 inverse table is the inverse permutation of convert.py:19
+    assert [po.AWQ_REORDER[i] for i in po.AWQ_INV_REORDER] == list(range(8))
+
+
+# ---- G2: _to_awq_buffers (cli/convert.py:194-203) ------------------------------
+
+def test_g2_to_awq_buffers(golden_dir):
+    g = _load(golden_dir, "to_awq_buffers.npz")
+    b = po.to_awq_buffers(g["quantized"], g["scales_2d"], g["zeros_2d"])
+    assert np.array_equal(b["qweight"], g["qweight"])
+    assert np.array_equal(b["qzeros"], g["qzeros"])
+    assert np.array_equal(b["scales"].view(np.uint16), g["scales"].view(np.uint16))
+    # and the dequant of those buffers reproduces (q - z) * s
+    w = po.dequant_awq(b["qweight"], b["qzeros"], b["scales"], 128, out_dtype=np.float32)
+    q = g["quantized"].T.astype(np.float32)
+    z = np.repeat(g["zeros_2d"].T.astype(np.float32), 128, axis=0)
+    s = np.repeat(g["scales_2d"].T.astype(np.float16).astype(np.float32), 128, axis=0)
+    assert np.array_equal(w, (q - z) * s)
+
+
+# ---- G3: quantiser convention (optim/quantizer.py:10-25,87-117) -----------------
+
+def test_g3_quantizer(golden_dir):
+    g = _load(golden_dir, "quantizer.npz")
+    sc, zp = po.calc_scales_and_zero_points(g["w"], 128, 15)
+    np.testing.assert_allclose(sc, g["scale"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(zp, g["zero_point"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(po.pseudo_quantize(g["w"], 4, 128), g["pq_auto"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(po.pseudo_quantize(g["w"], 4, 128, g["scale2"], g["zero_point2"]), g["pq_given"],
+                               rtol=1e-6, atol=1e-7)
+
+
+# ---- G4: kernel-data layout of pairs/theta (optim/rotation.py:69-87) ------------
+
+def test_g4_kernel_pairs_layout(golden_dir):
+    g = _load(golden_dir, "kernel_pairs.npz")
+    for tag in ("", "_partial"):
+        pairs, angles, mask = g["pairs" + tag], g["angles" + tag], g["mask" + tag]
+        krot, K = pairs.shape
+        assert pairs.dtype == np.int16 and angles.shape == (krot, K // 2) and mask.shape == angles.shape
+        assert po.is_valid_pairing(pairs, 128)            # every (stage, group) slice is a permutation
+        assert np.all(angles[mask] == 0)                  # dummies carry theta = 0
+        # real (non-dummy) pairs appear in order with their group offset removed
+        raw, raw_a = g["raw_pairs" + tag], g["raw_angles" + tag]
+        for r in range(krot):
+            got = pairs[r].reshape(-1, 2)[~mask[r]]
+            assert np.array_equal(got, raw[r] % 128)
+            np.testing.assert_array_equal(angles[r][~mask[r]], raw_a[r])
+    # rotating with the real generator's output is orthogonal and invertible
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 512))
+    y = po.rotate(x, g["pairs"], g["angles"], None, 128, mode="ideal")
+    np.testing.assert_allclose(np.linalg.norm(y.reshape(3, 4, 128), axis=-1),
+                               np.linalg.norm(x.reshape(3, 4, 128), axis=-1), rtol=1e-12)
+    ip, it = po.inverse_rotation_params(g["pairs"], g["angles"])
+    np.testing.assert_allclose(po.rotate(y, ip, it, None, 128, mode="ideal"), x, atol=1e-12)
+
+
+# ---- G5/G6: quantise-after-rotate export (cli/convert.py:158-191,239-277) -------
+
+def test_g5_quantize_rotated_weight(golden_dir):
+    g = _load(golden_dir, "quantize_rotated.npz")
+    q, s2d, z2d = po.quantize_rotated_weight(g["weight"], g["pairs"], g["theta"], g["channel_scales"],
+                                             g["scales_flat"], g["zp_flat"], 4, 128, rotate_mode="f32")
+    assert np.array_equal(q, g["quantized"])
+    assert np.array_equal(z2d, g["zeros_2d"])
+    np.testing.assert_array_equal(s2d, g["scales_2d"])
+
+
+def test_g6_quantize_layer_end_to_end(golden_dir):
+    g = _load(golden_dir, "quantize_layer.npz")
+    w = g["weight"].astype(np.float32)
+    q, s2d, z2d = po.quantize_rotated_weight(w, g["pairs_in"], g["theta_in"].astype(np.float32),
+                                             g["channel_scales_opt"], g["scale"], g["zero_point_float"], 4, 128, "f32")
+    b = po.to_awq_buffers(q, s2d, z2d)
+    assert np.array_equal(b["qweight"], g["out_qweight"])
+    assert np.array_equal(b["qzeros"], g["out_qzeros"])
+    assert np.array_equal(b["scales"].view(np.uint16), g["out_scales"].view(np.uint16))
+    # stored channel_scales = 1 / optimiser scales (convert.py:264), theta fp16 (:270), pairs int16 (:271)
+    cs = (1.0 / g["channel_scales_opt"].astype(np.float32)).astype(np.float16)[None, :]
+    assert np.array_equal(cs.view(np.uint16), g["out_channel_scales"].view(np.uint16))
+    assert np.array_equal(g["theta_in"].astype(np.float16).view(np.uint16), g["out_theta"].view(np.uint16))
+    assert np.array_equal(g["pairs_in"], g["out_pairs"]) and g["out_pairs"].dtype == np.int16
+    assert int(g["bits"]) == 4 and int(g["group_size"]) == 128 and int(g["krot"]) == 8
+    # K5 on the exported layer: x @ pseudo_weight.T == paro_linear(x, buffers)  (optim/qlinear.py:89-123)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, w.shape[1]))
+    pw = po.pseudo_weight(w, g["pairs_in"], g["theta_in"], g["channel_scales_opt"], g["scale"], g["zero_point_float"])
+    y_ref = x @ pw.T
+    y = po.paro_linear(x, g["out_qweight"], g["out_qzeros"], g["out_scales"], g["out_theta"], g["out_pairs"],
+                       g["out_channel_scales"], None, 128, ideal=True)
+    assert po.rel_err(y, y_ref) < 2e-3    # only fp16 storage of scales / channel_scales / theta separates the two
+
+
+# ---- K1..K4: rotation KATs / algebra (rotation.cuh:55-56; optim/qlinear.py:110-120) ----
+
+def _single_pair_idx(K=128):
+    idx = np.arange(K, dtype=np.int16)[None, :]     # pairs (0,1), (2,3), ...
+    return idx
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16", "f32", "ideal", "f16_once"])
+def test_k1_quarter_turn(mode):
+    x = np.arange(1, 129, dtype=np.float64)[None, :] / 16.0
+    theta = np.zeros((1, 64)); theta[0, 0] = np.pi / 2
+    y = po.rotate(x, _single_pair_idx(), theta, None, 128, mode=mode)
+    tol = {"ideal": 1e-12, "f32": 1e-6}.get(mode, 2e-2)
+    assert abs(y[0, 0] - x[0, 1]) <= tol and abs(y[0, 1] + x[0, 0]) <= tol
+    np.testing.assert_allclose(y[0, 2:], x[0, 2:], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16", "f32", "ideal"])
+def test_k2_zero_theta_is_scale(mode):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((4, 256)).astype(np.float16)
+    sc = rng.uniform(0.5, 2, 256).astype(np.float16)
+    idx = po.random_pairs(rng, 8, 256)
+    y = po.rotate(x, idx, np.zeros((8, 128)), sc[None, :], 128, mode=mode)
+    if mode in ("f16", "bf16"):
+        expect = po.round_to(po.round_to(x, mode) * po.round_to(sc, mode)[None, :], mode)
+    else:
+        expect = x.astype(np.float64) * sc.astype(np.float64)[None, :]
+    np.testing.assert_allclose(y, expect, rtol=1e-6)
+
+
+def test_k3_k4_orthogonal_and_inverse():
+    rng = np.random.default_rng(2)
+    K = 384
+    x = rng.standard_normal((7, K))
+    idx = po.random_pairs(rng, 8, K)
+    th = rng.standard_normal((8, K // 2))
+    y = po.rotate(x, idx, th, None, 128, mode="ideal")
+    np.testing.assert_allclose(np.linalg.norm(y.reshape(7, -1, 128), axis=-1),
+                               np.linalg.norm(x.reshape(7, -1, 128), axis=-1), rtol=1e-12)
+    ip, it = po.inverse_rotation_params(idx, th)
+    np.testing.assert_allclose(po.rotate(y, ip, it, None, 128, mode="ideal"), x, atol=1e-12)
+    # half paths stay within half-precision distance of the ideal
+    y16 = po.rotate(x, idx, th, None, 128, mode="f16")
+    assert po.rel_err(y16, y) < 5e-3
+    yb = po.rotate(x, idx, th, None, 128, mode="bf16")
+    assert po.rel_err(yb, y) < 4e-2
+    y1 = po.rotate(x, idx, th, None, 128, mode="f16_once")
+    assert po.rel_err(y1, y) < 2e-3
+
+
+def test_group_size_64_and_krot_1():
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 256))
+    idx = np.stack([np.concatenate([rng.permutation(64) for _ in range(4)])]).astype(np.int16)
+    th = rng.standard_normal((1, 128))
+    y = po.rotate(x, idx, th, None, 64, mode="ideal")
+    np.testing.assert_allclose(np.linalg.norm(y.reshape(2, 4, 64), axis=-1),
+                               np.linalg.norm(x.reshape(2, 4, 64), axis=-1), rtol=1e-12)
+
+
+def test_rotation_arg_validation():
+    rng = np.random.default_rng(5)
+    idx = po.random_pairs(rng, 8, 128)
+    with pytest.raises(RuntimeError):
+        po.rotate(np.zeros((1, 100)), idx[:, :100], np.zeros((8, 50)), None, 128)   # h % GS (rotation.cu:66)
+    with pytest.raises(RuntimeError):
+        po.rotate(np.zeros((1, 128)), idx, np.zeros((4, 64)), None, 128)            # krot mismatch (rotation.cu:114)
+    with pytest.raises(RuntimeError):
+        po.rotate(np.zeros((1, 128)), idx, np.zeros((8, 64)), None, 32)             # group_size (rotation.cu:116-122)
+
+
+# ---- K5..K7: the fused operator ------------------------------------------------
+
+def test_k5_end_to_end_identity():
+    """paro_linear(x, pack(Q(R(W*cs))), channel_scales=1/cs) ~= x @ pseudo_weight.T (optim/qlinear.py:89-123)."""
+    rng = np.random.default_rng(6)
+    N, K = 32, 256
+    w = rng.standard_normal((N, K)) * 0.05
+    cs = rng.uniform(0.5, 2.0, K)
+    idx = po.random_pairs(rng, 8, K)
+    th = rng.standard_normal((8, K // 2)) * 0.2
+    rot = po.rotate(w * cs[None, :], idx, th, None, 128, mode="ideal")
+    sf, zf = po.calc_scales_and_zero_points(rot, 128, 15)
+    q, s2d, z2d = po.quantize_rotated_weight(w, idx, th, cs, sf, zf, 4, 128, rotate_mode="ideal")
+    b = po.to_awq_buffers(q, s2d, z2d)
+    x = rng.standard_normal((4, K))
+    # exact-arithmetic identity (ideal mode): difference comes only from fp16 scale storage
+    y = po.paro_linear(x, b["qweight"], b["qzeros"], b["scales"], th, idx, (1.0 / cs)[None, :], None, 128, ideal=True)
+    ref = x @ po.pseudo_weight(w, idx, th, cs, sf, zf).T
+    assert po.rel_err(y, ref) < 1e-3
+    # and the fp16 operator stays within the BASELINE 1e-2 gate of the ideal
+    y16 = po.paro_linear(x.astype(np.float16), b["qweight"], b["qzeros"], b["scales"], th.astype(np.float16), idx,
+                         (1.0 / cs).astype(np.float16)[None, :], None, 128, act="f16")
+    assert po.rel_err(y16, ref) < 1e-2
+
+
+def test_k6_merged_partitions_equal_concat():
+    L = po.make_layer(10, 256, [64, 32, 32], bias=True)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3, 256)).astype(np.float16)
+    y = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"],
+                              L["sizes"], L["bias"])
+    col = 0
+    parts = []
+    for i, n in enumerate(L["sizes"]):
+        parts.append(po.paro_linear(x, np.ascontiguousarray(L["qweight"][:, col // 8:(col + n) // 8]),
+                                    np.ascontiguousarray(L["qzeros"][:, col // 8:(col + n) // 8]),
+                                    np.ascontiguousarray(L["scales"][:, col:col + n]),
+                                    L["theta"][i], L["pairs"][i], L["channel_scales"][i], None))
+        col += n
+    cat = np.concatenate(parts, -1)
+    expect = po.round_to(cat.astype(np.float64) + L["bias"].astype(np.float64), "f16")
+    np.testing.assert_array_equal(y, expect)
+
+
+def test_k7_row_parallel_shards_sum_to_full():
+    """Row-parallel TP: rotation params narrowed along the input dim (plugin.py:47-50) and the
+    weight rows sliced; the per-rank partial outputs sum to the unsharded result."""
+    L = po.make_layer(12, 512, [64])
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, 512)).astype(np.float16)
+    full = po.paro_linear(x, L["qweight"], L["qzeros"], L["scales"], L["theta"][0], L["pairs"][0],
+                          L["channel_scales"][0], None, ideal=True)
+    tp = 2
+    Kp = 512 // tp
+    acc = 0
+    for r in range(tp):
+        sl = slice(r * Kp, (r + 1) * Kp)
+        acc = acc + po.paro_linear(x[:, sl], L["qweight"][sl], L["qzeros"][r * Kp // 128:(r + 1) * Kp // 128],
+                                   L["scales"][r * Kp // 128:(r + 1) * Kp // 128],
+                                   L["theta"][0][:, r * Kp // 2:(r + 1) * Kp // 2], L["pairs"][0][:, sl],
+                                   L["channel_scales"][0][:, sl], None, ideal=True)
+    np.testing.assert_allclose(acc, full, rtol=1e-10, atol=1e-10)
+
+
+def test_config1_cpu_gate():
+    """BASELINE config 1: single 4096x4096 gs=128 layer, CPU only: fp16 operator within 1e-2 of the ideal."""
+    L = po.make_layer(0, 4096, [4096])
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 4096)).astype(np.float16)
+    args = (L["qweight"], L["qzeros"], L["scales"], L["theta"][0], L["pairs"][0], L["channel_scales"][0])
+    ideal = po.paro_linear(x, *args, None, ideal=True)
+    y16 = po.paro_linear(x, *args, None, act="f16")
+    yb = po.paro_linear(x, *args, None, act="bf16")
+    assert po.rel_err(y16, ideal) < 1e-2
+    assert po.rel_err(yb, ideal) < 3e-2      # bf16 theta/scale casts (rotation.cu:75-78) cost ~3 bits
