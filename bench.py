@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the MI355X-native ParoQuant hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload qwen3-4b] [--no-graph] [--per-shape]
+
+A "step" is ONE batch-1 decode token through the hot path of the named model: every quantised
+linear of every decoder layer (merged qkv with 3 rotations, o_proj, merged gate_up with 2 rotations,
+down_proj), fp16 activations, chained so each launch consumes the previous launch's output
+(attention / norms / activation are outside the hot path -- SURVEY.md section 8 -- and are replaced by
+zero-cost views).  Weights are synthetic (random INT4 in the checkpoint's AWQ format, repacked by
+the product path), distinct per layer, so a step streams the whole model from HBM (Qwen3-4B:
+1.9 GB -- far past the 256 MB Infinity Cache).  The step is captured once in a HIP graph and
+replayed (vLLM captures decode the same way).
+
+At N > 1 the default workload runs N independent replicas (data-parallel decode: one process per
+GPU, no data-path collective; `scaling: weak`).  `--workload llama3-70b-tp` instead shards every
+linear Megatron-style across the N ranks (column-parallel qkv / gate_up, row-parallel o / down with
+an RCCL all-reduce after each row-parallel linear) -- `scaling: strong`.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline      -- the fused GEMV kernel family `paro::gemv_kernel`: algorithmic bytes per launch
+                   (BASELINE.md section 3 formula, averaged over the step's launches) / average launch
+                   duration from HIP events around the timed region on the launch stream.
+  cpu_baseline  -- the C port of the reference algorithm (oracle/paro_cpu.c) timed on the host
+                   cores on a bounded sample (one decoder layer) of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+MODELS = {
+    #              hidden, inter, q_dim, kv_dim, layers
+    "qwen3-0.6b": (1024, 3072, 2048, 1024, 28),
+    "qwen3-4b": (2560, 9728, 4096, 1024, 36),
+    "llama3-8b": (4096, 14336, 4096, 1024, 32),
+    "llama3-70b": (8192, 28672, 8192, 1024, 80),
+}
+
+
+def alg_bytes(K: int, N: int, P: int) -> int:
+    """Algorithmic bytes of one fused GEMV call in the REFERENCE format."""
+    G = K // 128
+    return K * N // 2 + G * N * 2 + G * N // 2 + 2 * K + 2 * N + P * (16 * K + 8 * K + 2 * K)
+
+
+def layer_shapes(model: str, tp: int = 1):
+    """[(name, K, partition sizes, kind)] of one decoder layer (per TP rank)."""
+    h, inter, q, kv, _ = MODELS[model]
+    return [
+        ("qkv_proj", h, [q // tp, kv // tp, kv // tp], "col"),
+        ("o_proj", q // tp, [h], "row"),
+        ("gate_up_proj", h, [inter // tp, inter // tp], "col"),
+        ("down_proj", inter // tp, [h], "row"),
+    ]
+
+
+def synth_packed(K: int, sizes, dev, gen: torch.Generator):
+    """Random layer in checkpoint format (SURVEY section 8d synthetic inputs), unit gain, repacked by the
+    product path (torch.ops.paro.repack_awq)."""
+    from paroquant_amd.linear import PackedParoWeights
+    from oracle import paro_oracle as po   # bench-only: pair generator for the synthetic inputs
+    N = sum(sizes)
+    P = len(sizes)
+    G = K // 128
+    qweight = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    qzeros = torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    gain = 1.0 / (6.52 * (K ** 0.5) * (1.75 ** 0.5))        # unit RMS gain through rotate + dequant matmul
+    scales = ((torch.rand(G, N, device=dev, generator=gen) + 0.5) * gain).half()
+    theta = (torch.randn(P, 8, K // 2, device=dev, generator=gen) * 0.1).half()
+    rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=dev).item()))
+    pairs = torch.from_numpy(np.stack([po.random_pairs(rng, 8, K) for _ in range(P)])).to(dev)
+    cs = (torch.rand(P, 1, K, device=dev, generator=gen) * 1.5 + 0.5).half()
+    return PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes)
+
+
+class DecodeStack:
+    """All quantised linears of `n_layers` decoder layers, chained for one batch-1 decode token."""
+
+    def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0):
+        self.model, self.tp, self.rank = model, tp, rank
+        h, inter, q, kv, L = MODELS[model]
+        self.n_layers = n_layers or L
+        self.hidden, self.q_local, self.inter_local = h, q // tp, inter // tp
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 1000 * rank)
+        self.shapes = layer_shapes(model, tp)
+        self.layers = []
+        for _ in range(self.n_layers):
+            self.layers.append([synth_packed(K, sizes, dev, gen) for (_, K, sizes, _) in self.shapes])
+        self.x = torch.randn(1, h, device=dev, dtype=torch.float16, generator=gen)
+        self.launches_per_step = 4 * self.n_layers
+        self.bytes_per_step = self.n_layers * sum(alg_bytes(K, sum(s), len(s)) for (_, K, s, _) in self.shapes)
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        h = x
+        tp = self.tp
+        for qkv, o, gu, down in self.layers:
+            a = qkv.apply(h)[:, : self.q_local]            # attention stand-in: a view, no kernel
+            h = o.apply(a)
+            if tp > 1:
+                dist.all_reduce(h)                          # RowParallelLinear all-reduce (RCCL over xGMI)
+            d = gu.apply(h)[:, : self.inter_local]         # SiLU*mul stand-in: a view, no kernel
+            h = down.apply(d)
+            if tp > 1:
+                dist.all_reduce(h)
+        return h
+
+
+def time_steps(fn, steps: int, warmup: int, world: int, dev):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = t[0].item(), t[1].item()
+    return wall, ev_ms
+
+
+def per_shape_table(model: str, dev, reps: int = 400):
+    """Per-linear GEMV timing (events around `reps` back-to-back launches cycling >= 1 GiB of distinct
+    weights so neither L2 nor the Infinity Cache can serve them)."""
+    rows = []
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    for name, K, sizes, _ in layer_shapes(model):
+        nb = alg_bytes(K, sum(sizes), len(sizes))
+        copies = max(2, min(64, int((1 << 30) // nb) + 1))
+        packs = [synth_packed(K, sizes, dev, gen) for _ in range(copies)]
+        x = torch.randn(1, K, device=dev, dtype=torch.float16, generator=gen)
+        for i in range(20):
+            packs[i % copies].apply(x)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(reps):
+                packs[i % copies].apply(x)
+        g.replay()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        rows.append({"linear": name, "K": K, "N": sum(sizes), "P": len(sizes), "bytes": nb, "us_per_launch": round(us, 3),
+                     "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4)})
+        del packs, g
+        torch.cuda.empty_cache()
+    return rows
+
+
+def cpu_baseline(model: str, budget_s: float = 20.0):
+    """Time the C port of the reference algorithm on ONE decoder layer (1/n_layers of a step)."""
+    from oracle import paro_cpu as pc
+    from oracle import paro_oracle as po
+    _, _, _, _, L = MODELS[model]
+    rng = np.random.default_rng(0)
+    layers = []
+    for name, K, sizes, _ in layer_shapes(model):
+        N, P, G = sum(sizes), len(sizes), K // 128
+        layers.append(dict(
+            qweight=rng.integers(-2**31, 2**31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32),
+            qzeros=rng.integers(-2**31, 2**31 - 1, size=(G, N // 8), dtype=np.int64).astype(np.int32),
+            scales=rng.uniform(0.002, 0.02, size=(G, N)).astype(np.float16),
+            theta=(rng.standard_normal((P, 8, K // 2)) * 0.1).astype(np.float16),
+            pairs=np.stack([po.random_pairs(rng, 8, K) for _ in range(P)]),
+            channel_scales=rng.uniform(0.5, 2.0, size=(P, 1, K)).astype(np.float16), sizes=sizes, K=K))
+    xs = [rng.standard_normal((1, l["K"])).astype(np.float16) for l in layers]
+    pc.load()
+    times = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for l, x in zip(layers, xs):
+            pc.linear_f16(x, l)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 3 and (time.perf_counter() - t_start > budget_s or len(times) >= 20):
+            break
+    t_layer = float(np.median(times))
+    return {"value": round(1.0 / (t_layer * L), 4), "unit": "tokens/s", "cores": pc.threads(), "kind": "port",
+            "sample": f"1 of {L} decoder layers (4 fused linears, M=1) x {len(times)} runs, median {t_layer * 1e3:.1f} ms/layer; "
+                      f"tokens/s = 1 / (ms_per_layer * {L})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="qwen3-4b", choices=list(MODELS) + ["llama3-70b-tp"])
+    ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the ParoQuant hot path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import paroquant_amd  # noqa: F401
+    from paroquant_amd import _native
+    _native.load()
+
+    tp_mode = args.workload.endswith("-tp")
+    model = args.workload[:-3] if tp_mode else args.workload
+    tp = world if tp_mode else 1
+    stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank)
+
+    out = stack.step(stack.x)           # eager warm-up (also sizes the shared workspace)
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(out.float()).all(), "non-finite activations in the synthetic decode chain"
+
+    use_graph = not args.no_graph
+    if use_graph:
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            stack.step(stack.x)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stack.step(stack.x)
+        fn = graph.replay
+    else:
+        fn = lambda: stack.step(stack.x)
+
+    wall, ev_ms = time_steps(fn, args.steps, args.warmup, world, dev)
+    ms_per_step = wall * 1e3 / args.steps
+    replicas = 1 if tp_mode else world
+    tokens_per_s = replicas * args.steps / wall
+
+    launches = stack.launches_per_step
+    us_per_launch = ev_ms * 1e3 / (args.steps * launches)
+    bytes_per_launch = stack.bytes_per_step / launches
+    achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s
+    roofline = {"bound": "hbm", "kernel": "paro::gemv_kernel (fused rotate+INT4 GEMV, all launches of the step)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
+                "launches_per_step": launches,
+                "note": "launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps)"}
+
+    result = {
+        "metric": "decode tokens/s through the ParoQuant quantised-linear hot path (fused rotation + INT4 GEMV), batch 1",
+        "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f16 activations x int4 weights (fp32 accumulate)",
+        "data": "synthetic (random INT4 AWQ-format weights, random fp16 activations, random perfect-matching pairs)",
+        "config": {"workload": f"{model}-PARO batch-1 decode: {stack.n_layers} layers x (qkv[P=3], o, gate_up[P=2], down) "
+                               f"W4A16 g128 krot8, {'TP=%d' % tp if tp_mode else 'replica per GPU'}",
+                   "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
+                   "bytes_per_token": stack.bytes_per_step, "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world)},
+        "roofline": roofline,
+    }
+
+    if rank == 0:
+        if args.per_shape:
+            for row in per_shape_table(model, dev):
+                print(json.dumps(row), file=sys.stderr, flush=True)
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""ctypes binding of ``libparo_mi355x.so`` (C ABI declared in ``include/paro_abi.h``).
+
+The library is hand-written HIP for gfx950, built in-tree by ``__graft_entry__.build()`` /
+``make -C paroquant_amd/csrc``.  There is NO CPU or PyTorch fallback: if the shared object is
+missing or a call fails, the product path raises (the reference behaves the same way -- its
+``rotation::rotate`` exists for the CUDA dispatch key only, rotation.cu:133-135, and
+``ParoQuantHfQuantizer.validate_environment`` raises without a GPU, transformers/quantizer.py:78-80).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
+
+PARO_ABI_VERSION = 1
+PARO_MAX_PARTS = 8
+PARO_WS_COUNTER_BYTES = 16384
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libparo_mi355x.so")
+
+EXPORTS = (
+    "paro_abi_version",
+    "paro_last_error",
+    "paro_rotate",
+    "paro_packed_qweight_bytes",
+    "paro_packed_qzeros_bytes",
+    "paro_repack_awq",
+    "paro_linear_workspace_bytes",
+    "paro_w4a16_gemv",
+    "paro_w4a16_gemm",
+    "paro_w4a16_linear",
+    "paro_dequant_packed",
+)
+
+
+class ParoLinearDesc(Structure):
+    """``paro_linear_t`` (include/paro_abi.h)."""
+
+    _fields_ = [
+        ("K", c_int64),
+        ("N", c_int64),
+        ("n_parts", c_int32),
+        ("krot", c_int32),
+        ("part_cols", c_int32 * PARO_MAX_PARTS),
+        ("act_dtype", c_int32),
+        ("reserved", c_int32),
+        ("wq", c_void_p),
+        ("zq", c_void_p),
+        ("scales", c_void_p),
+        ("pairs", c_void_p),
+        ("theta", c_void_p),
+        ("channel_scales", c_void_p),
+        ("bias", c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared object (once) and declare every prototype; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"paroquant_amd: native library not found at {_LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C paroquant_amd/csrc`. "
+            "There is no CPU fallback for the ParoQuant hot path."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.paro_abi_version.restype = c_int
+    lib.paro_abi_version.argtypes = []
+    lib.paro_last_error.restype = c_char_p
+    lib.paro_last_error.argtypes = []
+    lib.paro_rotate.restype = c_int
+    lib.paro_rotate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                c_int, c_int, c_void_p]
+    lib.paro_packed_qweight_bytes.restype = c_int64
+    lib.paro_packed_qweight_bytes.argtypes = [c_int64, c_int64]
+    lib.paro_packed_qzeros_bytes.restype = c_int64
+    lib.paro_packed_qzeros_bytes.argtypes = [c_int64, c_int64]
+    lib.paro_repack_awq.restype = c_int
+    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    lib.paro_linear_workspace_bytes.restype = c_int64
+    lib.paro_linear_workspace_bytes.argtypes = [POINTER(ParoLinearDesc), c_int64]
+    lib.paro_w4a16_gemv.restype = c_int
+    lib.paro_w4a16_gemv.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                    c_int, c_void_p]
+    lib.paro_w4a16_gemm.restype = c_int
+    lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.paro_w4a16_linear.restype = c_int
+    lib.paro_w4a16_linear.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                      c_void_p]
+    lib.paro_dequant_packed.restype = c_int
+    lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
+    if lib.paro_abi_version() != PARO_ABI_VERSION:
+        raise RuntimeError(f"paroquant_amd: ABI version mismatch (library {lib.paro_abi_version()}, "
+                           f"binding {PARO_ABI_VERSION})")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Negative return code -> RuntimeError(paro_last_error()), mirroring TORCH_CHECK (rotation.cu:66,114)."""
+    if rc != 0:
+        msg = load().paro_last_error()
+        raise RuntimeError((msg or b"unknown error").decode("utf-8", "replace"))
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return DTYPE_F16
+    if dt == torch.bfloat16:
+        return DTYPE_BF16
+    if dt == torch.float32:
+        return DTYPE_F32
+    raise RuntimeError(f"rotate supports Float, Half, and BFloat16, got {dt}")   # rotation.cu:92
+
+
+def current_stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,179 @@
+// Shared device/host helpers for libparo_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "paro_abi.h"
+
+namespace paro {
+
+// ---- error reporting (thread-local, no exceptions across the ABI) -------------
+char* error_buffer();
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PARO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return PARO_OK;
+}
+
+// ---- vector types ---------------------------------------------------------------
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- scalar conversions -----------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {  // round-to-nearest-even
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) {
+  return (float)__builtin_bit_cast(f16, b);
+}
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+  return __builtin_bit_cast(unsigned short, (f16)f);
+}
+
+// Activation-type traits: 16-bit storage, MFMA flavour, INT4 -> (16 + q) magic unpack.
+template <typename T>
+struct Act;
+
+template <>
+struct Act<f16> {
+  typedef f16x8 vec8;
+  static constexpr int kDtype = PARO_DTYPE_F16;
+  static constexpr unsigned kMask = 0x03C003C0u;   // nibble lands on mantissa bits 6..9
+  static constexpr unsigned kMagic = 0x4C004C00u;  // 16.0h | nibble<<6  == 16 + q exactly
+  static constexpr unsigned kOnes = 0x3C003C00u;   // (1.0h, 1.0h)
+  __device__ static __forceinline__ float to_f32(unsigned short b) { return f16_bits_to_f32(b); }
+  __device__ static __forceinline__ unsigned short from_f32(float f) { return f32_to_f16_bits(f); }
+  // word w holds 8 nibbles; out[v] = (16 + nibble v, 16 + nibble v+4) as a packed pair
+  __device__ static __forceinline__ void unpack(unsigned w, unsigned (&o)[4]) {
+    o[0] = ((w << 6) & kMask) | kMagic;
+    o[1] = ((w << 2) & kMask) | kMagic;
+    o[2] = ((w >> 2) & kMask) | kMagic;
+    o[3] = ((w >> 6) & kMask) | kMagic;
+  }
+  __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <>
+struct Act<bf16> {
+  typedef bf16x8 vec8;
+  static constexpr int kDtype = PARO_DTYPE_BF16;
+  static constexpr unsigned kMask = 0x00780078u;   // mantissa bits 3..6
+  static constexpr unsigned kMagic = 0x41804180u;  // 16.0bf16 | nibble<<3 == 16 + q exactly
+  static constexpr unsigned kOnes = 0x3F803F80u;
+  __device__ static __forceinline__ float to_f32(unsigned short b) { return bf16_bits_to_f32(b); }
+  __device__ static __forceinline__ unsigned short from_f32(float f) { return f32_to_bf16_bits(f); }
+  __device__ static __forceinline__ void unpack(unsigned w, unsigned (&o)[4]) {
+    o[0] = ((w << 3) & kMask) | kMagic;
+    o[1] = ((w >> 1) & kMask) | kMagic;
+    o[2] = ((w >> 5) & kMask) | kMagic;
+    o[3] = ((w >> 9) & kMask) | kMagic;
+  }
+  __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// Load a rotation/quantisation parameter of dtype code `dt` as fp32.
+__device__ __forceinline__ float load_param(const void* p, int64_t i, int dt) {
+  if (dt == PARO_DTYPE_F16) return f16_bits_to_f32(((const unsigned short*)p)[i]);
+  if (dt == PARO_DTYPE_BF16) return bf16_bits_to_f32(((const unsigned short*)p)[i]);
+  return ((const float*)p)[i];
+}
+
+// sin/cos of an angle in radians on the transcendental unit (v_sin_f32 / v_cos_f32 take revolutions).
+__device__ __forceinline__ void fast_sincos(float theta, float& s, float& c) {
+  const float rev = theta * 0.15915494309189535f;
+  s = __builtin_amdgcn_sinf(rev);
+  c = __builtin_amdgcn_cosf(rev);
+}
+
+// ---------------------------------------------------------------------------------
+// One wavefront applies all `krot` Givens stages to ONE 128-channel span held in
+// wave-private LDS.  Lane l owns pair l of every stage: (i, j) = the l-th int16 pair
+// of the span, theta = the l-th angle.  Restates rotation.cu:36-39 +
+// rotation.cuh:53-56/:143-153 with fp32 state and no per-stage rounding.
+//
+// LDS layout: xr[(chunk * 128 + channel) * VW + v], rows = NCH * VW, row = chunk * VW + v.
+// A span is 128 channels = one GS=128 group or two GS=64 groups (lanes 32..63 then
+// index the upper 64 channels: `sub` = 64 for those lanes).
+//
+// No workgroup barrier is needed: the span is private to this wave and a wave's DS
+// operations execute in order; the wavefront fence stops the compiler reordering.
+// ---------------------------------------------------------------------------------
+template <int VW, int NCH>
+__device__ __forceinline__ void rotate_stage(float* xr, unsigned ij, float th, int sub) {
+  typedef float V __attribute__((ext_vector_type(VW)));
+  const int i = (int)(ij & 0xffffu) + sub;
+  const int j = (int)(ij >> 16) + sub;
+  float s, c;
+  fast_sincos(th, s, c);
+  V a[NCH], b[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    a[ch] = *(const V*)(xr + (ch * 128 + i) * VW);
+    b[ch] = *(const V*)(xr + (ch * 128 + j) * VW);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    *(V*)(xr + (ch * 128 + i) * VW) = a[ch] * c + b[ch] * s;
+    *(V*)(xr + (ch * 128 + j) * VW) = b[ch] * c - a[ch] * s;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Runtime-krot form: the next stage's coefficients are fetched under the current stage's LDS work.
+template <int VW, int NCH>
+__device__ __forceinline__ void rotate_span_lds(float* xr, const int16_t* __restrict__ idx_span,
+                                                int64_t idx_stride, const void* __restrict__ theta,
+                                                int64_t theta_off, int64_t theta_stride, int theta_dt,
+                                                int krot, int lane, int sub) {
+  unsigned ij = *(const unsigned*)(idx_span + 2 * lane);
+  float th = load_param(theta, theta_off + lane, theta_dt);
+  for (int r = 0; r < krot; ++r) {
+    unsigned ij_next = 0;
+    float th_next = 0.f;
+    if (r + 1 < krot) {
+      ij_next = *(const unsigned*)(idx_span + (int64_t)(r + 1) * idx_stride + 2 * lane);
+      th_next = load_param(theta, theta_off + (int64_t)(r + 1) * theta_stride + lane, theta_dt);
+    }
+    rotate_stage<VW, NCH>(xr, ij, th, sub);
+    ij = ij_next;
+    th = th_next;
+  }
+}
+
+// Compile-time-krot form: all coefficients are already in registers (loaded BEFORE the weight
+// tiles were requested, so waiting for them does not wait for the tiles: vmcnt retires in order).
+template <int VW, int NCH, int KROT>
+__device__ __forceinline__ void rotate_span_regs(float* xr, const unsigned (&ij)[KROT], const float (&th)[KROT],
+                                                 int sub) {
+#pragma unroll
+  for (int r = 0; r < KROT; ++r) rotate_stage<VW, NCH>(xr, ij[r], th[r], sub);
+}
+
+}  // namespace paro

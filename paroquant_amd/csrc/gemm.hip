@@ -1,0 +1,228 @@
+// W4A16 MFMA GEMM for gfx950 (prefill / large-batch path):  y = rotate(x) @ dequant(W) (+ bias).
+//
+// Two steps behind one ABI call (paro_w4a16_gemm):
+//   1. rotate pre-pass (rotate.hip) writes the rotated activations once per merged partition
+//      into the caller's workspace  xrot[p][rows][K]  (the reference re-launches `rotate` per
+//      partition too -- vllm/plugin.py:288-290 -- but then hands fp16 x to a separate Marlin GEMM);
+//   2. this kernel: 128 x 128 output tile per 256-thread workgroup, K walked one quantisation
+//      group (128) at a time.  The A tile goes through LDS in full 256-byte rows with a 16-slot XOR
+//      swizzle (conflict-free ds_read_b128 fragments); the INT4 B tiles are NOT staged: each wave
+//      loads its four 1-KiB tiles straight to VGPRs in MFMA B-fragment order (paro_repack_awq),
+//      unpacks to (16 + q) halves and feeds v_mfma_f32_16x16x32.  Scale and zero point are applied
+//      per (group, column) on the fp32 group result, exactly as in gemv.hip:
+//          acc += s * (D_g - (16 + z) * sum_k x_k)
+#include "common.hpp"
+
+namespace paro {
+
+int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
+                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st);
+int validate_linear(const paro_linear_t* L);
+
+struct GemmArgs {
+  const u32x4* wq;
+  const unsigned* zq;
+  const unsigned short* scales;
+  const unsigned short* bias;
+  const unsigned short* xrot;  // [nparts][rows][K]
+  unsigned short* y;
+  int K, N, G, rows, nparts;
+  int part_tile_start[PARO_MAX_PARTS + 1];
+  int part_cb_start[PARO_MAX_PARTS + 1];
+};
+
+constexpr int BM = 128;
+constexpr int BN_TILES = 8;  // 128 columns per workgroup
+
+template <typename AT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+  typedef Act<AT> A;
+  typedef typename A::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BM * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int cb = blockIdx.x;
+  const int row0 = blockIdx.y * BM;
+
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < PARO_MAX_PARTS; ++q)
+    if (q < a.nparts && cb >= a.part_cb_start[q]) p = q;
+  const int tile0 = a.part_tile_start[p] + (cb - a.part_cb_start[p]) * BN_TILES + wc * 4;
+  const int nt = max(0, min(4, a.part_tile_start[p + 1] - tile0));
+  const unsigned short* xp = a.xrot + (int64_t)p * a.rows * a.K;
+
+  const int n = lane & 15, mq = lane >> 4;
+  const int NW = a.N >> 3;
+
+  // staging map: chunk c -> row (tid >> 4) + 16 c, 16-byte slot tid & 15
+  const int srow = tid >> 4, sslot = tid & 15;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 stg[8];
+  u32x4 qv[4];
+  unsigned short sraw[4];
+  unsigned zw[4];
+
+  auto issue_loads = [&](int g) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int row = row0 + srow + 16 * c;
+      stg[c] = (u32x4){0u, 0u, 0u, 0u};
+      if (row < a.rows) stg[c] = *(const u32x4*)(xp + (int64_t)row * a.K + g * 128 + sslot * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nt) {
+        const int t = tile0 + j;
+        qv[j] = *(a.wq + ((int64_t)t * a.G + g) * 64 + lane);
+        sraw[j] = a.scales[(int64_t)g * a.N + t * 16 + n];
+        zw[j] = a.zq[(int64_t)g * NW + t * 2 + (n >> 3)];
+      }
+    }
+  };
+
+  issue_loads(0);
+  for (int g = 0; g < a.G; ++g) {
+    __syncthreads();  // every wave is done reading the previous A tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int row = srow + 16 * c;
+      *(u32x4*)(lds + row * 256 + ((sslot ^ (row & 15)) << 4)) = stg[c];
+    }
+    u32x4 qc[4];
+    unsigned short sc[4];
+    unsigned zc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qc[j] = qv[j];
+      sc[j] = sraw[j];
+      zc[j] = zw[j];
+    }
+    __syncthreads();
+    if (g + 1 < a.G) issue_loads(g + 1);  // next group's A rows + INT4 tiles fly under this group's MFMAs
+
+    vec8 af[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = wr * 64 + rt * 16 + n;  // MFMA row m' = lane & 15
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[rt][i] = *(const vec8*)(lds + row * 256 + (((4 * i + mq) ^ (row & 15)) << 4));
+    }
+    f32x4 sx[4];
+    {
+      const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+      const vec8 ob = __builtin_bit_cast(vec8, ones);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        sx[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sx[rt] = A::mfma(af[rt][i], ob, sx[rt]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nt) {
+        f32x4 d[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) d[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned w4[4];
+          A::unpack(qc[j][i], w4);
+          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+          const vec8 bf = __builtin_bit_cast(vec8, wv);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) d[rt] = A::mfma(af[rt][i], bf, d[rt]);
+        }
+        const float s = f16_bits_to_f32(sc[j]);
+        const float zf = (float)(16 + ((zc[j] >> (4 * (n & 7))) & 0xFu));
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[rt][j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][r], d[rt][r]), acc[rt][j][r]);
+      }
+    }
+  }
+
+  // epilogue: D layout row = 4 * (lane >> 4) + r, col = lane & 15
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < nt) {
+      const int col = (tile0 + j) * 16 + n;
+      const float bv = a.bias ? A::to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + wr * 64 + rt * 16 + 4 * mq + r;
+          if (row < a.rows) a.y[(int64_t)row * a.N + col] = A::from_f32(acc[rt][j][r] + bv);
+        }
+    }
+  }
+}
+
+}  // namespace paro
+
+extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  using namespace paro;
+  int rc = validate_linear(L);
+  if (rc != PARO_OK) return rc;
+  if (rows == 0) return PARO_OK;
+  if (rows < 0 || rows > 0x7fffffff) return fail(PARO_ERR_INVALID, "rows out of range");
+  if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
+  const int64_t need = PARO_WS_COUNTER_BYTES + (int64_t)L->n_parts * rows * L->K * 2;
+  if (!workspace || workspace_bytes < need)
+    return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES);
+  for (int p = 0; p < L->n_parts; ++p) {
+    rc = launch_rotate(x, xrot + (int64_t)p * rows * L->K, L->pairs + (int64_t)p * L->krot * L->K,
+                       (const unsigned short*)L->theta + (int64_t)p * L->krot * (L->K / 2),
+                       (const unsigned short*)L->channel_scales + (int64_t)p * L->K, rows, L->K, L->krot, 128,
+                       L->act_dtype, PARO_DTYPE_F16, st);
+    if (rc != PARO_OK) return rc;
+  }
+  GemmArgs a;
+  a.wq = (const u32x4*)L->wq;
+  a.zq = (const unsigned*)L->zq;
+  a.scales = (const unsigned short*)L->scales;
+  a.bias = (const unsigned short*)L->bias;
+  a.xrot = xrot;
+  a.y = (unsigned short*)y;
+  a.K = (int)L->K;
+  a.N = (int)L->N;
+  a.G = (int)(L->K / 128);
+  a.rows = (int)rows;
+  a.nparts = L->n_parts;
+  int tiles = 0, cbs = 0;
+  for (int i = 0; i < PARO_MAX_PARTS; ++i) {
+    a.part_tile_start[i] = tiles;
+    a.part_cb_start[i] = cbs;
+    if (i < L->n_parts) {
+      const int pt = L->part_cols[i] / 16;
+      tiles += pt;
+      cbs += (pt + BN_TILES - 1) / BN_TILES;
+    }
+  }
+  a.part_tile_start[PARO_MAX_PARTS] = tiles;
+  a.part_cb_start[PARO_MAX_PARTS] = cbs;
+  const int64_t rb = (rows + BM - 1) / BM;
+  if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * BM);
+  dim3 grid((unsigned)cbs, (unsigned)rb);
+  if (L->act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(gemm_kernel<bf16>, grid, dim3(256), 0, st, a);
+  return check_launch("paro_w4a16_gemm");
+}

@@ -1,0 +1,155 @@
+"""``RotateQuantizedLinear`` -- the HF-side operator of the reference, backed by the fused
+MI355X kernels.
+
+Same constructor, same flat buffer names / dtypes / shapes and the same ``forward`` contract as
+``paroquant/inference/backends/transformers/modules.py:16-71`` so existing ``*-PARO`` checkpoints
+load unchanged through ``from_pretrained`` (state-dict keys ``...q_proj.qweight``,
+``...q_proj.theta`` ... match directly, modules.py:19-22).  The difference is underneath:
+``rotate -> AutoAWQ WQLinearMMFunction`` (two launches + a third-party GEMM) becomes ONE call of
+``torch.ops.paro.w4a16_linear`` on a one-time CDNA4 repack of the AWQ buffers.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def pad_partitions(qweight, qzeros, scales, sizes, pack: int = 8, multiple: int = 16):
+    """Pad every merged partition's column count up to ``multiple`` with zero weights / zero scales
+    (the reference pads N to the Marlin tile the same way, vllm/plugin.py:210-217).
+    Returns ``(qweight, qzeros, scales, padded_sizes)``; a no-op when nothing needs padding."""
+    sizes = [int(s) for s in sizes]
+    padded = [((s + multiple - 1) // multiple) * multiple for s in sizes]
+    if padded == sizes:
+        return qweight, qzeros, scales, padded
+    F = torch.nn.functional
+    qws = qweight.split([s // pack for s in sizes], dim=1)
+    qzs = qzeros.split([s // pack for s in sizes], dim=1)
+    scs = scales.split(sizes, dim=1)
+    qweight = torch.cat([F.pad(t, (0, (p - s) // pack)) for t, s, p in zip(qws, sizes, padded)], dim=1)
+    qzeros = torch.cat([F.pad(t, (0, (p - s) // pack)) for t, s, p in zip(qzs, sizes, padded)], dim=1)
+    scales = torch.cat([F.pad(t, (0, p - s)) for t, s, p in zip(scs, sizes, padded)], dim=1)
+    return qweight.contiguous(), qzeros.contiguous(), scales.contiguous(), padded
+
+
+class PackedParoWeights:
+    """Kernel-ready parameters of one (possibly merged) ParoQuant linear.
+
+    Built once from checkpoint-format tensors (``cli/convert.py:268-277``):
+      qweight int32 [K, N/8], qzeros int32 [K/128, N/8], scales f16 [K/128, N],
+      theta f16 [P, krot, K/2], pairs int16 [P, krot, K], channel_scales f16 [P, 1, K].
+    Takes the place of the Marlin-repacked tensors the reference stashes on the layer in
+    ``process_weights_after_loading`` (vllm/plugin.py:251-279).
+    """
+
+    def __init__(self, qweight, qzeros, scales, theta, pairs, channel_scales, partition_sizes: Sequence[int],
+                 bias: Optional[torch.Tensor] = None, group_size: int = 128, bits: int = 4):
+        if bits != 4:
+            raise ValueError(f"Unsupported bits={bits}. Supported: [4]")          # plugin.py:84-85
+        if group_size != 128:
+            raise ValueError(f"Unsupported group_size={group_size}; the fused kernels need 128 "
+                             "(rotation group is fixed at 128 at inference, modules.py:60)")
+        self.partition_sizes = [int(s) for s in partition_sizes]
+        K = qweight.shape[0]
+        N = qweight.shape[1] * 8
+        if sum(self.partition_sizes) != N:
+            raise ValueError(f"partition sizes {self.partition_sizes} do not sum to out_features {N}")
+        if any(s % 16 for s in self.partition_sizes):
+            raise ValueError(f"partition sizes must be multiples of 16, got {self.partition_sizes}")
+        P = len(self.partition_sizes)
+        if theta.dim() == 2:
+            theta, pairs = theta[None], pairs[None]
+        channel_scales = channel_scales.reshape(P, K)
+        self.K, self.N = K, N
+        self.wq, self.zq = torch.ops.paro.repack_awq(qweight, qzeros)
+        self.scales = scales.to(torch.float16).contiguous()
+        self.theta = theta.to(torch.float16).contiguous()
+        self.pairs = pairs.to(torch.int16).contiguous()
+        self.channel_scales = channel_scales.to(torch.float16).contiguous()
+        self.bias = bias
+        self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N))
+
+    def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b = self.bias if bias is None else bias
+        if b is not None and b.dtype != x.dtype:
+            b = b.to(x.dtype)
+        return torch.ops.paro.w4a16_linear(x, self.wq, self.zq, self.scales, self.pairs, self.theta,
+                                           self.channel_scales, b, self.partition_sizes, self.workspace)
+
+    def nbytes(self) -> int:
+        ts = [self.wq, self.zq, self.scales, self.theta, self.pairs, self.channel_scales]
+        return sum(t.numel() * t.element_size() for t in ts)
+
+
+class RotateQuantizedLinear(nn.Module):
+    """Pairwise Givens rotation + INT4 quantized matmul (fused CDNA4 kernels).
+
+    All parameters are stored flat (no submodules), so state dict keys like ``gate_proj.theta`` and
+    ``gate_proj.qweight`` match checkpoint naming directly (reference modules.py:16-55).
+    """
+
+    def __init__(
+        self,
+        in_features: int,
+        out_features: int,
+        bias: bool = False,
+        group_size: int = 128,
+        bits: int = 4,
+        krot: int = 8,
+    ):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.w_bit = bits
+        self.group_size = group_size
+
+        pack = 32 // bits
+        n_groups = in_features // group_size
+
+        # Rotation buffers (modules.py:43-46)
+        self.register_buffer("theta", torch.zeros(krot, in_features // 2, dtype=torch.float16))
+        self.register_buffer("pairs", torch.zeros(krot, in_features, dtype=torch.int16))
+        self.register_buffer("channel_scales", torch.ones(1, in_features, dtype=torch.float16))
+
+        # AWQ quantized weight buffers (modules.py:48-50)
+        self.register_buffer("qweight", torch.zeros(in_features, out_features // pack, dtype=torch.int32))
+        self.register_buffer("qzeros", torch.zeros(n_groups, out_features // pack, dtype=torch.int32))
+        self.register_buffer("scales", torch.zeros(n_groups, out_features, dtype=torch.float16))
+
+        if bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float16))
+        else:
+            self.bias = None
+        self._packed: Optional[PackedParoWeights] = None
+
+    def prepare(self) -> "RotateQuantizedLinear":
+        """One-time repack of the checkpoint buffers into the CDNA4 tile layout (device side).
+
+        Called lazily by ``forward``; call it explicitly after loading weights (the HF quantizer does,
+        in ``_process_model_after_weight_loading``) so nothing allocates inside a captured HIP graph."""
+        if not self.qweight.is_cuda:
+            raise RuntimeError("ParoQuant requires a GPU: RotateQuantizedLinear has no CPU path "
+                               "(reference: transformers/quantizer.py:78-80)")
+        qw, qz, sc, padded = pad_partitions(self.qweight, self.qzeros, self.scales, [self.out_features])
+        bias = self.bias
+        if bias is not None and padded[0] != self.out_features:
+            bias = torch.nn.functional.pad(bias, (0, padded[0] - self.out_features))
+        self._packed = PackedParoWeights(qw, qz, sc, self.theta, self.pairs, self.channel_scales, padded, bias,
+                                         self.group_size, self.w_bit)
+        return self
+
+    def _apply(self, fn, *args, **kwargs):   # .to()/.cuda() invalidate the packed copy
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dtype in (torch.float16, torch.bfloat16), f"Expected float16 input, got {x.dtype}"   # modules.py:59
+        if self._packed is None:
+            self.prepare()
+        y = self._packed.apply(x)
+        return y if y.shape[-1] == self.out_features else y[..., : self.out_features]

@@ -1,0 +1,264 @@
+"""Torch operator surface of the MI355X-native ParoQuant hot path.
+
+Registers, with the reference's exact schema,
+
+    torch.ops.rotation.rotate(Tensor x, Tensor idx_ij, Tensor theta, Tensor? scales=None,
+                              int group_size=128) -> Tensor
+
+(reference: ``TORCH_LIBRARY(rotation)`` at paroquant/kernels/cuda/rotation.cu:128-135, fake kernel at
+paroquant/kernels/cuda/__init__.py:54-61) and the fused operator this build adds behind
+``RotateQuantizedLinear`` / ``ParoQuantLinearMethod``:
+
+    torch.ops.paro.w4a16_linear(x, wq, zq, scales, pairs, theta, channel_scales, bias?,
+                                partition_sizes, workspace) -> Tensor
+    torch.ops.paro.repack_awq(qweight, qzeros) -> (wq, zq)
+
+All device work goes through the C ABI of ``libparo_mi355x.so`` (``_native``) on torch's current
+HIP stream; implementations exist for the GPU dispatch key only, exactly like the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as nat
+
+_ROTATE_SCHEMA = "rotate(Tensor x, Tensor idx_ij, Tensor theta, Tensor? scales=None, int group_size=128) -> Tensor"
+
+# --------------------------------------------------------------------------------------
+# rotation::rotate
+# --------------------------------------------------------------------------------------
+
+
+def _rotate_impl(x: torch.Tensor, idx_ij: torch.Tensor, theta: torch.Tensor,
+                 scales: Optional[torch.Tensor] = None, group_size: int = 128) -> torch.Tensor:
+    lib = nat.load()
+    # same checks, same order, same messages as rotate_dynamic / rotate_launcher (rotation.cu:111-124,62-66)
+    if theta.size(0) != idx_ij.size(0):
+        raise RuntimeError("theta.size(0) must equal idx_ij.size(0)")
+    if idx_ij.dtype != torch.int16:
+        raise RuntimeError(f"idx_ij must be int16, got {idx_ij.dtype}")
+    h = x.size(-1)
+    x = x.contiguous()                      # the reference reads raw data_ptr (rotation.cu:48)
+    idx_ij = idx_ij.contiguous()
+    theta = theta.contiguous()
+    pd = theta.dtype
+    if scales is not None and scales.numel() > 0:
+        scales = scales.reshape(-1).to(dtype=pd).contiguous()
+        if scales.numel() != h:
+            raise RuntimeError(f"scales must have {h} elements, got {scales.numel()}")
+        s_ptr = scales.data_ptr()
+    else:
+        s_ptr = None
+    out = torch.empty_like(x)
+    rows = x.numel() // h if h > 0 else 0
+    nat.check(lib.paro_rotate(x.data_ptr(), out.data_ptr(), idx_ij.data_ptr(), theta.data_ptr(), s_ptr, rows, h,
+                              int(theta.size(0)), int(group_size), nat.dtype_code(x.dtype), nat.dtype_code(pd),
+                              nat.current_stream_ptr(x.device)))
+    return out
+
+
+def _rotate_fake(x, idx_ij, theta, scales=None, group_size=128):
+    return torch.empty_like(x)
+
+
+# --------------------------------------------------------------------------------------
+# paro::repack_awq / paro::w4a16_linear / paro::dequant_packed
+# --------------------------------------------------------------------------------------
+
+
+def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor):
+    lib = nat.load()
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
+        raise RuntimeError("qweight / qzeros must be int32 (AWQ packing, cli/convert.py:149-155)")
+    K, NW = qweight.shape
+    N = NW * 8
+    if K % 128 != 0:
+        raise ValueError(f"in_features must be a multiple of 128, got {K}")
+    if N % 16 != 0:
+        raise ValueError(f"out_features must be a multiple of 16, got {N}")
+    if tuple(qzeros.shape) != (K // 128, NW):
+        raise ValueError(f"qzeros shape {tuple(qzeros.shape)} != {(K // 128, NW)} (group_size must be 128)")
+    qweight = qweight.contiguous()
+    qzeros = qzeros.contiguous()
+    wq = torch.empty(lib.paro_packed_qweight_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
+    zq = torch.empty(lib.paro_packed_qzeros_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
+    nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), K, N, wq.data_ptr(), zq.data_ptr(),
+                                  nat.current_stream_ptr(qweight.device)))
+    return wq, zq
+
+
+def _repack_fake(qweight, qzeros):
+    K, NW = qweight.shape
+    return (qweight.new_empty(K * NW), qzeros.new_empty(qzeros.numel()))
+
+
+def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, zq, scales, pairs,
+              theta, channel_scales, bias) -> nat.ParoLinearDesc:
+    d = nat.ParoLinearDesc()
+    d.K = K
+    d.N = int(sum(partition_sizes))
+    d.n_parts = len(partition_sizes)
+    d.krot = krot
+    if len(partition_sizes) > nat.PARO_MAX_PARTS:
+        raise ValueError(f"at most {nat.PARO_MAX_PARTS} merged partitions are supported")
+    for i, n in enumerate(partition_sizes):
+        d.part_cols[i] = int(n)
+    d.act_dtype = nat.dtype_code(act_dtype)
+    d.wq = wq.data_ptr()
+    d.zq = zq.data_ptr()
+    d.scales = scales.data_ptr()
+    d.pairs = pairs.data_ptr()
+    d.theta = theta.data_ptr()
+    d.channel_scales = channel_scales.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    return d
+
+
+def _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes):
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"paro::w4a16_linear expects float16 or bfloat16 activations, got {x.dtype}")
+    P = len(partition_sizes)
+    K = x.size(-1)
+    if scales.dtype != torch.float16 or theta.dtype != torch.float16 or channel_scales.dtype != torch.float16:
+        raise RuntimeError("scales / theta / channel_scales must be float16 (checkpoint dtype, cli/convert.py:264-277)")
+    if pairs.dtype != torch.int16:
+        raise RuntimeError("pairs must be int16")
+    if pairs.dim() != 3 or pairs.size(0) != P or pairs.size(2) != K:
+        raise ValueError(f"pairs must be [n_parts={P}, krot, K={K}], got {tuple(pairs.shape)}")
+    if theta.dim() != 3 or theta.size(0) != P or theta.size(1) != pairs.size(1) or theta.size(2) != K // 2:
+        raise ValueError(f"theta must be [n_parts={P}, krot, K/2], got {tuple(theta.shape)}")
+    if channel_scales.numel() != P * K:
+        raise ValueError(f"channel_scales must hold n_parts*K elements, got {channel_scales.numel()}")
+    if bias is not None and bias.dtype != x.dtype:
+        raise RuntimeError("bias dtype must match the activation dtype")
+
+
+def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, zq: torch.Tensor, scales: torch.Tensor, pairs: torch.Tensor,
+                theta: torch.Tensor, channel_scales: torch.Tensor, bias: Optional[torch.Tensor],
+                partition_sizes: Sequence[int], workspace: torch.Tensor) -> torch.Tensor:
+    lib = nat.load()
+    partition_sizes = [int(s) for s in partition_sizes]
+    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
+    K = x.size(-1)
+    N = sum(partition_sizes)
+    x2 = x.reshape(-1, K).contiguous()
+    rows = x2.size(0)
+    y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    if rows == 0:
+        return y.reshape(*x.shape[:-1], N)
+    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
+    ws = workspace
+    if rows > 16:
+        # prefill: rotated activations live in a scratch buffer from torch's caching allocator
+        need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
+        if ws.numel() * ws.element_size() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    nat.check(lib.paro_w4a16_linear(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                    ws.numel() * ws.element_size(), nat.current_stream_ptr(x.device)))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def _w4a16_fake(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes, workspace):
+    return x.new_empty((*x.shape[:-1], int(sum(partition_sizes))))
+
+
+def w4a16_gemv_tuned(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes, workspace,
+                     tiles_per_wave: int = 0, ksplit: int = 0) -> torch.Tensor:
+    """Direct call of ``paro_w4a16_gemv`` with explicit launch-shape knobs (benchmarks / tuning sweeps)."""
+    lib = nat.load()
+    partition_sizes = [int(s) for s in partition_sizes]
+    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
+    K = x.size(-1)
+    N = sum(partition_sizes)
+    x2 = x.reshape(-1, K).contiguous()
+    rows = x2.size(0)
+    y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
+    nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, workspace.data_ptr(),
+                                  workspace.numel() * workspace.element_size(), tiles_per_wave, ksplit,
+                                  nat.current_stream_ptr(x.device)))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def w4a16_gemm_forced(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes) -> torch.Tensor:
+    """Direct call of ``paro_w4a16_gemm`` regardless of the row count (tests / benchmarks)."""
+    lib = nat.load()
+    partition_sizes = [int(s) for s in partition_sizes]
+    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
+    K = x.size(-1)
+    N = sum(partition_sizes)
+    x2 = x.reshape(-1, K).contiguous()
+    rows = x2.size(0)
+    y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
+    need = nat.PARO_WS_COUNTER_BYTES + len(partition_sizes) * rows * K * 2
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(), need,
+                                  nat.current_stream_ptr(x.device)))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def dequant_packed(wq, zq, scales, K: int, N: int, dtype=torch.float16) -> torch.Tensor:
+    """Dense ``W[K, N] = (q - z) * s`` from the packed buffers (verification aid)."""
+    lib = nat.load()
+    out = torch.empty((K, N), dtype=dtype, device=wq.device)
+    d = nat.ParoLinearDesc()
+    d.K, d.N, d.n_parts, d.krot = K, N, 1, 8
+    d.part_cols[0] = N
+    d.act_dtype = nat.dtype_code(dtype)
+    d.wq, d.zq, d.scales = wq.data_ptr(), zq.data_ptr(), scales.data_ptr()
+    nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
+    return out
+
+
+_workspaces: dict = {}
+
+
+def get_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device zero-initialised scratch shared by all layers (split-K slabs + arrival counters).
+
+    The GEMV kernels leave the counters at zero on exit, so one buffer serves every layer that
+    runs on the same stream; it only ever grows (never during graph capture: size it up front via
+    ``RotateQuantizedLinear.prepare`` / ``process_weights_after_loading``)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def decode_workspace_bytes(K: int, N: int, rows: int = 16) -> int:
+    return nat.PARO_WS_COUNTER_BYTES + (K // 128) * min(rows, 16) * N * 4
+
+
+# --------------------------------------------------------------------------------------
+# registration
+# --------------------------------------------------------------------------------------
+
+_libs = []
+
+
+def _register() -> None:
+    rot = torch.library.Library("rotation", "DEF")
+    rot.define(_ROTATE_SCHEMA)
+    rot.impl("rotate", _rotate_impl, "CUDA")       # ROCm tensors dispatch under the CUDA key
+    torch.library.register_fake("rotation::rotate", _rotate_fake, lib=rot)
+    _libs.append(rot)
+
+    par = torch.library.Library("paro", "DEF")
+    par.define("repack_awq(Tensor qweight, Tensor qzeros) -> (Tensor, Tensor)")
+    par.impl("repack_awq", _repack_impl, "CUDA")
+    torch.library.register_fake("paro::repack_awq", _repack_fake, lib=par)
+    par.define("w4a16_linear(Tensor x, Tensor wq, Tensor zq, Tensor scales, Tensor pairs, Tensor theta, "
+               "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace) -> Tensor")
+    par.impl("w4a16_linear", _w4a16_impl, "CUDA")
+    torch.library.register_fake("paro::w4a16_linear", _w4a16_fake, lib=par)
+    _libs.append(par)
+
+
+_register()

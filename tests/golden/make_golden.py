@@ -123,7 +123,7 @@ def main():
                             raw_angles_partial=np.stack([a.numpy() for a in angles_qt]))
 
         # G5 -----------------------------------------------------------------
-        N5, K5 = 24, 256
+        N5, K5 = 32, 256
         w5 = torch.randn(N5, K5, generator=g) * 0.05
         cs5 = torch.rand(K5, generator=g) * 1.5 + 0.5
         rng = np.random.default_rng(5)

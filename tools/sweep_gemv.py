@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""GPU tuning sweep for the fused GEMV: (tiles_per_wave x ksplit) per linear shape.
+
+    python tools/sweep_gemv.py [--model llama3-8b] [--rows 1] [--reps 300] > gpurun_out/sweep.jsonl
+
+Each variant is captured in a HIP graph of `reps` back-to-back launches that cycle through
+>= 1 GiB of distinct weight copies (so the 256 MB Infinity Cache cannot serve them) and timed with
+events around one replay; variants of one shape are interleaved over `rounds` rounds and the
+median is reported (within-process A/B, cdna guide section 5.4 rule 24)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from bench import MODELS, alg_bytes, layer_shapes, synth_packed
+from paroquant_amd import ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--rows", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--tpw", default="1,2,4,8")
+    ap.add_argument("--ksplit", default="0,1,2,4,8")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    tpws = [int(t) for t in args.tpw.split(",")]
+    ksps = [int(k) for k in args.ksplit.split(",")]
+    for name, K, sizes, _ in layer_shapes(args.model):
+        nb = alg_bytes(K, sum(sizes), len(sizes))
+        copies = max(2, min(48, int((1 << 30) // nb) + 1))
+        packs = [synth_packed(K, sizes, dev, gen) for _ in range(copies)]
+        x = torch.randn(args.rows, K, device=dev, dtype=torch.float16, generator=gen)
+        graphs = {}
+        G = K // 128
+        for tpw in tpws:
+            for ksp in ksps:
+                if ksp > max(1, G // 2):
+                    continue
+
+                def run(i, tpw=tpw, ksp=ksp):
+                    p = packs[i % copies]
+                    return ops.w4a16_gemv_tuned(x, p.wq, p.zq, p.scales, p.pairs, p.theta, p.channel_scales, None,
+                                                sizes, p.workspace, tpw, ksp)
+                for i in range(3):
+                    run(i)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(args.reps):
+                        run(i)
+                graphs[(tpw, ksp)] = g
+        times = {k: [] for k in graphs}
+        for _ in range(args.rounds):
+            for k, g in graphs.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                times[k].append(e0.elapsed_time(e1) * 1e3 / args.reps)
+        for (tpw, ksp), ts in sorted(times.items(), key=lambda kv: np.median(kv[1])):
+            us = float(np.median(ts))
+            print(json.dumps({"model": args.model, "linear": name, "K": K, "N": sum(sizes), "rows": args.rows, "tpw": tpw,
+                              "ksplit": ksp, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
+                              "frac": round(nb / us / 1e3 / 8000, 4)}), flush=True)
+        del graphs, packs
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
