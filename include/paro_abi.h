@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 1
+#define PARO_ABI_VERSION 2
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -76,23 +76,39 @@ int paro_rotate(const void* x, void* out, const int16_t* idx_ij, const void* the
                 void* stream);
 
 /* ---------------------------------------------------------------------------
- * One-time weight repack: AWQ checkpoint layout -> CDNA4 tile layout.
- * Replaces the per-partition AWQ->Marlin conversion of
- * ParoQuantLinearMethod.process_weights_after_loading / _convert_partition
+ * One-time repack: checkpoint layout -> CDNA4 kernel layout.  Replaces the
+ * per-partition AWQ->Marlin conversion of ParoQuantLinearMethod.
+ * process_weights_after_loading / _convert_partition
  * (paroquant/inference/backends/vllm/plugin.py:208-279).
  *
- *   qweight int32 [K, N/8]      nibble p of word c = column 8c + (0,2,4,6,1,3,5,7)[p]  (cli/convert.py:19,149-155)
+ * Inputs (checkpoint format, cli/convert.py:149-155,194-203,264-277):
+ *   qweight int32 [K, N/8]      nibble p of word c = column 8c + (0,2,4,6,1,3,5,7)[p]
  *   qzeros  int32 [K/128, N/8]  same packing
- *   out_wq  uint32 [N/16][K/128][64][4]  tile (t,g) = 1 KiB; lane l = (kb = l>>4, n = l&15), word i holds
+ *   scales  fp16  [K/128, N]
+ *   part_cols[n_parts]          columns of each merged partition (multiples of 16, sum = N)
+ * Outputs:
+ *   out_wq  uint32 [N/16][K/128][64][4]   tile (t,g) = 1 KiB; lane l = (kb = l>>4, n = l&15), word i holds
  *           k = 128g + 32i + 8kb + e (e = 0..7) of column 16t+n; element e sits in nibble (e>>1) + 4*(e&1)
- *           -- the MFMA 16x16x32 B-fragment order, two k-adjacent nibbles 16 bits apart.
- *   out_zq  uint32 [K/128][N/8]  natural nibble order (nibble j of word c = column 8c + j)
- *   K % 128 == 0, N % 16 == 0.
+ *           -- the v_mfma_f32_16x16x32 B-fragment order, the two k-adjacent nibbles 16 bits apart.
+ *   out_sz  uint32 [K/128][Tsz/4][16][4]  one word per (group, column): lo16 = scale (fp16 bits),
+ *           hi16 = fp16(16 + zero_point).  Column tiles are indexed in a padded tile space: partition p
+ *           starts at the sum of its predecessors' tile counts rounded up to 8 (Tsz = that sum over all
+ *           partitions); word ((g*Tsz/4 + ts/4)*16 + n)*4 + ts%4 belongs to padded tile ts, column n.
+ *           Padding words are zero.
  */
 int64_t paro_packed_qweight_bytes(int64_t K, int64_t N);
-int64_t paro_packed_qzeros_bytes(int64_t K, int64_t N);
-int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, int64_t K, int64_t N, void* out_wq,
-                    void* out_zq, void* stream);
+int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols);
+int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
+                    int n_parts, const int32_t* part_cols, void* out_wq, void* out_sz, void* stream);
+
+/* Rotation parameters -> one word per (partition, group, pair lane, stage):
+ *   out_rot uint32 [n_parts][K/128][64][8]:  i | j << 8 | theta_fp16_bits << 16,
+ * (i, j) = pairs[p, r, 128g + 2l], pairs[p, r, 128g + 2l + 1], theta = theta[p, r, 64g + l]
+ * (indexing of rotation.cuh:126-127).  Stages r >= krot are filled with the identity (2l, 2l+1, 0).
+ * Requires krot <= 8 (larger krot uses the unfused rotate + GEMV route). */
+int64_t paro_packed_rot_bytes(int64_t K, int n_parts);
+int paro_pack_rotation(const int16_t* pairs, const void* theta, int64_t K, int n_parts, int krot, void* out_rot,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused rotate + INT4 dequant + matmul.  Replaces, in one call,
@@ -109,9 +125,9 @@ typedef struct paro_linear {
   int32_t part_cols[PARO_MAX_PARTS];  /* columns per partition, each a multiple of 16 */
   int32_t act_dtype;                  /* PARO_DTYPE_F16 | PARO_DTYPE_BF16: dtype of x, y, bias */
   int32_t reserved;
-  const void* wq;                     /* packed weights (paro_repack_awq) */
-  const void* zq;                     /* packed zeros   (paro_repack_awq) */
-  const void* scales;                 /* fp16 [K/128, N]            (checkpoint layout, unchanged) */
+  const void* wq;                     /* packed INT4 tiles        (paro_repack_awq) */
+  const void* sz;                     /* packed scale/zero words  (paro_repack_awq) */
+  const void* rot;                    /* packed rotation words    (paro_pack_rotation); NULL iff krot > 8 */
   const int16_t* pairs;               /* int16 [n_parts, krot, K]   (checkpoint layout) */
   const void* theta;                  /* fp16 [n_parts, krot, K/2]  (checkpoint layout) */
   const void* channel_scales;         /* fp16 [n_parts, K]          (checkpoint layout) */
@@ -122,18 +138,21 @@ typedef struct paro_linear {
  * (split-K slabs + arrival counters for the GEMV path, rotated activations for
  * the GEMM path).  The first PARO_WS_COUNTER_BYTES of the workspace hold
  * arrival counters: the caller zero-fills the workspace ONCE after allocating
- * it (the kernels leave the counters at zero on exit). */
+ * it (the kernels leave the counters at zero on exit).  A workspace must not be
+ * shared by launches that may run concurrently on different streams. */
 #define PARO_WS_COUNTER_BYTES 16384
 int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
 
 /* Decode / small-batch path (rows <= 16): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
- * tiles_per_wave in {0 (auto), 1, 2, 4, 8}; ksplit >= 0 (0 = auto). */
+ * Launch-shape knobs (0 = auto): tiles_per_wave in {1,2,4,8}; ksplit >= 1;
+ * waves per workgroup in {4,8,16}.  mode: 0 = fused rotation (default),
+ * 1 = rotate pre-pass kernel into the workspace, then the same GEMV on rotated x. */
 int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
-                    int64_t workspace_bytes, int tiles_per_wave, int ksplit, void* stream);
+                    int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);
 
 /* Prefill path (any rows): rotate pre-pass into the workspace, then an
- * LDS-staged MFMA GEMM with in-register (q - z) * s dequant. */
+ * LDS-staged MFMA GEMM with in-register INT4 unpack. */
 int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, void* stream);
 

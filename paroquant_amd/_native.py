@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 1
+PARO_ABI_VERSION = 2
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -26,8 +26,10 @@ EXPORTS = (
     "paro_last_error",
     "paro_rotate",
     "paro_packed_qweight_bytes",
-    "paro_packed_qzeros_bytes",
+    "paro_packed_sz_bytes",
+    "paro_packed_rot_bytes",
     "paro_repack_awq",
+    "paro_pack_rotation",
     "paro_linear_workspace_bytes",
     "paro_w4a16_gemv",
     "paro_w4a16_gemm",
@@ -48,8 +50,8 @@ class ParoLinearDesc(Structure):
         ("act_dtype", c_int32),
         ("reserved", c_int32),
         ("wq", c_void_p),
-        ("zq", c_void_p),
-        ("scales", c_void_p),
+        ("sz", c_void_p),
+        ("rot", c_void_p),
         ("pairs", c_void_p),
         ("theta", c_void_p),
         ("channel_scales", c_void_p),
@@ -85,15 +87,20 @@ def load() -> ctypes.CDLL:
                                 c_int, c_int, c_void_p]
     lib.paro_packed_qweight_bytes.restype = c_int64
     lib.paro_packed_qweight_bytes.argtypes = [c_int64, c_int64]
-    lib.paro_packed_qzeros_bytes.restype = c_int64
-    lib.paro_packed_qzeros_bytes.argtypes = [c_int64, c_int64]
+    lib.paro_packed_sz_bytes.restype = c_int64
+    lib.paro_packed_sz_bytes.argtypes = [c_int64, c_int, POINTER(c_int32)]
+    lib.paro_packed_rot_bytes.restype = c_int64
+    lib.paro_packed_rot_bytes.argtypes = [c_int64, c_int]
     lib.paro_repack_awq.restype = c_int
-    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int32), c_void_p,
+                                    c_void_p, c_void_p]
+    lib.paro_pack_rotation.restype = c_int
+    lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.paro_linear_workspace_bytes.restype = c_int64
     lib.paro_linear_workspace_bytes.argtypes = [POINTER(ParoLinearDesc), c_int64]
     lib.paro_w4a16_gemv.restype = c_int
     lib.paro_w4a16_gemv.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
-                                    c_int, c_void_p]
+                                    c_int, c_int, c_int, c_void_p]
     lib.paro_w4a16_gemm.restype = c_int
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
     lib.paro_w4a16_linear.restype = c_int

@@ -24,6 +24,53 @@ inline int check_launch(const char* what) {
   return PARO_OK;
 }
 
+// ---- merged-partition bookkeeping (passed by value to kernels) ------------------------
+// tile_start : first 16-column tile of each partition (prefix sums of part_cols / 16)
+// szt_start  : the same in the padded tile space of the scale/zero words (each partition rounded up to 8 tiles)
+// cb_start   : first column block (= workgroup x-index) of each partition for a given tiles-per-block
+struct PartTable {
+  int nparts, tiles, tsz, cbs;
+  int tile_start[PARO_MAX_PARTS + 1];
+  int szt_start[PARO_MAX_PARTS + 1];
+  int cb_start[PARO_MAX_PARTS + 1];
+  __host__ __device__ int part_of_tile(int t) const {
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < PARO_MAX_PARTS; ++q)
+      if (q < nparts && t >= tile_start[q]) p = q;
+    return p;
+  }
+  __host__ __device__ int part_of_cb(int cb) const {
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < PARO_MAX_PARTS; ++q)
+      if (q < nparts && cb >= cb_start[q]) p = q;
+    return p;
+  }
+};
+
+inline bool fill_part_table(PartTable& pt, int nparts, const int32_t* part_cols, int tiles_per_cb) {
+  if (nparts < 1 || nparts > PARO_MAX_PARTS || !part_cols || tiles_per_cb < 1) return false;
+  pt.nparts = nparts;
+  int tiles = 0, tsz = 0, cbs = 0;
+  for (int i = 0; i <= PARO_MAX_PARTS; ++i) {
+    pt.tile_start[i] = tiles;
+    pt.szt_start[i] = tsz;
+    pt.cb_start[i] = cbs;
+    if (i < nparts) {
+      if (part_cols[i] <= 0 || part_cols[i] % 16 != 0) return false;
+      const int t = part_cols[i] / 16;
+      tiles += t;
+      tsz += (t + 7) / 8 * 8;
+      cbs += (t + tiles_per_cb - 1) / tiles_per_cb;
+    }
+  }
+  pt.tiles = tiles;
+  pt.tsz = tsz;
+  pt.cbs = cbs;
+  return true;
+}
+
 // ---- vector types ---------------------------------------------------------------
 typedef _Float16 f16;
 typedef __bf16 bf16;

@@ -9,7 +9,7 @@
 //      swizzle (conflict-free ds_read_b128 fragments); the INT4 B tiles are NOT staged: each wave
 //      loads its four 1-KiB tiles straight to VGPRs in MFMA B-fragment order (paro_repack_awq),
 //      unpacks to (16 + q) halves and feeds v_mfma_f32_16x16x32.  Scale and zero point are applied
-//      per (group, column) on the fp32 group result, exactly as in gemv.hip:
+//      per (group, column) on the fp32 group result, exactly as in the GEMV:
 //          acc += s * (D_g - (16 + z) * sum_k x_k)
 #include "common.hpp"
 
@@ -21,14 +21,12 @@ int validate_linear(const paro_linear_t* L);
 
 struct GemmArgs {
   const u32x4* wq;
-  const unsigned* zq;
-  const unsigned short* scales;
+  const unsigned* sz;
   const unsigned short* bias;
   const unsigned short* xrot;  // [nparts][rows][K]
   unsigned short* y;
-  int K, N, G, rows, nparts;
-  int part_tile_start[PARO_MAX_PARTS + 1];
-  int part_cb_start[PARO_MAX_PARTS + 1];
+  int K, N, G, rows;
+  PartTable pt;                // column blocks of BN_TILES tiles
 };
 
 constexpr int BM = 128;
@@ -47,16 +45,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   const int cb = blockIdx.x;
   const int row0 = blockIdx.y * BM;
 
-  int p = 0;
-#pragma unroll
-  for (int q = 1; q < PARO_MAX_PARTS; ++q)
-    if (q < a.nparts && cb >= a.part_cb_start[q]) p = q;
-  const int tile0 = a.part_tile_start[p] + (cb - a.part_cb_start[p]) * BN_TILES + wc * 4;
-  const int nt = max(0, min(4, a.part_tile_start[p + 1] - tile0));
+  const int p = a.pt.part_of_cb(cb);
+  const int ltile0 = (cb - a.pt.cb_start[p]) * BN_TILES + wc * 4;
+  const int tile0 = a.pt.tile_start[p] + ltile0;
+  const int nt = max(0, min(4, a.pt.tile_start[p + 1] - tile0));
+  const int ts0 = a.pt.szt_start[p] + ltile0;  // multiple of 4
   const unsigned short* xp = a.xrot + (int64_t)p * a.rows * a.K;
 
   const int n = lane & 15, mq = lane >> 4;
-  const int NW = a.N >> 3;
+  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;
+  const unsigned* szp = a.sz + ((int64_t)(ts0 >> 2) * 16 + n) * 4;
 
   // staging map: chunk c -> row (tid >> 4) + 16 c, 16-byte slot tid & 15
   const int srow = tid >> 4, sslot = tid & 15;
@@ -69,8 +67,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 
   u32x4 stg[8];
   u32x4 qv[4];
-  unsigned short sraw[4];
-  unsigned zw[4];
+  u32x4 szv;
 
   auto issue_loads = [&](int g) {
 #pragma unroll
@@ -80,14 +77,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
       if (row < a.rows) stg[c] = *(const u32x4*)(xp + (int64_t)row * a.K + g * 128 + sslot * 8);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < nt) {
-        const int t = tile0 + j;
-        qv[j] = *(a.wq + ((int64_t)t * a.G + g) * 64 + lane);
-        sraw[j] = a.scales[(int64_t)g * a.N + t * 16 + n];
-        zw[j] = a.zq[(int64_t)g * NW + t * 2 + (n >> 3)];
-      }
-    }
+    for (int j = 0; j < 4; ++j)
+      if (j < nt) qv[j] = *(a.wq + ((int64_t)(tile0 + j) * a.G + g) * 64 + lane);
+    if (nt > 0) szv = *(const u32x4*)(szp + (int64_t)g * szrow);
   };
 
   issue_loads(0);
@@ -99,14 +91,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
       *(u32x4*)(lds + row * 256 + ((sslot ^ (row & 15)) << 4)) = stg[c];
     }
     u32x4 qc[4];
-    unsigned short sc[4];
-    unsigned zc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      qc[j] = qv[j];
-      sc[j] = sraw[j];
-      zc[j] = zw[j];
-    }
+    for (int j = 0; j < 4; ++j) qc[j] = qv[j];
+    const u32x4 szc = szv;
     __syncthreads();
     if (g + 1 < a.G) issue_loads(g + 1);  // next group's A rows + INT4 tiles fly under this group's MFMAs
 
@@ -143,8 +130,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) d[rt] = A::mfma(af[rt][i], bf, d[rt]);
         }
-        const float s = f16_bits_to_f32(sc[j]);
-        const float zf = (float)(16 + ((zc[j] >> (4 * (n & 7))) & 0xFu));
+        const float s = f16_bits_to_f32(szc[j] & 0xffffu);
+        const float zf = f16_bits_to_f32(szc[j] >> 16);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -195,8 +182,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   }
   GemmArgs a;
   a.wq = (const u32x4*)L->wq;
-  a.zq = (const unsigned*)L->zq;
-  a.scales = (const unsigned short*)L->scales;
+  a.sz = (const unsigned*)L->sz;
   a.bias = (const unsigned short*)L->bias;
   a.xrot = xrot;
   a.y = (unsigned short*)y;
@@ -204,22 +190,10 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.N = (int)L->N;
   a.G = (int)(L->K / 128);
   a.rows = (int)rows;
-  a.nparts = L->n_parts;
-  int tiles = 0, cbs = 0;
-  for (int i = 0; i < PARO_MAX_PARTS; ++i) {
-    a.part_tile_start[i] = tiles;
-    a.part_cb_start[i] = cbs;
-    if (i < L->n_parts) {
-      const int pt = L->part_cols[i] / 16;
-      tiles += pt;
-      cbs += (pt + BN_TILES - 1) / BN_TILES;
-    }
-  }
-  a.part_tile_start[PARO_MAX_PARTS] = tiles;
-  a.part_cb_start[PARO_MAX_PARTS] = cbs;
+  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
   const int64_t rb = (rows + BM - 1) / BM;
   if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * BM);
-  dim3 grid((unsigned)cbs, (unsigned)rb);
+  dim3 grid((unsigned)a.pt.cbs, (unsigned)rb);
   if (L->act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
   else

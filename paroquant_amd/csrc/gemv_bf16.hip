@@ -1,0 +1,8 @@
+// Instantiations of the fused GEMV for bf16 activations (see gemv_impl.hpp).
+#include "gemv_impl.hpp"
+
+namespace paro {
+int launch_gemv_bf16(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st) {
+  return launch_gemv_variant<bf16, false>(a, tpw, waves, grid, st);
+}
+}  // namespace paro

@@ -1,0 +1,349 @@
+// Fused pairwise-rotation + INT4 dequant + GEMV/small-batch GEMM for gfx950 (decode path).
+//
+// One launch computes  y[b, :] = rotate_p(x[b, :] * cs_p) @ dequant(W)  for every merged
+// partition p (qkv = 3 rotations, gate_up = 2) -- the work the reference spreads over
+// `rotate` + AWQ/Marlin GEMM launches per partition + torch.cat + bias
+// (transformers/modules.py:57-71, vllm/plugin.py:281-311).
+//
+// Mapping (CDNA4-first, not a warp-tiled port):
+//   * work unit = (128-channel quantisation group g) x (TPW column tiles of 16 outputs).
+//     A 64-lane wavefront owns one unit at a time: 64 lanes == the 64 Givens pairs of the
+//     group, so the wave rotates ITS OWN slice of x in wave-private LDS with no workgroup
+//     barrier.  All 8 stages' coefficients arrive as two 16-byte loads per lane
+//     (paro_pack_rotation), requested BEFORE the unit's INT4 tiles so that waiting for them
+//     does not wait for the tiles (vmcnt retires in order); the rotation then runs while
+//     the tiles (non-temporal, 1 KiB per wave-load, straight to VGPRs) are in flight.
+//   * the group loop is software-pipelined: unit n+1's coefficients and tiles are requested
+//     before unit n's tiles are consumed.
+//   * the INT4 tile is stored in MFMA B-fragment order (paro_repack_awq), so a lane's
+//     16-byte load IS its four v_mfma_f32_16x16x32 B operands after a shift/and/or unpack
+//     to (16 + q) halves; scale and zero point come as one packed word per (group, column)
+//     and are applied on the fp32 MFMA result:  acc += s * (D - (16 + z) * sum_k x_k),
+//     with sum_k x_k from one extra MFMA against a ones fragment.
+//   * batch rows (<= 16) ride in the MFMA M dimension: rows <= 4 occupy MFMA rows 0,4,8,12
+//     so a single accumulator register per tile suffices.
+//   * the WAVES (4..16) waves of a workgroup take different groups of the same columns and
+//     reduce through LDS; by default one workgroup covers ALL of K, so no cross-workgroup
+//     reduction exists.  An optional K-split (grid.y) is combined in-launch without fences:
+//     write-through (sc1) slab stores -> drain -> barrier -> one relaxed agent-scope ticket;
+//     the last arriver reads the slabs with sc1 loads and writes y exactly once.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace paro {
+
+struct GemvArgs {
+  const u32x4* wq;
+  const unsigned* sz;
+  const unsigned* rot;
+  const unsigned short* cs;
+  const unsigned short* bias;
+  const unsigned short* x;  // [rows][K], or pre-rotated [nparts][rows][K] when PREROT
+  unsigned short* y;
+  float* slabs;
+  unsigned* counters;
+  int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
+  int flags;                             // debug (PARO_GEMV_FLAGS): 16 = return at kernel entry (launch floor)
+  PartTable pt;
+};
+
+constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
+
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT>
+__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
+  typedef Act<AT> A;
+  typedef typename A::vec8 vec8;
+  constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile
+  constexpr int VW = MB >= 4 ? 4 : MB;                  // LDS vector width of the rotation state
+  constexpr int NCH = MB / VW;
+  typedef float V __attribute__((ext_vector_type(VW)));
+  constexpr int XR_FLOATS = PREROT ? 0 : MB * 128;
+  constexpr int XH_HALVES = PREROT ? 0 : (MB + 1) * kXhStride;  // + one all-zero row for unused MFMA rows
+  constexpr int WAVE_BYTES = XR_FLOATS * 4 + ((XH_HALVES * 2 + 15) / 16) * 16;
+  constexpr int RED_FLOATS = WAVES * TPW * MR * 64;
+  constexpr int LDS_BYTES = (WAVES * WAVE_BYTES > RED_FLOATS * 4 ? WAVES * WAVE_BYTES : RED_FLOATS * 4) + 16;
+  constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;  // 16-byte scale/zero vectors per unit
+  constexpr int SZW = TPW < 4 ? TPW : 4;
+  typedef unsigned SZV __attribute__((ext_vector_type(SZW)));
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = blockIdx.x, ks = blockIdx.y;
+  if (a.flags & 16) return;  // ablation: launch floor
+
+  const int p = a.pt.part_of_cb(cb);
+  const int ltile0 = (cb - a.pt.cb_start[p]) * TPW;
+  const int tile0 = a.pt.tile_start[p] + ltile0;
+  const int nt = min(TPW, a.pt.tile_start[p + 1] - tile0);
+  const int ts0 = a.pt.szt_start[p] + ltile0;
+  const int g_begin = ks * a.gps;
+  const int g_end = min(a.G, g_begin + a.gps);
+
+  float* xr = (float*)(lds + wave * WAVE_BYTES);
+  unsigned short* xh = (unsigned short*)(lds + wave * WAVE_BYTES + XR_FLOATS * 4);
+  if constexpr (!PREROT) {
+    for (int c = lane; c < kXhStride; c += 64) xh[MB * kXhStride + c] = 0;  // zero row
+  }
+
+  const int n = lane & 15, mq = lane >> 4;
+  // A-fragment source row of this lane: MFMA row m' = lane & 15 carries batch row (m'>>2)*MR + (m'&3)
+  const int mrow = lane & 15;
+  const int brow = (mrow >> 2) * MR + (mrow & 3);
+  const bool avalid = ((mrow & 3) < MR) && (brow < a.rows);
+
+  float acc[TPW][MR];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int r = 0; r < MR; ++r) acc[j][r] = 0.f;
+
+  struct PBuf {
+    unsigned xv[PREROT ? 1 : MB];
+    unsigned csv;
+    u32x4 r0, r1;
+    u32x4 xa[PREROT ? 4 : 1];
+  };
+  struct TBuf {
+    u32x4 q[TPW];
+    SZV sz[NSZ];
+  };
+
+  const unsigned short* xrot_p = a.x + (PREROT ? (int64_t)p * a.rows * a.K : 0);
+  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;  // words per group row of the scale/zero array
+
+  auto load_p = [&](PBuf& b, int g) {
+    if constexpr (PREROT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        b.xa[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (avalid) b.xa[i] = *(const u32x4*)(xrot_p + (int64_t)brow * a.K + g * 128 + 32 * i + 8 * mq);
+      }
+    } else {
+      const u32x4* rp = (const u32x4*)(a.rot + (((int64_t)p * a.G + g) * 64 + lane) * 8);
+      b.r0 = rp[0];
+      b.r1 = rp[1];
+      b.csv = *(const unsigned*)(a.cs + (int64_t)p * a.K + g * 128 + 2 * lane);
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        const int rr = r < a.rows ? r : 0;  // clamp instead of branching: keeps the load count static
+        b.xv[r] = *(const unsigned*)(a.x + (int64_t)rr * a.K + g * 128 + 2 * lane);
+      }
+    }
+  };
+  // Every load below is unconditional (ragged column blocks re-read their last tile and mask it
+  // later) so that the compiler's vmcnt bookkeeping is exact: the wait in front of the rotation
+  // covers only the coefficient loads and leaves the tile loads in flight.
+  auto load_t = [&](TBuf& b, int g) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int jj = j < nt ? j : nt - 1;
+      b.q[j] = __builtin_nontemporal_load(a.wq + ((int64_t)(tile0 + jj) * a.G + g) * 64 + lane);
+    }
+    const unsigned* sp = a.sz + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
+#pragma unroll
+    for (int v = 0; v < NSZ; ++v) b.sz[v] = *(const SZV*)(sp + v * 64);
+  };
+
+  PBuf pc, pn;
+  TBuf tc, tn;
+
+  // One work unit: rotate group g's slice of x (coefficients in pc), then consume its tiles (tc).
+  // PF = std::true_type: also request unit gn's coefficients (before the rotation) and tiles (before
+  // consuming this unit's tiles) -- the software pipeline.
+  auto step = [&](auto pf_tag, int gn) {
+    constexpr bool PF = decltype(pf_tag)::value;
+    if constexpr (PF) load_p(pn, gn);
+
+    // ---- A fragments of this group (4 x K=32)
+    vec8 af[4];
+    if constexpr (PREROT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
+    } else {
+      const float c0 = f16_bits_to_f32(pc.csv & 0xffffu), c1 = f16_bits_to_f32(pc.csv >> 16);
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        const int ch = r / VW, v = r % VW;
+        const unsigned xv = r < a.rows ? pc.xv[r] : 0u;
+        xr[(ch * 128 + 2 * lane) * VW + v] = A::to_f32(xv & 0xffffu) * c0;
+        xr[(ch * 128 + 2 * lane + 1) * VW + v] = A::to_f32(xv >> 16) * c1;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < a.krot) {
+          const unsigned w = r < 4 ? pc.r0[r & 3] : pc.r1[r & 3];
+          const int i = (int)(w & 0xffu), j = (int)((w >> 8) & 0xffu);
+          float s, c;
+          fast_sincos(f16_bits_to_f32(w >> 16), s, c);
+          V va[NCH], vb[NCH];
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            va[ch] = *(const V*)(xr + (ch * 128 + i) * VW);
+            vb[ch] = *(const V*)(xr + (ch * 128 + j) * VW);
+          }
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            *(V*)(xr + (ch * 128 + i) * VW) = va[ch] * c + vb[ch] * s;
+            *(V*)(xr + (ch * 128 + j) * VW) = vb[ch] * c - va[ch] * s;
+          }
+          // a wave's DS operations execute in issue order, so the next stage's reads see these
+          // writes; the barrier only stops the compiler from reordering across stages
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      // fp32 state -> activation-dtype fragment rows (one rounding), lane l converts channels 2l, 2l+1
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        const int ch = r / VW, v = r % VW;
+        const float v0 = xr[(ch * 128 + 2 * lane) * VW + v];
+        const float v1 = xr[(ch * 128 + 2 * lane + 1) * VW + v];
+        *(unsigned*)(xh + r * kXhStride + 2 * lane) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const unsigned short* afrag = xh + (avalid ? brow : MB) * kXhStride + 8 * mq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
+    }
+    f32x4 sx = {0.f, 0.f, 0.f, 0.f};
+    {
+      const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+      const vec8 ob = __builtin_bit_cast(vec8, ones);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sx = A::mfma(af[i], ob, sx);
+    }
+    if constexpr (PF) load_t(tn, gn);
+
+    // ---- per tile: unpack -> 4 MFMA -> scale / zero point on the fp32 result
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned w4[4];
+        A::unpack(tc.q[j][i], w4);
+        const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+        d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+      }
+      const unsigned szw = tc.sz[j / 4][j % 4];
+      const float s = f16_bits_to_f32(szw & 0xffffu);
+      const float zf = f16_bits_to_f32(szw >> 16);
+#pragma unroll
+      for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r]), acc[j][r]);
+    }
+    if constexpr (PF) {
+      pc = pn;
+      tc = tn;
+    }
+  };
+
+  {
+    int g = g_begin + wave;
+    if (g < g_end) {
+      load_p(pc, g);
+      load_t(tc, g);
+      for (; g + WAVES < g_end; g += WAVES) step(std::true_type{}, g + WAVES);
+      step(std::false_type{}, g);
+    }
+  }
+
+  // ---- reduce the workgroup's waves (different groups, same columns) through LDS
+  __syncthreads();
+  float* red = (float*)lds;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int r = 0; r < MR; ++r) red[((wave * TPW + j) * MR + r) * 64 + lane] = acc[j][r];
+  __syncthreads();
+
+  const bool direct = (a.ksplit == 1);
+  for (int e = tid; e < TPW * MR * 64; e += WAVES * 64) {
+    const int el = e & 63, r = (e >> 6) % MR, j = e / (MR * 64);
+    const int b = (el >> 4) * MR + r;
+    if (j >= nt || b >= a.rows) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MR * 64];
+    const int col = (tile0 + j) * 16 + (el & 15);
+    if (direct) {
+      if (a.bias) v += A::to_f32(a.bias[col]);
+      a.y[(int64_t)b * a.N + col] = A::from_f32(v);
+    } else {  // write-through so the reducing workgroup can read it with sc1 loads, no fences
+      __hip_atomic_store(a.slabs + ((int64_t)ks * a.rows + b) * a.N + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (direct) return;
+
+  // ---- in-launch K-split combine (placement-independent, fence-free):
+  // sc1 slab stores -> every wave drains -> barrier -> ONE relaxed agent-scope ticket;
+  // the last arriver reads all slabs with sc1 loads and writes y once, then re-arms the counter.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* flag = (unsigned*)(lds + LDS_BYTES - 16);
+  if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*flag != (unsigned)(a.ksplit - 1)) return;
+  const int ncols = nt * 16;
+  for (int e = tid; e < a.rows * ncols; e += WAVES * 64) {
+    const int b = e / ncols, c = e % ncols;
+    const int col = tile0 * 16 + c;
+    float v = 0.f;
+    for (int s = 0; s < a.ksplit; ++s)
+      v += __hip_atomic_load(a.slabs + ((int64_t)s * a.rows + b) * a.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.bias) v += A::to_f32(a.bias[col]);
+    a.y[(int64_t)b * a.N + col] = A::from_f32(v);
+  }
+  if (tid == 0) __hip_atomic_store(a.counters + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
+template <typename AT, int TPW, int MB, bool PREROT>
+int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if constexpr (MB <= 4 && TPW <= 4) {
+    if (waves == 16) {
+      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT>), grid, dim3(1024), 0, st, a);
+      return PARO_OK;
+    }
+  }
+  if (waves == 8) {
+    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 8, PREROT>), grid, dim3(512), 0, st, a);
+    return PARO_OK;
+  }
+  if (waves == 4) {
+    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT>), grid, dim3(256), 0, st, a);
+    return PARO_OK;
+  }
+  return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d batch rows", waves, MB);
+}
+
+template <typename AT, int TPW, bool PREROT>
+int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (a.rows <= 1) return launch_waves<AT, TPW, 1, PREROT>(a, waves, grid, st);
+  if (a.rows <= 4) return launch_waves<AT, TPW, 4, PREROT>(a, waves, grid, st);
+  if (a.rows <= 8) return launch_waves<AT, TPW, 8, PREROT>(a, waves, grid, st);
+  if constexpr (TPW <= 4) return launch_waves<AT, TPW, 16, PREROT>(a, waves, grid, st);
+  return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = 8 is not built for more than 8 batch rows");
+}
+
+template <typename AT, bool PREROT>
+int launch_gemv_variant(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st) {
+  switch (tpw) {
+    case 1: return launch_rows<AT, 1, PREROT>(a, waves, grid, st);
+    case 2: return launch_rows<AT, 2, PREROT>(a, waves, grid, st);
+    case 4: return launch_rows<AT, 4, PREROT>(a, waves, grid, st);
+    case 8: return launch_rows<AT, 8, PREROT>(a, waves, grid, st);
+  }
+  return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 1, 2, 4 or 8 (got %d)", tpw);
+}
+
+// defined in gemv_f16.hip / gemv_f16_pre.hip / gemv_bf16.hip / gemv_bf16_pre.hip
+int launch_gemv_f16(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
+int launch_gemv_f16_pre(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
+int launch_gemv_bf16(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
+int launch_gemv_bf16_pre(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
+
+}  // namespace paro

@@ -65,23 +65,26 @@ class PackedParoWeights:
             theta, pairs = theta[None], pairs[None]
         channel_scales = channel_scales.reshape(P, K)
         self.K, self.N = K, N
-        self.wq, self.zq = torch.ops.paro.repack_awq(qweight, qzeros)
-        self.scales = scales.to(torch.float16).contiguous()
         self.theta = theta.to(torch.float16).contiguous()
         self.pairs = pairs.to(torch.int16).contiguous()
         self.channel_scales = channel_scales.to(torch.float16).contiguous()
+        # kernel layouts: INT4 tiles in MFMA B-fragment order, one (scale, 16 + zero) word per (group,
+        # column), one (i, j, theta) word per (group, pair lane, stage)  -- include/paro_abi.h
+        self.wq, self.sz = torch.ops.paro.repack_awq(qweight, qzeros, scales.to(torch.float16),
+                                                     self.partition_sizes)
+        self.rot = torch.ops.paro.pack_rotation(self.pairs, self.theta)
         self.bias = bias
-        self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N))
+        self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N, P))
 
     def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self.bias if bias is None else bias
         if b is not None and b.dtype != x.dtype:
             b = b.to(x.dtype)
-        return torch.ops.paro.w4a16_linear(x, self.wq, self.zq, self.scales, self.pairs, self.theta,
+        return torch.ops.paro.w4a16_linear(x, self.wq, self.sz, self.rot, self.pairs, self.theta,
                                            self.channel_scales, b, self.partition_sizes, self.workspace)
 
     def nbytes(self) -> int:
-        ts = [self.wq, self.zq, self.scales, self.theta, self.pairs, self.channel_scales]
+        ts = [self.wq, self.sz, self.rot, self.channel_scales]
         return sum(t.numel() * t.element_size() for t in ts)
 
 

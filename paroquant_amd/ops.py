@@ -6,12 +6,13 @@ Registers, with the reference's exact schema,
                               int group_size=128) -> Tensor
 
 (reference: ``TORCH_LIBRARY(rotation)`` at paroquant/kernels/cuda/rotation.cu:128-135, fake kernel at
-paroquant/kernels/cuda/__init__.py:54-61) and the fused operator this build adds behind
+paroquant/kernels/cuda/__init__.py:54-61) and the operators this build adds behind
 ``RotateQuantizedLinear`` / ``ParoQuantLinearMethod``:
 
-    torch.ops.paro.w4a16_linear(x, wq, zq, scales, pairs, theta, channel_scales, bias?,
+    torch.ops.paro.repack_awq(qweight, qzeros, scales, partition_sizes) -> (wq, sz)
+    torch.ops.paro.pack_rotation(pairs, theta) -> rot
+    torch.ops.paro.w4a16_linear(x, wq, sz, rot, pairs, theta, channel_scales, bias?,
                                 partition_sizes, workspace) -> Tensor
-    torch.ops.paro.repack_awq(qweight, qzeros) -> (wq, zq)
 
 All device work goes through the C ABI of ``libparo_mi355x.so`` (``_native``) on torch's current
 HIP stream; implementations exist for the GPU dispatch key only, exactly like the reference.
@@ -54,6 +55,10 @@ def _rotate_impl(x: torch.Tensor, idx_ij: torch.Tensor, theta: torch.Tensor,
         s_ptr = None
     out = torch.empty_like(x)
     rows = x.numel() // h if h > 0 else 0
+    if rows == 0:
+        if group_size not in (64, 128):
+            raise RuntimeError(f"Unsupported group_size: {group_size}; expected 64 or 128")
+        return out
     nat.check(lib.paro_rotate(x.data_ptr(), out.data_ptr(), idx_ij.data_ptr(), theta.data_ptr(), s_ptr, rows, h,
                               int(theta.size(0)), int(group_size), nat.dtype_code(x.dtype), nat.dtype_code(pd),
                               nat.current_stream_ptr(x.device)))
@@ -65,37 +70,76 @@ def _rotate_fake(x, idx_ij, theta, scales=None, group_size=128):
 
 
 # --------------------------------------------------------------------------------------
-# paro::repack_awq / paro::w4a16_linear / paro::dequant_packed
+# paro::repack_awq / paro::pack_rotation
 # --------------------------------------------------------------------------------------
 
 
-def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor):
+def _part_array(partition_sizes: Sequence[int]):
+    sizes = [int(s) for s in partition_sizes]
+    if not 1 <= len(sizes) <= nat.PARO_MAX_PARTS:
+        raise ValueError(f"between 1 and {nat.PARO_MAX_PARTS} merged partitions are supported, got {len(sizes)}")
+    return (ctypes.c_int32 * len(sizes))(*sizes), sizes
+
+
+def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                 partition_sizes: Sequence[int]):
     lib = nat.load()
     if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
         raise RuntimeError("qweight / qzeros must be int32 (AWQ packing, cli/convert.py:149-155)")
+    if scales.dtype != torch.float16:
+        raise RuntimeError("scales must be float16 (checkpoint dtype, cli/convert.py:201)")
     K, NW = qweight.shape
     N = NW * 8
+    arr, sizes = _part_array(partition_sizes)
     if K % 128 != 0:
         raise ValueError(f"in_features must be a multiple of 128, got {K}")
-    if N % 16 != 0:
-        raise ValueError(f"out_features must be a multiple of 16, got {N}")
-    if tuple(qzeros.shape) != (K // 128, NW):
-        raise ValueError(f"qzeros shape {tuple(qzeros.shape)} != {(K // 128, NW)} (group_size must be 128)")
-    qweight = qweight.contiguous()
-    qzeros = qzeros.contiguous()
+    if any(s <= 0 or s % 16 for s in sizes) or sum(sizes) != N:
+        raise ValueError(f"partition sizes {sizes} must be positive multiples of 16 summing to out_features {N}")
+    if tuple(qzeros.shape) != (K // 128, NW) or tuple(scales.shape) != (K // 128, N):
+        raise ValueError(f"qzeros {tuple(qzeros.shape)} / scales {tuple(scales.shape)} do not match "
+                         f"[{K // 128}, {NW}] / [{K // 128}, {N}] (group_size must be 128)")
+    qweight, qzeros, scales = qweight.contiguous(), qzeros.contiguous(), scales.contiguous()
     wq = torch.empty(lib.paro_packed_qweight_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
-    zq = torch.empty(lib.paro_packed_qzeros_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
-    nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), K, N, wq.data_ptr(), zq.data_ptr(),
-                                  nat.current_stream_ptr(qweight.device)))
-    return wq, zq
+    sz = torch.empty(lib.paro_packed_sz_bytes(K, len(sizes), arr) // 4, dtype=torch.int32, device=qweight.device)
+    nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, len(sizes), arr,
+                                  wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
+    return wq, sz
 
 
-def _repack_fake(qweight, qzeros):
+def _repack_fake(qweight, qzeros, scales, partition_sizes):
     K, NW = qweight.shape
-    return (qweight.new_empty(K * NW), qzeros.new_empty(qzeros.numel()))
+    tsz = sum((int(s) // 16 + 7) // 8 * 8 for s in partition_sizes)
+    return qweight.new_empty(K * NW), qweight.new_empty((K // 128) * tsz * 16)
 
 
-def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, zq, scales, pairs,
+def _pack_rotation_impl(pairs: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    lib = nat.load()
+    if pairs.dtype != torch.int16 or theta.dtype != torch.float16:
+        raise RuntimeError("pairs must be int16 and theta float16 (checkpoint dtypes, cli/convert.py:270-271)")
+    if pairs.dim() != 3 or theta.dim() != 3 or pairs.shape[:2] != theta.shape[:2] or pairs.size(2) != 2 * theta.size(2):
+        raise ValueError(f"expected pairs [P, krot, K] and theta [P, krot, K/2], got {tuple(pairs.shape)} / "
+                         f"{tuple(theta.shape)}")
+    P, krot, K = pairs.shape
+    if krot > 8:
+        return torch.empty(0, dtype=torch.int32, device=pairs.device)   # unfused route (rotate kernel + GEMV)
+    pairs, theta = pairs.contiguous(), theta.contiguous()
+    rot = torch.empty(lib.paro_packed_rot_bytes(K, P) // 4, dtype=torch.int32, device=pairs.device)
+    nat.check(lib.paro_pack_rotation(pairs.data_ptr(), theta.data_ptr(), K, P, krot, rot.data_ptr(),
+                                     nat.current_stream_ptr(pairs.device)))
+    return rot
+
+
+def _pack_rotation_fake(pairs, theta):
+    P, krot, K = pairs.shape
+    return pairs.new_empty(0 if krot > 8 else P * (K // 128) * 512, dtype=torch.int32)
+
+
+# --------------------------------------------------------------------------------------
+# paro::w4a16_linear
+# --------------------------------------------------------------------------------------
+
+
+def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, sz, rot, pairs,
               theta, channel_scales, bias) -> nat.ParoLinearDesc:
     d = nat.ParoLinearDesc()
     d.K = K
@@ -108,8 +152,8 @@ def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torc
         d.part_cols[i] = int(n)
     d.act_dtype = nat.dtype_code(act_dtype)
     d.wq = wq.data_ptr()
-    d.zq = zq.data_ptr()
-    d.scales = scales.data_ptr()
+    d.sz = sz.data_ptr()
+    d.rot = rot.data_ptr() if rot is not None and rot.numel() > 0 else None
     d.pairs = pairs.data_ptr()
     d.theta = theta.data_ptr()
     d.channel_scales = channel_scales.data_ptr()
@@ -117,13 +161,13 @@ def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torc
     return d
 
 
-def _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes):
+def _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes):
     if x.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"paro::w4a16_linear expects float16 or bfloat16 activations, got {x.dtype}")
     P = len(partition_sizes)
     K = x.size(-1)
-    if scales.dtype != torch.float16 or theta.dtype != torch.float16 or channel_scales.dtype != torch.float16:
-        raise RuntimeError("scales / theta / channel_scales must be float16 (checkpoint dtype, cli/convert.py:264-277)")
+    if theta.dtype != torch.float16 or channel_scales.dtype != torch.float16:
+        raise RuntimeError("theta / channel_scales must be float16 (checkpoint dtype, cli/convert.py:264-277)")
     if pairs.dtype != torch.int16:
         raise RuntimeError("pairs must be int16")
     if pairs.dim() != 3 or pairs.size(0) != P or pairs.size(2) != K:
@@ -136,12 +180,12 @@ def _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_
         raise RuntimeError("bias dtype must match the activation dtype")
 
 
-def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, zq: torch.Tensor, scales: torch.Tensor, pairs: torch.Tensor,
+def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.Tensor, pairs: torch.Tensor,
                 theta: torch.Tensor, channel_scales: torch.Tensor, bias: Optional[torch.Tensor],
                 partition_sizes: Sequence[int], workspace: torch.Tensor) -> torch.Tensor:
     lib = nat.load()
     partition_sizes = [int(s) for s in partition_sizes]
-    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
+    _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes)
     K = x.size(-1)
     N = sum(partition_sizes)
     x2 = x.reshape(-1, K).contiguous()
@@ -149,7 +193,7 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, zq: torch.Tensor, scales: tor
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     if rows == 0:
         return y.reshape(*x.shape[:-1], N)
-    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
+    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias)
     ws = workspace
     if rows > 16:
         # prefill: rotated activations live in a scratch buffer from torch's caching allocator
@@ -161,55 +205,57 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, zq: torch.Tensor, scales: tor
     return y.reshape(*x.shape[:-1], N)
 
 
-def _w4a16_fake(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes, workspace):
+def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace):
     return x.new_empty((*x.shape[:-1], int(sum(partition_sizes))))
 
 
-def w4a16_gemv_tuned(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes, workspace,
-                     tiles_per_wave: int = 0, ksplit: int = 0) -> torch.Tensor:
-    """Direct call of ``paro_w4a16_gemv`` with explicit launch-shape knobs (benchmarks / tuning sweeps)."""
+def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int = 0, mode: int = 0,
+                     bias=None) -> torch.Tensor:
+    """Direct call of ``paro_w4a16_gemv`` with explicit launch-shape knobs (benchmarks / tuning sweeps).
+    ``pk`` is a :class:`paroquant_amd.linear.PackedParoWeights`."""
     lib = nat.load()
-    partition_sizes = [int(s) for s in partition_sizes]
-    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
-    K = x.size(-1)
-    N = sum(partition_sizes)
+    _check_linear_args(x, pk.pairs, pk.theta, pk.channel_scales, bias, pk.partition_sizes)
+    K, N = pk.K, pk.N
     x2 = x.reshape(-1, K).contiguous()
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
-    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
-    nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, workspace.data_ptr(),
-                                  workspace.numel() * workspace.element_size(), tiles_per_wave, ksplit,
+    d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                  pk.channel_scales, bias)
+    ws = pk.workspace
+    nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                  ws.numel() * ws.element_size(), tiles_per_wave, ksplit, waves, mode,
                                   nat.current_stream_ptr(x.device)))
     return y.reshape(*x.shape[:-1], N)
 
 
-def w4a16_gemm_forced(x, wq, zq, scales, pairs, theta, channel_scales, bias, partition_sizes) -> torch.Tensor:
+def w4a16_gemm_forced(x, pk, bias=None) -> torch.Tensor:
     """Direct call of ``paro_w4a16_gemm`` regardless of the row count (tests / benchmarks)."""
     lib = nat.load()
-    partition_sizes = [int(s) for s in partition_sizes]
-    _check_linear_args(x, scales, pairs, theta, channel_scales, bias, partition_sizes)
-    K = x.size(-1)
-    N = sum(partition_sizes)
+    _check_linear_args(x, pk.pairs, pk.theta, pk.channel_scales, bias, pk.partition_sizes)
+    K, N = pk.K, pk.N
     x2 = x.reshape(-1, K).contiguous()
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
-    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, zq, scales, pairs, theta, channel_scales, bias)
-    need = nat.PARO_WS_COUNTER_BYTES + len(partition_sizes) * rows * K * 2
+    d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                  pk.channel_scales, bias)
+    need = nat.PARO_WS_COUNTER_BYTES + len(pk.partition_sizes) * rows * K * 2
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(), need,
                                   nat.current_stream_ptr(x.device)))
     return y.reshape(*x.shape[:-1], N)
 
 
-def dequant_packed(wq, zq, scales, K: int, N: int, dtype=torch.float16) -> torch.Tensor:
+def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.float16) -> torch.Tensor:
     """Dense ``W[K, N] = (q - z) * s`` from the packed buffers (verification aid)."""
     lib = nat.load()
+    N = int(sum(partition_sizes))
     out = torch.empty((K, N), dtype=dtype, device=wq.device)
     d = nat.ParoLinearDesc()
-    d.K, d.N, d.n_parts, d.krot = K, N, 1, 8
-    d.part_cols[0] = N
+    d.K, d.N, d.n_parts, d.krot = K, N, len(partition_sizes), 8
+    for i, n in enumerate(partition_sizes):
+        d.part_cols[i] = int(n)
     d.act_dtype = nat.dtype_code(dtype)
-    d.wq, d.zq, d.scales = wq.data_ptr(), zq.data_ptr(), scales.data_ptr()
+    d.wq, d.sz = wq.data_ptr(), sz.data_ptr()
     nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
     return out
 
@@ -218,11 +264,12 @@ _workspaces: dict = {}
 
 
 def get_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-device zero-initialised scratch shared by all layers (split-K slabs + arrival counters).
+    """Per-device zero-initialised scratch shared by all layers (split-K slabs + arrival counters,
+    rotated activations of the unfused routes).
 
     The GEMV kernels leave the counters at zero on exit, so one buffer serves every layer that
-    runs on the same stream; it only ever grows (never during graph capture: size it up front via
-    ``RotateQuantizedLinear.prepare`` / ``process_weights_after_loading``)."""
+    runs on the same stream; it only ever grows (never during graph capture: it is sized when the
+    layer is prepared)."""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     ws = _workspaces.get(key)
@@ -232,8 +279,9 @@ def get_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def decode_workspace_bytes(K: int, N: int, rows: int = 16) -> int:
-    return nat.PARO_WS_COUNTER_BYTES + (K // 128) * min(rows, 16) * N * 4
+def decode_workspace_bytes(K: int, N: int, n_parts: int, rows: int = 16) -> int:
+    """Mirror of ``paro_linear_workspace_bytes`` for rows <= 16."""
+    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 4 + n_parts * rows * K * 2
 
 
 # --------------------------------------------------------------------------------------
@@ -251,10 +299,13 @@ def _register() -> None:
     _libs.append(rot)
 
     par = torch.library.Library("paro", "DEF")
-    par.define("repack_awq(Tensor qweight, Tensor qzeros) -> (Tensor, Tensor)")
+    par.define("repack_awq(Tensor qweight, Tensor qzeros, Tensor scales, int[] partition_sizes) -> (Tensor, Tensor)")
     par.impl("repack_awq", _repack_impl, "CUDA")
     torch.library.register_fake("paro::repack_awq", _repack_fake, lib=par)
-    par.define("w4a16_linear(Tensor x, Tensor wq, Tensor zq, Tensor scales, Tensor pairs, Tensor theta, "
+    par.define("pack_rotation(Tensor pairs, Tensor theta) -> Tensor")
+    par.impl("pack_rotation", _pack_rotation_impl, "CUDA")
+    torch.library.register_fake("paro::pack_rotation", _pack_rotation_fake, lib=par)
+    par.define("w4a16_linear(Tensor x, Tensor wq, Tensor sz, Tensor rot, Tensor pairs, Tensor theta, "
                "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace) -> Tensor")
     par.impl("w4a16_linear", _w4a16_impl, "CUDA")
     torch.library.register_fake("paro::w4a16_linear", _w4a16_fake, lib=par)

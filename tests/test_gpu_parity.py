@@ -120,35 +120,71 @@ def test_rotate_inverse_and_norm_full_size(dev):
 
 # ---------------------------------------------------------------- repack / dequant (bit-exact)
 
-@pytest.mark.parametrize("K,N", [(128, 16), (256, 64), (512, 272), (4096, 1024)])
-def test_repack_dequant_bit_exact(dev, K, N):
+@pytest.mark.parametrize("K,sizes", [(128, [16]), (256, [64]), (512, [208, 48, 16]), (4096, [1024])])
+def test_repack_dequant_bit_exact(dev, K, sizes):
+    """Integer/byte work: the repack + (q - z) * s dequant are bit-exact against the oracle, and the
+    packed words match the layout spec of include/paro_abi.h."""
     from paroquant_amd import ops
-    L = po.make_layer(K + N, K, [N])
-    wq, zq = torch.ops.paro.repack_awq(_t(L["qweight"], dev), _t(L["qzeros"], dev))
-    w = ops.dequant_packed(wq, zq, _t(L["scales"], dev), K, N, torch.float16).cpu().numpy()
+    N = sum(sizes)
+    L = po.make_layer(K + N, K, sizes)
+    wq, sz = torch.ops.paro.repack_awq(_t(L["qweight"], dev), _t(L["qzeros"], dev), _t(L["scales"], dev), sizes)
+    w = ops.dequant_packed(wq, sz, K, sizes, torch.float16).cpu().numpy()
     ref = po.dequant_awq(L["qweight"], L["qzeros"], L["scales"], 128, np.float16)
     assert np.array_equal(w.view(np.uint16), ref.view(np.uint16))
-    # the packed words themselves match the layout spec in include/paro_abi.h
     q = po.unpack_awq(L["qweight"]).astype(np.uint32)          # [K, N]
     got = wq.cpu().numpy().view(np.uint32).reshape(N // 16, K // 128, 64, 4)
-    t, g, lane, i = 0, K // 128 - 1, 37, 2
+    t, g, lane, i = N // 16 - 1, K // 128 - 1, 37, 2
     n, kb = lane & 15, lane >> 4
     word = 0
     for e in range(8):
         word |= int(q[g * 128 + 32 * i + 8 * kb + e, t * 16 + n]) << (4 * ((e >> 1) + 4 * (e & 1)))
     assert int(got[t, g, lane, i]) == word
+    # scale/zero words: padded tile space, partition p starts at sum(pad8(tiles_q), q < p)
     z = po.unpack_awq(L["qzeros"]).astype(np.uint32)
-    zg = zq.cpu().numpy().view(np.uint32).reshape(K // 128, N // 8)
-    assert int(zg[0, 1]) == sum(int(z[0, 8 + j]) << (4 * j) for j in range(8))
+    tsz = sum((s // 16 + 7) // 8 * 8 for s in sizes)
+    szw = sz.cpu().numpy().view(np.uint32).reshape(K // 128, tsz // 4, 16, 4)
+    col0, ts0 = 0, 0
+    for s_ in sizes:
+        for (lt, nn) in ((0, 3), (s_ // 16 - 1, 15)):
+            col = col0 + lt * 16 + nn
+            ts = ts0 + lt
+            wv = int(szw[g, ts // 4, nn, ts % 4])
+            assert wv & 0xffff == int(L["scales"][g, col].view(np.uint16))
+            assert np.array([wv >> 16], dtype=np.uint16).view(np.float16)[0] == 16 + int(z[g, col])
+        col0 += s_
+        ts0 += (s_ // 16 + 7) // 8 * 8
+    # rotation words: i | j << 8 | theta bits << 16
+    rot = torch.ops.paro.pack_rotation(_t(L["pairs"], dev), _t(L["theta"], dev)).cpu().numpy().view(np.uint32)
+    rot = rot.reshape(len(sizes), K // 128, 64, 8)
+    # Each stage holds the same 64 (i, j, theta) rotations as the checkpoint -- possibly re-ordered over
+    # the lanes and re-oriented ((i, j, theta) == (j, i, -theta)) -- arranged so that within each 32-lane
+    # half all i are distinct mod 32 and all j are distinct mod 32 (bank-conflict-free LDS schedule).
+    for pp in range(len(sizes)):
+        for r in range(8):
+            w = rot[pp, g, :, r]
+            i, j, th = w & 0xff, (w >> 8) & 0xff, (w >> 16).astype(np.uint16)
+            got = set()
+            for a, b, t in zip(i.tolist(), j.tolist(), th.tolist()):
+                got.add((a, b, t))
+                got.add((b, a, t ^ 0x8000))
+            pr = L["pairs"][pp, r, g * 128:(g + 1) * 128].astype(np.int64)
+            tb = L["theta"][pp, r, g * 64:(g + 1) * 64].view(np.uint16)
+            for e in range(64):
+                assert (int(pr[2 * e]), int(pr[2 * e + 1]), int(tb[e])) in got
+            assert sorted(np.concatenate([i, j]).tolist()) == list(range(128))
+            for h in (slice(0, 32), slice(32, 64)):
+                assert len(set((i[h] % 32).tolist())) == 32 and len(set((j[h] % 32).tolist())) == 32
 
 
 def test_repack_rejects_bad_shapes(dev):
+    z = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    h = lambda *s: torch.zeros(*s, dtype=torch.float16, device=dev)
     with pytest.raises(ValueError):
-        torch.ops.paro.repack_awq(torch.zeros(100, 8, dtype=torch.int32, device=dev),
-                                  torch.zeros(1, 8, dtype=torch.int32, device=dev))
+        torch.ops.paro.repack_awq(z(100, 8), z(1, 8), h(1, 64), [64])        # K % 128
     with pytest.raises(ValueError):
-        torch.ops.paro.repack_awq(torch.zeros(128, 1, dtype=torch.int32, device=dev),
-                                  torch.zeros(1, 1, dtype=torch.int32, device=dev))
+        torch.ops.paro.repack_awq(z(128, 1), z(1, 1), h(1, 8), [8])          # N % 16
+    with pytest.raises(ValueError):
+        torch.ops.paro.repack_awq(z(128, 8), z(1, 8), h(1, 64), [32, 16])    # sizes do not sum to N
 
 
 # ---------------------------------------------------------------- fused GEMV (decode)
@@ -184,18 +220,21 @@ def test_gemv_matches_oracle(dev, K, sizes, rows):
 
 
 @pytest.mark.parametrize("tpw", [1, 2, 4, 8])
-@pytest.mark.parametrize("ksplit", [1, 2, 3, 0])
-def test_gemv_launch_shapes_agree(dev, tpw, ksplit):
-    """Every tiles-per-wave / K-split combination gives the same answer (split-K combine included)."""
+@pytest.mark.parametrize("ksplit,waves,mode", [(1, 4, 0), (2, 4, 0), (3, 8, 0), (0, 0, 0), (1, 16, 0), (2, 16, 0),
+                                               (1, 0, 1), (2, 4, 1)])
+def test_gemv_launch_shapes_agree(dev, tpw, ksplit, waves, mode):
+    """Every tiles-per-wave / K-split / waves-per-workgroup combination and the unfused (rotate pre-pass)
+    route give the same answer (split-K combine included)."""
     from paroquant_amd import ops
     K, sizes = 1536, [400, 112]      # 12 groups; 25 + 7 tiles -> ragged column blocks for every tpw
     L = po.make_layer(99, K, sizes, bias=True)
     rng = np.random.default_rng(5)
+    pk = _packed(L, dev, L["bias"])
     for rows in (1, 4, 6, 13):
+        if (rows > 4 and waves == 16) or (rows > 8 and tpw == 8) or (tpw == 8 and waves == 16):
+            continue   # combinations that are not built (see launch tables in gemv_impl.hpp)
         x = rng.standard_normal((rows, K)).astype(np.float16)
-        pk = _packed(L, dev, L["bias"])
-        y = ops.w4a16_gemv_tuned(_t(x, dev), pk.wq, pk.zq, pk.scales, pk.pairs, pk.theta, pk.channel_scales, pk.bias,
-                                 sizes, pk.workspace, tpw, ksplit)
+        y = ops.w4a16_gemv_tuned(_t(x, dev), pk, tpw, ksplit, waves, mode, pk.bias)
         ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
                                       L["channel_scales"], sizes, L["bias"], ideal=True)
         assert po.rel_err(_np(y), ideal) < TIGHT_F16
@@ -227,11 +266,12 @@ def test_gemv_bf16(dev):
         assert po.rel_err(_np(y), ideal) < TIGHT_BF16
 
 
-def test_gemv_generic_krot(dev):
-    """krot != 8 takes the runtime-krot build."""
+@pytest.mark.parametrize("krot", [1, 3, 8, 12])
+def test_gemv_other_krot(dev, krot):
+    """krot < 8 pads the packed coefficients with identity stages; krot > 8 takes the unfused route."""
     rng = np.random.default_rng(8)
     K, N = 512, 256
-    L = po.make_layer(31, K, [N], krot=3)
+    L = po.make_layer(31, K, [N], krot=krot)
     x = rng.standard_normal((2, K)).astype(np.float16)
     y = _packed(L, dev).apply(_t(x, dev))
     ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
@@ -289,7 +329,7 @@ def test_gemm_and_gemv_agree(dev):
     pk = _packed(L, dev)
     x = torch.randn(16, 1024, device=dev, dtype=torch.float16)
     y1 = pk.apply(x)
-    y2 = ops.w4a16_gemm_forced(x, pk.wq, pk.zq, pk.scales, pk.pairs, pk.theta, pk.channel_scales, None, L["sizes"])
+    y2 = ops.w4a16_gemm_forced(x, pk)
     assert (y1.float() - y2.float()).abs().max().item() <= 2e-3 * y1.float().abs().max().item()
 
 
@@ -323,7 +363,7 @@ def test_full_size_consistency_and_linearity(dev, K, sizes):
     cs = (torch.rand(P, 1, K, device=dev) * 1.5 + 0.5).half()
     from paroquant_amd.linear import PackedParoWeights
     pk = PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes)
-    W = ops.dequant_packed(pk.wq, pk.zq, pk.scales, K, N, torch.float16).float()
+    W = ops.dequant_packed(pk.wq, pk.sz, K, sizes, torch.float16).float()
     for rows in (1, 4, 48):
         x = torch.randn(rows, K, device=dev, dtype=torch.float16)
         y = pk.apply(x).float()

@@ -1,0 +1,176 @@
+"""CPU tests of the host side: C-ABI exports, operator registration, plug-in contract, loud failure."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from paroquant_amd import _native
+    if not os.path.exists(_native.lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return _native.load()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    """The shared object loads and exports every function include/paro_abi.h declares (no compute calls)."""
+    from paroquant_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "paro_abi.h")).read()
+    declared = set(re.findall(r"\b(paro_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.paro_abi_version() == _native.PARO_ABI_VERSION == int(re.search(r"PARO_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_abi_validation_without_gpu(lib):
+    """Argument validation happens on the host before any launch (same conditions/messages as
+    rotate_dynamic / rotate_launcher, rotation.cu:66,114-123)."""
+    one = ctypes.c_void_p(1)
+    assert lib.paro_rotate(one, one, one, one, None, 1, 256, 8, 32, 1, 1, None) == -2
+    assert b"group_size" in lib.paro_last_error()
+    assert lib.paro_rotate(one, one, one, one, None, 1, 200, 8, 128, 1, 1, None) == -1
+    assert b"divisible" in lib.paro_last_error()
+    assert lib.paro_rotate(one, one, one, one, None, 1, 256, 17, 128, 1, 1, None) == -2
+    assert lib.paro_packed_qweight_bytes(4096, 4096) == 4096 * 4096 // 2
+    assert lib.paro_packed_qweight_bytes(100, 64) == -1
+    sizes = (ctypes.c_int32 * 3)(4096, 1024, 1024)
+    assert lib.paro_packed_sz_bytes(4096, 3, sizes) == 32 * (256 + 64 + 64) * 16 * 4
+    sizes2 = (ctypes.c_int32 * 2)(48, 16)      # 3 + 1 tiles -> padded to 8 + 8
+    assert lib.paro_packed_sz_bytes(256, 2, sizes2) == 2 * 16 * 16 * 4
+    assert lib.paro_packed_rot_bytes(4096, 3) == 3 * 32 * 64 * 8 * 4
+
+
+def test_ops_registered_with_reference_schema():
+    import paroquant_amd  # noqa: F401
+    schema = str(torch.ops.rotation.rotate.default._schema)
+    assert schema == ("rotation::rotate(Tensor x, Tensor idx_ij, Tensor theta, Tensor? scales=None, "
+                      "int group_size=128) -> Tensor")
+    # fake (meta) kernel like kernels/cuda/__init__.py:54-61
+    x = torch.empty(3, 256, device="meta", dtype=torch.float16)
+    out = torch.ops.rotation.rotate(x, torch.empty(8, 256, device="meta", dtype=torch.int16),
+                                    torch.empty(8, 128, device="meta", dtype=torch.float16))
+    assert out.shape == x.shape and out.device.type == "meta"
+    # GPU-only, like the reference (rotation.cu:133-135): no CPU kernel, no silent fallback
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.rotation.rotate(torch.zeros(1, 128), torch.zeros(8, 128, dtype=torch.int16), torch.zeros(8, 64))
+
+
+def test_native_load_fails_loudly_when_library_missing(monkeypatch, tmp_path):
+    from paroquant_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_rotate_quantized_linear_api_matches_reference():
+    """Same ctor / buffer names / dtypes / shapes as transformers/modules.py:24-55."""
+    from paroquant_amd import RotateQuantizedLinear
+    m = RotateQuantizedLinear(512, 256, bias=True, group_size=128, bits=4, krot=8)
+    sd = m.state_dict()
+    expect = {"theta": ((8, 256), torch.float16), "pairs": ((8, 512), torch.int16),
+              "channel_scales": ((1, 512), torch.float16), "qweight": ((512, 32), torch.int32),
+              "qzeros": ((4, 32), torch.int32), "scales": ((4, 256), torch.float16), "bias": ((256,), torch.float16)}
+    assert set(sd) == set(expect)
+    for k, (shape, dt) in expect.items():
+        assert tuple(sd[k].shape) == shape and sd[k].dtype == dt
+    assert RotateQuantizedLinear(512, 256).bias is None
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 512, dtype=torch.float16))
+
+
+def test_vllm_config_and_loaders():
+    from paroquant_amd.vllm_plugin import (ParoQuantConfig, ParoQuantLinearMethod, _maybe_shard_input,
+                                           _rotation_weight_loader)
+    cfg = ParoQuantConfig.from_config({})
+    assert (cfg.bits, cfg.group_size, cfg.krot, cfg.zero_point, cfg.pack_factor) == (4, 128, 8, True, 8)
+    assert ParoQuantConfig.get_name() == "paroquant"
+    assert ParoQuantConfig.get_supported_act_dtypes() == [torch.half, torch.bfloat16]
+    with pytest.raises(ValueError, match="Unsupported bits"):
+        ParoQuantConfig(bits=3, group_size=128, krot=8, zero_point=True)
+    # shard-id dispatch of _rotation_weight_loader (plugin.py:53-76)
+    layer = torch.nn.Module()
+    ParoQuantLinearMethod(cfg).create_weights(layer, 256, [64, 32, 32], 256, 128, torch.float16)
+    assert layer.qweight.shape == (256, 16) and layer.qzeros.shape == (2, 16) and layer.scales.shape == (2, 128)
+    assert layer.channel_scales.data.eq(1).all() and layer.theta.shape == (3, 8, 128) and layer.num_partitions == 3
+    w = torch.arange(8 * 256, dtype=torch.int16).reshape(8, 256)
+    for sid, idx in (("q", 0), ("k", 1), ("v", 2), (1, 1)):
+        layer.pairs.data.zero_()
+        layer.pairs.weight_loader(layer.pairs, w, sid)
+        assert torch.equal(layer.pairs.data[idx], w) and layer.pairs.data.sum() == w.sum()
+    layer.pairs.data.zero_()
+    _rotation_weight_loader(layer.pairs, w, (0, 2))
+    assert torch.equal(layer.pairs.data[0], w) and torch.equal(layer.pairs.data[2], w) and layer.pairs.data[1].sum() == 0
+    single = torch.nn.Module()
+    ParoQuantLinearMethod(cfg).create_weights(single, 256, [64], 256, 64, torch.float16)
+    single.pairs.weight_loader(single.pairs, w)
+    assert torch.equal(single.pairs.data[0], w)
+    # row-parallel narrowing (plugin.py:33-50)
+    tgt = torch.zeros(8, 128, dtype=torch.int16)
+    assert torch.equal(_maybe_shard_input(tgt, w, tp_rank=1), w[:, 128:])
+    with pytest.raises(ValueError, match="incompatible shapes"):
+        _maybe_shard_input(torch.zeros(8, 100), w)
+    with pytest.raises(ValueError, match="not aligned"):
+        ParoQuantLinearMethod(cfg).create_weights(torch.nn.Module(), 200, [64], 200, 64, torch.float16)
+    # unquantised-layer detection (plugin.py:123-151)
+    meta = {"model.layers.0.self_attn.q_proj.qweight": {"dtype": "I32"},
+            "model.layers.0.self_attn.q_proj.scales": {"dtype": "F16"},
+            "model.layers.0.mlp.gate.weight": {"dtype": "BF16"},
+            "model.visual.blocks.0.attn.qkv.weight": {"dtype": "F16"},
+            "lm_head.weight": {"dtype": "F16"}}
+    assert ParoQuantConfig.unquantized_modules_from_metadata(meta) == ["layers.0.mlp.gate", "lm_head",
+                                                                        "visual.blocks.0.attn.qkv"]
+
+
+def test_hf_quantizer_swaps_only_quantized_linears(tmp_path):
+    from safetensors.torch import save_file
+
+    from paroquant_amd import RotateQuantizedLinear
+    from paroquant_amd.hf_quantizer import ParoQuantConfig, ParoQuantHfQuantizer, _find_quantized_modules, replace_linears
+    save_file({"model.layers.0.q_proj.qweight": torch.zeros(256, 8, dtype=torch.int32),
+               "model.layers.0.q_proj.theta": torch.zeros(8, 128, dtype=torch.float16),
+               "model.layers.0.gate.weight": torch.zeros(4, 256, dtype=torch.float16)},
+              str(tmp_path / "model.safetensors"))
+    assert _find_quantized_modules(str(tmp_path)) == {"model.layers.0.q_proj"}
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = torch.nn.Linear(256, 64, bias=False)
+            self.gate = torch.nn.Linear(256, 4, bias=False)
+
+    model = torch.nn.Module()
+    model.model = torch.nn.Module()
+    model.model.layers = torch.nn.ModuleList([Block()])
+    cfg = ParoQuantConfig()
+    assert (cfg.quant_method, cfg.bits, cfg.group_size, cfg.krot) == ("paroquant", 4, 128, 8)
+    assert replace_linears(model, {"model.layers.0.q_proj"}, cfg) == 1
+    assert isinstance(model.model.layers[0].q_proj, RotateQuantizedLinear)
+    assert isinstance(model.model.layers[0].gate, torch.nn.Linear)
+    q = ParoQuantHfQuantizer(cfg)
+    assert q.update_dtype(torch.bfloat16) == torch.float16 and not q.is_trainable
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU"):
+            q.validate_environment()
+    from transformers.quantizers.auto import AUTO_QUANTIZATION_CONFIG_MAPPING, AUTO_QUANTIZER_MAPPING
+    assert AUTO_QUANTIZER_MAPPING["paroquant"] is ParoQuantHfQuantizer
+    assert AUTO_QUANTIZATION_CONFIG_MAPPING["paroquant"] is ParoQuantConfig
+
+
+def test_bench_byte_model():
+    """bench.py's algorithmic-byte formula reproduces the BASELINE.md table."""
+    import bench
+    assert bench.alg_bytes(4096, 4096, 1) == 8839168
+    assert bench.alg_bytes(4096, 6144, 3) == 13414400
+    assert bench.alg_bytes(4096, 28672, 2) == 61292544
+    assert bench.alg_bytes(14336, 4096, 1) == 30916608
+    per_tok = 32 * sum(bench.alg_bytes(K, sum(s), len(s)) for _, K, s, _ in bench.layer_shapes("llama3-8b"))
+    assert per_tok == 32 * (13414400 + 8839168 + 61292544 + 30916608)

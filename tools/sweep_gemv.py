@@ -29,13 +29,17 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tpw", default="1,2,4,8")
-    ap.add_argument("--ksplit", default="0,1,2,4,8")
+    ap.add_argument("--ksplit", default="1,2,4")
+    ap.add_argument("--waves", default="4,8,16")
+    ap.add_argument("--mode", default="0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
     tpws = [int(t) for t in args.tpw.split(",")]
     ksps = [int(k) for k in args.ksplit.split(",")]
+    wvs = [int(k) for k in args.waves.split(",")]
+    modes = [int(k) for k in args.mode.split(",")]
     for name, K, sizes, _ in layer_shapes(args.model):
         nb = alg_bytes(K, sum(sizes), len(sizes))
         copies = max(2, min(48, int((1 << 30) // nb) + 1))
@@ -43,23 +47,21 @@ def main():
         x = torch.randn(args.rows, K, device=dev, dtype=torch.float16, generator=gen)
         graphs = {}
         G = K // 128
-        for tpw in tpws:
-            for ksp in ksps:
-                if ksp > max(1, G // 2):
-                    continue
+        import itertools
+        for tpw, ksp, wv, mode in itertools.product(tpws, ksps, wvs, modes):
+            if ksp > max(1, G // 2) or (tpw == 8 and wv == 16) or (args.rows > 4 and wv == 16):
+                continue
 
-                def run(i, tpw=tpw, ksp=ksp):
-                    p = packs[i % copies]
-                    return ops.w4a16_gemv_tuned(x, p.wq, p.zq, p.scales, p.pairs, p.theta, p.channel_scales, None,
-                                                sizes, p.workspace, tpw, ksp)
-                for i in range(3):
+            def run(i, tpw=tpw, ksp=ksp, wv=wv, mode=mode):
+                return ops.w4a16_gemv_tuned(x, packs[i % copies], tpw, ksp, wv, mode)
+            for i in range(3):
+                run(i)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(args.reps):
                     run(i)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for i in range(args.reps):
-                        run(i)
-                graphs[(tpw, ksp)] = g
+            graphs[(tpw, ksp, wv, mode)] = g
         times = {k: [] for k in graphs}
         for _ in range(args.rounds):
             for k, g in graphs.items():
@@ -69,10 +71,10 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[k].append(e0.elapsed_time(e1) * 1e3 / args.reps)
-        for (tpw, ksp), ts in sorted(times.items(), key=lambda kv: np.median(kv[1])):
+        for (tpw, ksp, wv, mode), ts in sorted(times.items(), key=lambda kv: np.median(kv[1])):
             us = float(np.median(ts))
             print(json.dumps({"model": args.model, "linear": name, "K": K, "N": sum(sizes), "rows": args.rows, "tpw": tpw,
-                              "ksplit": ksp, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
+                              "ksplit": ksp, "waves": wv, "mode": mode, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
                               "frac": round(nb / us / 1e3 / 8000, 4)}), flush=True)
         del graphs, packs
         torch.cuda.empty_cache()
