@@ -68,7 +68,7 @@ def layer_shapes(model: str, tp: int = 1):
     ]
 
 
-def synth_packed(K: int, sizes, dev, gen: torch.Generator):
+def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None):
     """Random layer in checkpoint format (SURVEY section 8d synthetic inputs), unit gain, repacked by the
     product path (torch.ops.paro.repack_awq)."""
     from paroquant_amd.linear import PackedParoWeights
@@ -84,7 +84,7 @@ def synth_packed(K: int, sizes, dev, gen: torch.Generator):
     rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=dev).item()))
     pairs = torch.from_numpy(np.stack([po.random_pairs(rng, 8, K) for _ in range(P)])).to(dev)
     cs = (torch.rand(P, 1, K, device=dev, generator=gen) * 1.5 + 0.5).half()
-    return PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes)
+    return PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes, wq_order=wq_order)
 
 
 class DecodeStack:

@@ -87,11 +87,11 @@ int paro_rotate(const void* x, void* out, const int16_t* idx_ij, const void* the
  *   scales  fp16  [K/128, N]
  *   part_cols[n_parts]          columns of each merged partition (multiples of 16, sum = N)
  * Outputs:
- *   out_wq  uint32 [N/16][K/128][64][4]   tile (t,g) = 1 KiB; lane l = (kb = l>>4, n = l&15), word i holds
+ *   out_wq  uint32 [N/16][K/128][64][4] (wq_order 0) or [K/128][N/16][64][4] (wq_order 1); tile (t,g) = 1 KiB; lane l = (kb = l>>4, n = l&15), word i holds
  *           k = 128g + 32i + 8kb + e (e = 0..7) of column 16t+n; element e sits in nibble (e>>1) + 4*(e&1)
  *           -- the v_mfma_f32_16x16x32 B-fragment order, the two k-adjacent nibbles 16 bits apart.
  *   out_sz  uint32 [K/128][Tsz/4][16][4]  one word per (group, column): lo16 = scale (fp16 bits),
- *           hi16 = fp16(16 + zero_point).  Column tiles are indexed in a padded tile space: partition p
+ *           hi16 = fp16(zero_point).  Column tiles are indexed in a padded tile space: partition p
  *           starts at the sum of its predecessors' tile counts rounded up to 8 (Tsz = that sum over all
  *           partitions); word ((g*Tsz/4 + ts/4)*16 + n)*4 + ts%4 belongs to padded tile ts, column n.
  *           Padding words are zero.
@@ -99,7 +99,7 @@ int paro_rotate(const void* x, void* out, const int16_t* idx_ij, const void* the
 int64_t paro_packed_qweight_bytes(int64_t K, int64_t N);
 int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols);
 int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
-                    int n_parts, const int32_t* part_cols, void* out_wq, void* out_sz, void* stream);
+                    int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz, void* stream);
 
 /* Rotation parameters -> one word per (partition, group, pair lane, stage):
  *   out_rot uint32 [n_parts][K/128][64][8]:  i | j << 8 | theta_fp16_bits << 16,
@@ -124,7 +124,7 @@ typedef struct paro_linear {
   int32_t krot;                       /* rotation stages (1..16), normally 8 */
   int32_t part_cols[PARO_MAX_PARTS];  /* columns per partition, each a multiple of 16 */
   int32_t act_dtype;                  /* PARO_DTYPE_F16 | PARO_DTYPE_BF16: dtype of x, y, bias */
-  int32_t reserved;
+  int32_t wq_order;                   /* tile order of wq: 0 = [tile][group], 1 = [group][tile] */
   const void* wq;                     /* packed INT4 tiles        (paro_repack_awq) */
   const void* sz;                     /* packed scale/zero words  (paro_repack_awq) */
   const void* rot;                    /* packed rotation words    (paro_pack_rotation); NULL iff krot > 8 */

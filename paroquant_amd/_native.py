@@ -48,7 +48,7 @@ class ParoLinearDesc(Structure):
         ("krot", c_int32),
         ("part_cols", c_int32 * PARO_MAX_PARTS),
         ("act_dtype", c_int32),
-        ("reserved", c_int32),
+        ("wq_order", c_int32),
         ("wq", c_void_p),
         ("sz", c_void_p),
         ("rot", c_void_p),
@@ -92,8 +92,8 @@ def load() -> ctypes.CDLL:
     lib.paro_packed_rot_bytes.restype = c_int64
     lib.paro_packed_rot_bytes.argtypes = [c_int64, c_int]
     lib.paro_repack_awq.restype = c_int
-    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int32), c_void_p,
-                                    c_void_p, c_void_p]
+    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int32), c_int,
+                                    c_void_p, c_void_p, c_void_p]
     lib.paro_pack_rotation.restype = c_int
     lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.paro_linear_workspace_bytes.restype = c_int64

@@ -119,6 +119,18 @@ struct Act<f16> {
     o[2] = ((w >> 2) & kMask) | kMagic;
     o[3] = ((w >> 6) & kMask) | kMagic;
   }
+  // Cheaper unpack for the VALU-bound GEMV: no shift for the nibbles that already sit on mantissa
+  // bits 0..3 (| 1024.0h -> 1024 + q) and 4..7 (| 64.0h -> 64 + q); one shift brings the other two
+  // pairs there.  5 VALU per word instead of 8; the per-element offsets (1024, 64, 1024, 64 per
+  // register) are removed with one extra MFMA against kOffFrag:  sum_k x_k off_k.
+  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4]) {
+    const unsigned t = w >> 8;
+    o[0] = (w & 0x000F000Fu) | 0x64006400u;
+    o[1] = (w & 0x00F000F0u) | 0x54005400u;
+    o[2] = (t & 0x000F000Fu) | 0x64006400u;
+    o[3] = (t & 0x00F000F0u) | 0x54005400u;
+  }
+  static constexpr unsigned kOffFrag0 = 0x64006400u, kOffFrag1 = 0x54005400u;  // registers 0/2 and 1/3
   __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
@@ -139,6 +151,15 @@ struct Act<bf16> {
     o[2] = ((w >> 5) & kMask) | kMagic;
     o[3] = ((w >> 9) & kMask) | kMagic;
   }
+  // bf16 has 7 mantissa bits: only bits 0..3 can hold a nibble without touching the exponent
+  // (| 128.0 -> 128 + q, exact in 8 significant bits); uniform offset 128, 7 VALU per word.
+  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4]) {
+    o[0] = (w & 0x000F000Fu) | 0x43004300u;
+    o[1] = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+    o[2] = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+    o[3] = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+  }
+  static constexpr unsigned kOffFrag0 = 0x43004300u, kOffFrag1 = 0x43004300u;
   __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }

@@ -26,6 +26,7 @@ struct GemmArgs {
   const unsigned short* xrot;  // [nparts][rows][K]
   unsigned short* y;
   int K, N, G, rows;
+  int tstride, gstride;        // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   PartTable pt;                // column blocks of BN_TILES tiles
 };
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nt) qv[j] = *(a.wq + ((int64_t)(tile0 + j) * a.G + g) * 64 + lane);
+      if (j < nt) qv[j] = *(a.wq + ((int64_t)(tile0 + j) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
     if (nt > 0) szv = *(const u32x4*)(szp + (int64_t)g * szrow);
   };
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
           for (int rt = 0; rt < 4; ++rt) d[rt] = A::mfma(af[rt][i], bf, d[rt]);
         }
         const float s = f16_bits_to_f32(szc[j] & 0xffffu);
-        const float zf = f16_bits_to_f32(szc[j] >> 16);
+        const float zf = f16_bits_to_f32(szc[j] >> 16) + 16.f;  // unpack() yields 16 + q
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -190,6 +191,8 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.N = (int)L->N;
   a.G = (int)(L->K / 128);
   a.rows = (int)rows;
+  a.tstride = L->wq_order ? 1 : a.G;
+  a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
   if (!fill_part_table(a.pt, L->n_parts, L->part_cols, BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
   const int64_t rb = (rows + BM - 1) / BM;
   if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * BM);

@@ -111,6 +111,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   a.G = G;
   a.rows = (int)rows;
   a.krot = L->krot;
+  a.tstride = L->wq_order ? 1 : G;
+  a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
   a.gps = (G + ksp - 1) / ksp;
   a.ksplit = (G + a.gps - 1) / a.gps;  // drop empty splits
   if (!fill_part_table(a.pt, L->n_parts, L->part_cols, tpw)) return fail(PARO_ERR_INVALID, "bad partition table");
@@ -118,6 +120,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   a.counters = nullptr;
   static const int env_flags = getenv("PARO_GEMV_FLAGS") ? atoi(getenv("PARO_GEMV_FLAGS")) : 0;
   a.flags = env_flags;
+  static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
+  a.pd = env_pd >= 1 && env_pd <= 3 ? env_pd : 1;
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)a.ksplit * rows * L->N * 4 : 0;
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;

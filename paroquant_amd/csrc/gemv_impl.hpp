@@ -45,13 +45,15 @@ struct GemvArgs {
   float* slabs;
   unsigned* counters;
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
+  int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int flags;                             // debug (PARO_GEMV_FLAGS): 16 = return at kernel entry (launch floor)
+  int pd;                                // software-pipeline distance in units (1 or 2)
   PartTable pt;
 };
 
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
-template <typename AT, int TPW, int MB, int WAVES, bool PREROT>
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>  // PD = prefetch distance in units (1 or 2)
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -141,22 +143,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int jj = j < nt ? j : nt - 1;
-      b.q[j] = __builtin_nontemporal_load(a.wq + ((int64_t)(tile0 + jj) * a.G + g) * 64 + lane);
+      b.q[j] = __builtin_nontemporal_load(a.wq + ((int64_t)(tile0 + jj) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
     }
     const unsigned* sp = a.sz + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
 #pragma unroll
     for (int v = 0; v < NSZ; ++v) b.sz[v] = *(const SZV*)(sp + v * 64);
   };
 
-  PBuf pc, pn;
-  TBuf tc, tn;
+  PBuf pc, pn, pn2;
+  TBuf tc, tn, tn2;
 
   // One work unit: rotate group g's slice of x (coefficients in pc), then consume its tiles (tc).
-  // PF = std::true_type: also request unit gn's coefficients (before the rotation) and tiles (before
-  // consuming this unit's tiles) -- the software pipeline.
-  auto step = [&](auto pf_tag, int gn) {
-    constexpr bool PF = decltype(pf_tag)::value;
-    if constexpr (PF) load_p(pn, gn);
+  // Software pipeline.  PFP: request coefficients of unit gp (before this unit's rotation); PFT:
+  // request tiles of unit gt (before this unit's tiles are consumed).  Coefficients are always
+  // requested before the tiles of the same unit (in-order vmcnt: a wait for coefficients never waits
+  // for younger tile loads).  PD selects the distances (measured, MI355X, same box, Llama-3-8B shapes):
+  //   PD 1: coefficients +1, tiles +1            gate_up 15.5 us  o_proj 6.9 us
+  //   PD 2: coefficients +2, tiles +2            gate_up 16.9 us  o_proj 7.8 us  (more bulk loads in
+  //         flight only lengthen the queue the small coefficient loads wait in)
+  //   PD 3: coefficients +2, tiles +1
+  auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt) {
+    constexpr bool PFP = decltype(pfp_tag)::value;
+    constexpr bool PFT = decltype(pft_tag)::value;
+    if constexpr (PFP) load_p(pn2, gp);
 
     // ---- A fragments of this group (4 x K=32)
     vec8 af[4];
@@ -209,14 +218,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
     }
-    f32x4 sx = {0.f, 0.f, 0.f, 0.f};
+    // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in)
+    f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
     {
       const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+      const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
       const vec8 ob = __builtin_bit_cast(vec8, ones);
+      const vec8 fb = __builtin_bit_cast(vec8, offs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sx = A::mfma(af[i], ob, sx);
+      for (int i = 0; i < 4; ++i) {
+        sx = A::mfma(af[i], ob, sx);
+        so = A::mfma(af[i], fb, so);
+      }
     }
-    if constexpr (PF) load_t(tn, gn);
+    if constexpr (PFT) load_t(tn2, gt);
 
     // ---- per tile: unpack -> 4 MFMA -> scale / zero point on the fp32 result
 #pragma unroll
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned w4[4];
-        A::unpack(tc.q[j][i], w4);
+        A::unpack_fast(tc.q[j][i], w4);
         const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
         d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
       }
@@ -233,21 +248,53 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       const float s = f16_bits_to_f32(szw & 0xffffu);
       const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
-      for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r]), acc[j][r]);
+      for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
     }
-    if constexpr (PF) {
+    if constexpr (PD == 1) {
+      if constexpr (PFP) pc = pn2;
+      if constexpr (PFT) tc = tn2;
+    } else {
       pc = pn;
-      tc = tn;
+      if constexpr (PFP) pn = pn2;
+      if constexpr (PD == 2) {
+        tc = tn;
+        if constexpr (PFT) tn = tn2;
+      } else if constexpr (PFT) {
+        tc = tn2;
+      }
     }
   };
 
   {
-    int g = g_begin + wave;
-    if (g < g_end) {
-      load_p(pc, g);
-      load_t(tc, g);
-      for (; g + WAVES < g_end; g += WAVES) step(std::true_type{}, g + WAVES);
-      step(std::false_type{}, g);
+    const int g0 = g_begin + wave;
+    const std::true_type yes{};
+    const std::false_type no{};
+    if (PD == 2 && g0 + WAVES < g_end) {  // >= 2 units: both units' coefficients, then both units' tiles, up front
+      load_p(pc, g0);
+      load_p(pn, g0 + WAVES);
+      load_t(tc, g0);
+      load_t(tn, g0 + WAVES);
+      for (int g = g0; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + 2 * WAVES);
+      step(no, no, 0, 0);
+      step(no, no, 0, 0);
+    } else if (PD == 3 && g0 + WAVES < g_end) {
+      load_p(pc, g0);
+      load_p(pn, g0 + WAVES);
+      load_t(tc, g0);
+      int g = g0;
+      for (; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + WAVES);
+      step(no, yes, 0, g + WAVES);
+      step(no, no, 0, 0);
+    } else if (PD == 1 && g0 < g_end) {  // distance 1: the next unit is requested while this one is processed
+      load_p(pc, g0);
+      load_t(tc, g0);
+      int g = g0;
+      for (; g + WAVES < g_end; g += WAVES) step(yes, yes, g + WAVES, g + WAVES);
+      step(no, no, 0, 0);
+    } else if (g0 < g_end) {
+      load_p(pc, g0);
+      load_t(tc, g0);
+      step(no, no, 0, 0);
     }
   }
 
@@ -301,23 +348,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 }
 
 // ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
-template <typename AT, int TPW, int MB, bool PREROT>
-int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+template <typename AT, int TPW, int MB, bool PREROT, int PD>
+int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (MB <= 4 && TPW <= 4) {
     if (waves == 16) {
-      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT>), grid, dim3(1024), 0, st, a);
+      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
       return PARO_OK;
     }
   }
   if (waves == 8) {
-    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 8, PREROT>), grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 8, PREROT, PD>), grid, dim3(512), 0, st, a);
     return PARO_OK;
   }
   if (waves == 4) {
-    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT, PD>), grid, dim3(256), 0, st, a);
     return PARO_OK;
   }
   return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d batch rows", waves, MB);
+}
+
+template <typename AT, int TPW, int MB, bool PREROT>
+int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (a.pd == 2) return launch_waves_pd<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
+  if (a.pd == 3) return launch_waves_pd<AT, TPW, MB, PREROT, 3>(a, waves, grid, st);
+  return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 
 template <typename AT, int TPW, bool PREROT>

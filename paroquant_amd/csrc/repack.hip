@@ -14,9 +14,9 @@ __device__ __forceinline__ unsigned awq_nibble(unsigned word, int col_in_word) {
   return (word >> (4 * p)) & 0xFu;
 }
 
-// one thread per output word: out[((t * G + g) * 64 + lane) * 4 + i]
+// one thread per output word: out[(chunk(t, g) * 64 + lane) * 4 + i], chunk = t*G+g (order 0) or g*T+t (order 1)
 __global__ __launch_bounds__(256) void repack_qweight_kernel(const unsigned* __restrict__ qw,
-                                                            unsigned* __restrict__ out, int K, int N) {
+                                                            unsigned* __restrict__ out, int K, int N, int order) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int G = K / 128;
   const int64_t total = (int64_t)(N / 16) * G * 256;
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void repack_qweight_kernel(const unsigned* __r
     const unsigned q = awq_nibble(qw[(int64_t)(k0 + e) * NW + wcol], cin);
     o |= q << (4 * ((e >> 1) + 4 * (e & 1)));
   }
-  out[gid] = o;
+  const int64_t chunk = order ? (int64_t)g * (N / 16) + t : tg;
+  out[(chunk << 8) | (gid & 255)] = o;
 }
 
 // one thread per (group, real column): scale + zero point -> one word in the padded tile space
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void pack_sz_kernel(const unsigned* __restrict
   const int p = pt.part_of_tile(t);
   const int ts = pt.szt_start[p] + (t - pt.tile_start[p]);
   const unsigned z = awq_nibble(qz[(int64_t)g * (N / 8) + (col >> 3)], col & 7);
-  const unsigned zf = f32_to_f16_bits((float)(16 + z));
+  const unsigned zf = f32_to_f16_bits((float)z);
   const unsigned s = scales[(int64_t)g * N + col];
   out[(((int64_t)g * (pt.tsz / 4) + (ts >> 2)) * 16 + n) * 4 + (ts & 3)] = s | (zf << 16);
 }
@@ -188,7 +189,7 @@ template <typename AT>
 __global__ __launch_bounds__(256) void dequant_packed_kernel(const unsigned* __restrict__ wq,
                                                             const unsigned* __restrict__ sz,
                                                             unsigned short* __restrict__ out, int K, int N,
-                                                            PartTable pt) {
+                                                            PartTable pt, int order) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)K * N) return;
   const int k = (int)(gid / N), n = (int)(gid % N);
@@ -196,14 +197,15 @@ __global__ __launch_bounds__(256) void dequant_packed_kernel(const unsigned* __r
   const int g = k >> 7, kk = k & 127;
   const int i = kk >> 5, kb = (kk >> 3) & 3, e = kk & 7;
   const int t = n >> 4, lane = (kb << 4) | (n & 15);
-  const unsigned w = wq[(((int64_t)t * G + g) * 64 + lane) * 4 + i];
+  const int64_t chunk = order ? (int64_t)g * (N / 16) + t : (int64_t)t * G + g;
+  const unsigned w = wq[(chunk * 64 + lane) * 4 + i];
   const int q = (int)((w >> (4 * ((e >> 1) + 4 * (e & 1)))) & 0xF);
   const int p = pt.part_of_tile(t);
   const int ts = pt.szt_start[p] + (t - pt.tile_start[p]);
   const unsigned word = sz[(((int64_t)g * (pt.tsz / 4) + (ts >> 2)) * 16 + (n & 15)) * 4 + (ts & 3)];
   const float s = f16_bits_to_f32(word & 0xffffu);
-  const float zf = f16_bits_to_f32(word >> 16);  // 16 + z
-  out[gid] = Act<AT>::from_f32(((float)(q + 16) - zf) * s);
+  const float zf = f16_bits_to_f32(word >> 16);  // zero point
+  out[gid] = Act<AT>::from_f32(((float)q - zf) * s);
 }
 
 }  // namespace paro
@@ -225,7 +227,8 @@ extern "C" int64_t paro_packed_rot_bytes(int64_t K, int n_parts) {
 }
 
 extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
-                               int n_parts, const int32_t* part_cols, void* out_wq, void* out_sz, void* stream) {
+                               int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz,
+                               void* stream) {
   using namespace paro;
   if (K <= 0 || N <= 0 || K % 128 != 0)
     return fail(PARO_ERR_INVALID, "in_features must be a multiple of 128 (got %lld)", (long long)K);
@@ -238,7 +241,7 @@ extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, co
   hipStream_t st = (hipStream_t)stream;
   const int64_t words = K * N / 8;
   hipLaunchKernelGGL(repack_qweight_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
-                     (const unsigned*)qweight, (unsigned*)out_wq, (int)K, (int)N);
+                     (const unsigned*)qweight, (unsigned*)out_wq, (int)K, (int)N, wq_order ? 1 : 0);
   const int G = (int)(K / 128);
   (void)hipMemsetAsync(out_sz, 0, (size_t)G * pt.tsz * 64, st);
   const int64_t cols = (int64_t)G * N;
@@ -271,10 +274,10 @@ extern "C" int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* st
   hipStream_t st = (hipStream_t)stream;
   if (L->act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(dequant_packed_kernel<f16>, grid, dim3(256), 0, st, (const unsigned*)L->wq,
-                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt);
+                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order);
   else if (L->act_dtype == PARO_DTYPE_BF16)
     hipLaunchKernelGGL(dequant_packed_kernel<bf16>, grid, dim3(256), 0, st, (const unsigned*)L->wq,
-                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt);
+                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order);
   else
     return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
   return check_launch("paro_dequant_packed");

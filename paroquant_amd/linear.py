@@ -47,7 +47,8 @@ class PackedParoWeights:
     """
 
     def __init__(self, qweight, qzeros, scales, theta, pairs, channel_scales, partition_sizes: Sequence[int],
-                 bias: Optional[torch.Tensor] = None, group_size: int = 128, bits: int = 4):
+                 bias: Optional[torch.Tensor] = None, group_size: int = 128, bits: int = 4,
+                 wq_order: Optional[int] = None):
         if bits != 4:
             raise ValueError(f"Unsupported bits={bits}. Supported: [4]")          # plugin.py:84-85
         if group_size != 128:
@@ -70,8 +71,11 @@ class PackedParoWeights:
         self.channel_scales = channel_scales.to(torch.float16).contiguous()
         # kernel layouts: INT4 tiles in MFMA B-fragment order, one (scale, 16 + zero) word per (group,
         # column), one (i, j, theta) word per (group, pair lane, stage)  -- include/paro_abi.h
+        # wide outputs are streamed 8 tiles per wave: keep a wave's tiles contiguous ([group][tile] order);
+        # narrow outputs run one tile per 16-wave workgroup: keep a workgroup's groups contiguous
+        self.wq_order = int(wq_order) if wq_order is not None else (1 if N // 16 >= 1024 else 0)
         self.wq, self.sz = torch.ops.paro.repack_awq(qweight, qzeros, scales.to(torch.float16),
-                                                     self.partition_sizes)
+                                                     self.partition_sizes, self.wq_order)
         self.rot = torch.ops.paro.pack_rotation(self.pairs, self.theta)
         self.bias = bias
         self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N, P))
@@ -81,7 +85,8 @@ class PackedParoWeights:
         if b is not None and b.dtype != x.dtype:
             b = b.to(x.dtype)
         return torch.ops.paro.w4a16_linear(x, self.wq, self.sz, self.rot, self.pairs, self.theta,
-                                           self.channel_scales, b, self.partition_sizes, self.workspace)
+                                           self.channel_scales, b, self.partition_sizes, self.workspace,
+                                           self.wq_order)
 
     def nbytes(self) -> int:
         ts = [self.wq, self.sz, self.rot, self.channel_scales]

@@ -82,7 +82,7 @@ def _part_array(partition_sizes: Sequence[int]):
 
 
 def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
-                 partition_sizes: Sequence[int]):
+                 partition_sizes: Sequence[int], wq_order: int = 0):
     lib = nat.load()
     if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
         raise RuntimeError("qweight / qzeros must be int32 (AWQ packing, cli/convert.py:149-155)")
@@ -102,11 +102,11 @@ def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
     wq = torch.empty(lib.paro_packed_qweight_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
     sz = torch.empty(lib.paro_packed_sz_bytes(K, len(sizes), arr) // 4, dtype=torch.int32, device=qweight.device)
     nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, len(sizes), arr,
-                                  wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
+                                  int(wq_order), wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
     return wq, sz
 
 
-def _repack_fake(qweight, qzeros, scales, partition_sizes):
+def _repack_fake(qweight, qzeros, scales, partition_sizes, wq_order=0):
     K, NW = qweight.shape
     tsz = sum((int(s) // 16 + 7) // 8 * 8 for s in partition_sizes)
     return qweight.new_empty(K * NW), qweight.new_empty((K // 128) * tsz * 16)
@@ -140,7 +140,7 @@ def _pack_rotation_fake(pairs, theta):
 
 
 def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, sz, rot, pairs,
-              theta, channel_scales, bias) -> nat.ParoLinearDesc:
+              theta, channel_scales, bias, wq_order: int = 0) -> nat.ParoLinearDesc:
     d = nat.ParoLinearDesc()
     d.K = K
     d.N = int(sum(partition_sizes))
@@ -151,6 +151,7 @@ def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torc
     for i, n in enumerate(partition_sizes):
         d.part_cols[i] = int(n)
     d.act_dtype = nat.dtype_code(act_dtype)
+    d.wq_order = int(wq_order)
     d.wq = wq.data_ptr()
     d.sz = sz.data_ptr()
     d.rot = rot.data_ptr() if rot is not None and rot.numel() > 0 else None
@@ -182,7 +183,7 @@ def _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes):
 
 def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.Tensor, pairs: torch.Tensor,
                 theta: torch.Tensor, channel_scales: torch.Tensor, bias: Optional[torch.Tensor],
-                partition_sizes: Sequence[int], workspace: torch.Tensor) -> torch.Tensor:
+                partition_sizes: Sequence[int], workspace: torch.Tensor, wq_order: int = 0) -> torch.Tensor:
     lib = nat.load()
     partition_sizes = [int(s) for s in partition_sizes]
     _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes)
@@ -193,7 +194,8 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     if rows == 0:
         return y.reshape(*x.shape[:-1], N)
-    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias)
+    d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias,
+                  wq_order)
     ws = workspace
     if rows > 16:
         # prefill: rotated activations live in a scratch buffer from torch's caching allocator
@@ -205,7 +207,7 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
     return y.reshape(*x.shape[:-1], N)
 
 
-def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace):
+def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace, wq_order=0):
     return x.new_empty((*x.shape[:-1], int(sum(partition_sizes))))
 
 
@@ -220,7 +222,7 @@ def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                  pk.channel_scales, bias)
+                  pk.channel_scales, bias, pk.wq_order)
     ws = pk.workspace
     nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
                                   ws.numel() * ws.element_size(), tiles_per_wave, ksplit, waves, mode,
@@ -237,7 +239,7 @@ def w4a16_gemm_forced(x, pk, bias=None) -> torch.Tensor:
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                  pk.channel_scales, bias)
+                  pk.channel_scales, bias, pk.wq_order)
     need = nat.PARO_WS_COUNTER_BYTES + len(pk.partition_sizes) * rows * K * 2
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(), need,
@@ -245,7 +247,7 @@ def w4a16_gemm_forced(x, pk, bias=None) -> torch.Tensor:
     return y.reshape(*x.shape[:-1], N)
 
 
-def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.float16) -> torch.Tensor:
+def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.float16, wq_order: int = 0) -> torch.Tensor:
     """Dense ``W[K, N] = (q - z) * s`` from the packed buffers (verification aid)."""
     lib = nat.load()
     N = int(sum(partition_sizes))
@@ -255,6 +257,7 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
     for i, n in enumerate(partition_sizes):
         d.part_cols[i] = int(n)
     d.act_dtype = nat.dtype_code(dtype)
+    d.wq_order = int(wq_order)
     d.wq, d.sz = wq.data_ptr(), sz.data_ptr()
     nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
     return out
@@ -299,14 +302,15 @@ def _register() -> None:
     _libs.append(rot)
 
     par = torch.library.Library("paro", "DEF")
-    par.define("repack_awq(Tensor qweight, Tensor qzeros, Tensor scales, int[] partition_sizes) -> (Tensor, Tensor)")
+    par.define("repack_awq(Tensor qweight, Tensor qzeros, Tensor scales, int[] partition_sizes, int wq_order=0) "
+               "-> (Tensor, Tensor)")
     par.impl("repack_awq", _repack_impl, "CUDA")
     torch.library.register_fake("paro::repack_awq", _repack_fake, lib=par)
     par.define("pack_rotation(Tensor pairs, Tensor theta) -> Tensor")
     par.impl("pack_rotation", _pack_rotation_impl, "CUDA")
     torch.library.register_fake("paro::pack_rotation", _pack_rotation_fake, lib=par)
     par.define("w4a16_linear(Tensor x, Tensor wq, Tensor sz, Tensor rot, Tensor pairs, Tensor theta, "
-               "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace) -> Tensor")
+               "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace, int wq_order=0) -> Tensor")
     par.impl("w4a16_linear", _w4a16_impl, "CUDA")
     torch.library.register_fake("paro::w4a16_linear", _w4a16_fake, lib=par)
     _libs.append(par)

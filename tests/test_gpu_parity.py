@@ -150,7 +150,7 @@ def test_repack_dequant_bit_exact(dev, K, sizes):
             ts = ts0 + lt
             wv = int(szw[g, ts // 4, nn, ts % 4])
             assert wv & 0xffff == int(L["scales"][g, col].view(np.uint16))
-            assert np.array([wv >> 16], dtype=np.uint16).view(np.float16)[0] == 16 + int(z[g, col])
+            assert np.array([wv >> 16], dtype=np.uint16).view(np.float16)[0] == int(z[g, col])
         col0 += s_
         ts0 += (s_ // 16 + 7) // 8 * 8
     # rotation words: i | j << 8 | theta bits << 16
@@ -323,10 +323,16 @@ def test_gemm_matches_oracle(dev, K, sizes, rows):
     assert po.rel_err(_np(y), ideal) < TIGHT_F16
 
 
-def test_gemm_and_gemv_agree(dev):
+@pytest.mark.parametrize("wq_order", [0, 1])
+def test_gemm_and_gemv_agree(dev, wq_order):
+    """Both tile orders of the packed weights ([tile][group] / [group][tile]) feed both kernels correctly."""
     from paroquant_amd import ops
+    from paroquant_amd.linear import PackedParoWeights
     L = po.make_layer(77, 1024, [512, 256])
-    pk = _packed(L, dev)
+    pk = PackedParoWeights(_t(L["qweight"], dev), _t(L["qzeros"], dev), _t(L["scales"], dev), _t(L["theta"], dev),
+                           _t(L["pairs"], dev), _t(L["channel_scales"], dev), L["sizes"], wq_order=wq_order)
+    W = ops.dequant_packed(pk.wq, pk.sz, 1024, L["sizes"], torch.float16, wq_order).cpu().numpy()
+    assert np.array_equal(W.view(np.uint16), po.dequant_awq(L["qweight"], L["qzeros"], L["scales"]).view(np.uint16))
     x = torch.randn(16, 1024, device=dev, dtype=torch.float16)
     y1 = pk.apply(x)
     y2 = ops.w4a16_gemm_forced(x, pk)
@@ -363,7 +369,7 @@ def test_full_size_consistency_and_linearity(dev, K, sizes):
     cs = (torch.rand(P, 1, K, device=dev) * 1.5 + 0.5).half()
     from paroquant_amd.linear import PackedParoWeights
     pk = PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes)
-    W = ops.dequant_packed(pk.wq, pk.sz, K, sizes, torch.float16).float()
+    W = ops.dequant_packed(pk.wq, pk.sz, K, sizes, torch.float16, pk.wq_order).float()
     for rows in (1, 4, 48):
         x = torch.randn(rows, K, device=dev, dtype=torch.float16)
         y = pk.apply(x).float()

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--ksplit", default="1,2,4")
     ap.add_argument("--waves", default="4,8,16")
     ap.add_argument("--mode", default="0")
+    ap.add_argument("--order", type=int, default=-1, help="wq tile order: 0 [tile][group], 1 [group][tile], -1 auto")
+    ap.add_argument("--only", default="", help="comma-separated linear names to run")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev)
@@ -43,7 +45,9 @@ def main():
     for name, K, sizes, _ in layer_shapes(args.model):
         nb = alg_bytes(K, sum(sizes), len(sizes))
         copies = max(2, min(48, int((1 << 30) // nb) + 1))
-        packs = [synth_packed(K, sizes, dev, gen) for _ in range(copies)]
+        if args.only and name not in args.only.split(","):
+            continue
+        packs = [synth_packed(K, sizes, dev, gen, None if args.order < 0 else args.order) for _ in range(copies)]
         x = torch.randn(args.rows, K, device=dev, dtype=torch.float16, generator=gen)
         graphs = {}
         G = K // 128
@@ -74,7 +78,7 @@ def main():
         for (tpw, ksp, wv, mode), ts in sorted(times.items(), key=lambda kv: np.median(kv[1])):
             us = float(np.median(ts))
             print(json.dumps({"model": args.model, "linear": name, "K": K, "N": sum(sizes), "rows": args.rows, "tpw": tpw,
-                              "ksplit": ksp, "waves": wv, "mode": mode, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
+                              "ksplit": ksp, "waves": wv, "mode": mode, "order": packs[0].wq_order, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
                               "frac": round(nb / us / 1e3 / 8000, 4)}), flush=True)
         del graphs, packs
         torch.cuda.empty_cache()
