@@ -17,6 +17,6 @@ extern "C" const char* paro_last_error(void) { return paro::error_buffer(); }
 // once through the fused GEMV kernel, everything else goes rotate pre-pass + MFMA GEMM.
 extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  if (rows <= 16) return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, stream);
+  if (rows <= 16) return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, -1, stream);
   return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, stream);
 }

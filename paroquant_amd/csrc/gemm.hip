@@ -16,7 +16,7 @@
 namespace paro {
 
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
-                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st);
+                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 int validate_linear(const paro_linear_t* L);
 
 struct GemmArgs {
@@ -174,13 +174,9 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES);
-  for (int p = 0; p < L->n_parts; ++p) {
-    rc = launch_rotate(x, xrot + (int64_t)p * rows * L->K, L->pairs + (int64_t)p * L->krot * L->K,
-                       (const unsigned short*)L->theta + (int64_t)p * L->krot * (L->K / 2),
-                       (const unsigned short*)L->channel_scales + (int64_t)p * L->K, rows, L->K, L->krot, 128,
-                       L->act_dtype, PARO_DTYPE_F16, st);
-    if (rc != PARO_OK) return rc;
-  }
+  rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
+                     PARO_DTYPE_F16, st, L->n_parts);  // one launch, blockIdx.z = merged partition
+  if (rc != PARO_OK) return rc;
   GemmArgs a;
   a.wq = (const u32x4*)L->wq;
   a.sz = (const unsigned*)L->sz;

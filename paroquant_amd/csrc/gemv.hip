@@ -6,7 +6,7 @@
 namespace paro {
 
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
-                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st);
+                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 
 int validate_linear(const paro_linear_t* L) {
   if (!L) return fail(PARO_ERR_INVALID, "null layer descriptor");
@@ -39,23 +39,31 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   // Measured on MI355X (tools/sweep_gemv.py; Llama-3-8B, Qwen3-4B, Qwen3-0.6B shapes, M = 1):
   //   * every workgroup rotates all the groups it covers, so the total rotation work is
   //     (#column blocks) x K/128 group rotations (~100 LDS cycles each): wide outputs want few, fat
-  //     column blocks (tpw 8), narrow outputs are launch/latency bound and want one tile per block;
-  //   * an in-launch K-split costs ~3.5 us (three dependent trips to the coherence point), so it
-  //     only pays for deep-K / narrow-N layers (down_proj), where it also cuts the rotation chain.
+  //     column blocks (tpw 8), narrow outputs are launch/latency bound and want one or two tiles;
+  //   * the in-launch K-split (data-tagged granules) costs one round trip to the coherence point
+  //     (~1.5-2 us): it pays for deep-K / narrow-N layers (down_proj: tpw 4 x ksplit 4), where it
+  //     also cuts the per-workgroup rotation chain, and marginally for K >= 4096 with <= 320 tiles.
   const int G = (int)(L->K / 128);
   const int64_t tiles = L->N / 16;
   const bool auto_tpw = tpw <= 0, auto_ks = ksplit <= 0, auto_wv = waves <= 0;
-  const bool deep_narrow = tiles <= 320 && G >= 64;
-  if (auto_tpw) {
+  const bool narrow = tiles <= 320;
+  if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {
+    if (G >= 64) {          // down_proj class
+      tpw = 4; ksplit = 4; waves = 8;
+    } else {                // o_proj class
+      tpw = 2; ksplit = 2; waves = 8;
+    }
+  }
+  if (tpw <= 0) {
     if (tiles >= 1024)
       tpw = rows > 8 ? 4 : 8;
     else if (tiles >= 320)
       tpw = 2;
     else
-      tpw = (deep_narrow && auto_ks) ? 4 : 1;
+      tpw = 1;
   }
-  if (auto_ks) ksplit = (deep_narrow && tpw == 4) ? 4 : 1;
-  if (auto_wv) {
+  if (ksplit <= 0) ksplit = 1;
+  if (waves <= 0) {
     if (rows > 4 || tpw > 2 || G < 24)
       waves = G >= 8 ? 8 : 4;
     else
@@ -73,7 +81,7 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
   const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
-  const int64_t slabs = r <= 16 ? (int64_t)kMaxKsplit * r * L->N * 4 : 0;
+  const int64_t slabs = r <= 16 ? (int64_t)kMaxKsplit * r * L->N * 8 : 0;  // 8-byte {tag, partial} granules
   return PARO_WS_COUNTER_BYTES + slabs + xrot;
 }
 
@@ -90,8 +98,13 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (tpw != 0 && tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8)
     return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto), 1, 2, 4 or 8 (got %d)", tpw);
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
-  if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be 0 (fused) or 1 (rotate pre-pass)");
+  const bool mode_auto = mode < 0;
+  if (mode_auto) mode = 0;
+  if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
   if (L->krot > 8) mode = 1;  // the packed-coefficient fast path holds 8 stages
+  // > 8 batch rows: rotating 16 rows inside every workgroup costs more LDS time than the weights take to
+  // stream (measured: gate_up M=16 fused 61 us vs 31 us with the pre-pass), so rotate once up front
+  if (mode_auto && rows > 8) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && tpw > 4) tpw = 4;
   if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
@@ -121,9 +134,9 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   static const int env_flags = getenv("PARO_GEMV_FLAGS") ? atoi(getenv("PARO_GEMV_FLAGS")) : 0;
   a.flags = env_flags;
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
-  a.pd = env_pd >= 1 && env_pd <= 3 ? env_pd : 1;
+  a.pd = (env_pd == 11 || env_pd == 12) ? env_pd : 1;
 
-  const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)a.ksplit * rows * L->N * 4 : 0;
+  const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
   const int64_t need = PARO_WS_COUNTER_BYTES + slab_bytes + xrot_bytes;
   if (slab_bytes + xrot_bytes > 0) {
@@ -131,17 +144,14 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
       return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
     if ((int64_t)a.pt.cbs * 4 > PARO_WS_COUNTER_BYTES) return fail(PARO_ERR_INVALID, "too many column blocks for the counter area");
     a.counters = (unsigned*)workspace;
-    a.slabs = (float*)((char*)workspace + PARO_WS_COUNTER_BYTES);
+    a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
   if (mode == 1) {
     unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);
-    for (int p = 0; p < L->n_parts; ++p) {
-      rc = launch_rotate(x, xrot + (int64_t)p * rows * L->K, L->pairs + (int64_t)p * L->krot * L->K,
-                         (const unsigned short*)L->theta + (int64_t)p * L->krot * (L->K / 2),
-                         (const unsigned short*)L->channel_scales + (int64_t)p * L->K, rows, L->K, L->krot, 128,
-                         L->act_dtype, PARO_DTYPE_F16, st);
-      if (rc != PARO_OK) return rc;
-    }
+    // ONE launch rotates x with every merged partition's parameters (blockIdx.z = partition)
+    rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
+                       PARO_DTYPE_F16, st, L->n_parts);
+    if (rc != PARO_OK) return rc;
     a.x = xrot;
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit);

@@ -24,9 +24,10 @@
 //     so a single accumulator register per tile suffices.
 //   * the WAVES (4..16) waves of a workgroup take different groups of the same columns and
 //     reduce through LDS; by default one workgroup covers ALL of K, so no cross-workgroup
-//     reduction exists.  An optional K-split (grid.y) is combined in-launch without fences:
-//     write-through (sc1) slab stores -> drain -> barrier -> one relaxed agent-scope ticket;
-//     the last arriver reads the slabs with sc1 loads and writes y exactly once.
+//     reduction exists.  An optional K-split (grid.y) is combined in-launch with data-tagged
+//     granules: the first ksplit-1 splits write {tag, partial} 8-byte granules with ONE
+//     write-through (sc1) store per output and exit; the last split polls them (sc1 loads, bounded
+//     spin), re-arms them, and writes y exactly once -- no fences, no tickets, one round trip.
 #pragma once
 #include <type_traits>
 
@@ -42,7 +43,7 @@ struct GemvArgs {
   const unsigned short* bias;
   const unsigned short* x;  // [rows][K], or pre-rotated [nparts][rows][K] when PREROT
   unsigned short* y;
-  float* slabs;
+  unsigned long long* slabs;  // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]
   unsigned* counters;
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
@@ -57,6 +58,8 @@ template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>  // PD =
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
+  constexpr int PDIST = PD % 10;   // pipeline distance variant
+  constexpr int DIAG = PD / 10;    // diagnostics (tools/ablate): 1 = no rotation stages, 2 = also no unpack/MFMA (pure stream)
   constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile
   constexpr int VW = MB >= 4 ? 4 : MB;                  // LDS vector width of the rotation state
   constexpr int NCH = MB / VW;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        if (r < a.krot) {
+        if (DIAG == 0 && r < a.krot) {
           const unsigned w = r < 4 ? pc.r0[r & 3] : pc.r1[r & 3];
           const int i = (int)(w & 0xffu), j = (int)((w >> 8) & 0xffu);
           float s, c;
@@ -237,12 +240,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (DIAG == 2) {
+        d[0] = __builtin_bit_cast(float, (tc.q[j][0] ^ tc.q[j][1] ^ tc.q[j][2] ^ tc.q[j][3]) & 0x3fffffffu);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned w4[4];
-        A::unpack_fast(tc.q[j][i], w4);
-        const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
-        d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+        for (int i = 0; i < 4; ++i) {
+          unsigned w4[4];
+          A::unpack_fast(tc.q[j][i], w4);
+          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+        }
       }
       const unsigned szw = tc.sz[j / 4][j % 4];
       const float s = f16_bits_to_f32(szw & 0xffffu);
@@ -250,13 +257,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
     }
-    if constexpr (PD == 1) {
+    if constexpr (PDIST == 1) {
       if constexpr (PFP) pc = pn2;
       if constexpr (PFT) tc = tn2;
     } else {
       pc = pn;
       if constexpr (PFP) pn = pn2;
-      if constexpr (PD == 2) {
+      if constexpr (PDIST == 2) {
         tc = tn;
         if constexpr (PFT) tn = tn2;
       } else if constexpr (PFT) {
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     const int g0 = g_begin + wave;
     const std::true_type yes{};
     const std::false_type no{};
-    if (PD == 2 && g0 + WAVES < g_end) {  // >= 2 units: both units' coefficients, then both units' tiles, up front
+    if (PDIST == 2 && g0 + WAVES < g_end) {  // >= 2 units: both units' coefficients, then both units' tiles, up front
       load_p(pc, g0);
       load_p(pn, g0 + WAVES);
       load_t(tc, g0);
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       for (int g = g0; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + 2 * WAVES);
       step(no, no, 0, 0);
       step(no, no, 0, 0);
-    } else if (PD == 3 && g0 + WAVES < g_end) {
+    } else if (PDIST == 3 && g0 + WAVES < g_end) {
       load_p(pc, g0);
       load_p(pn, g0 + WAVES);
       load_t(tc, g0);
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       for (; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + WAVES);
       step(no, yes, 0, g + WAVES);
       step(no, no, 0, 0);
-    } else if (PD == 1 && g0 < g_end) {  // distance 1: the next unit is requested while this one is processed
+    } else if (PDIST == 1 && g0 < g_end) {  // distance 1: the next unit is requested while this one is processed
       load_p(pc, g0);
       load_t(tc, g0);
       int g = g0;
@@ -319,32 +326,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     if (direct) {
       if (a.bias) v += A::to_f32(a.bias[col]);
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
-    } else {  // write-through so the reducing workgroup can read it with sc1 loads, no fences
-      __hip_atomic_store(a.slabs + ((int64_t)ks * a.rows + b) * a.N + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (ks != a.ksplit - 1) {
+      // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
+      // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
+      const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+      __hip_atomic_store(a.slabs + ((int64_t)ks * a.rows + b) * a.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // reducer (the last K-split of this column block; dispatched after the others): keep the own
+      // partial in registers, poll the other splits' granules until their tags appear (bounded),
+      // re-arm them to zero for the next launch, write y once.
+      for (int s = 0; s < a.ksplit - 1; ++s) {
+        unsigned long long* gp = a.slabs + ((int64_t)s * a.rows + b) * a.N + col;
+        unsigned long long gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
+          __builtin_amdgcn_s_sleep(2);
+          gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((gv >> 32) != 1ull) a.counters[PARO_WS_COUNTER_BYTES / 4 - 1] = 0xDEADu;  // give-up code, checked by tests
+        v += __builtin_bit_cast(float, (unsigned)gv);
+        __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (a.bias) v += A::to_f32(a.bias[col]);
+      a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     }
   }
-  if (direct) return;
-
-  // ---- in-launch K-split combine (placement-independent, fence-free):
-  // sc1 slab stores -> every wave drains -> barrier -> ONE relaxed agent-scope ticket;
-  // the last arriver reads all slabs with sc1 loads and writes y once, then re-arms the counter.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned* flag = (unsigned*)(lds + LDS_BYTES - 16);
-  if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (*flag != (unsigned)(a.ksplit - 1)) return;
-  const int ncols = nt * 16;
-  for (int e = tid; e < a.rows * ncols; e += WAVES * 64) {
-    const int b = e / ncols, c = e % ncols;
-    const int col = tile0 * 16 + c;
-    float v = 0.f;
-    for (int s = 0; s < a.ksplit; ++s)
-      v += __hip_atomic_load(a.slabs + ((int64_t)s * a.rows + b) * a.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.bias) v += A::to_f32(a.bias[col]);
-    a.y[(int64_t)b * a.N + col] = A::from_f32(v);
-  }
-  if (tid == 0) __hip_atomic_store(a.counters + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
@@ -353,6 +358,16 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (MB <= 4 && TPW <= 4) {
     if (waves == 16) {
       hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
+      return PARO_OK;
+    }
+  }
+  if constexpr (MB <= 4 && !PREROT) {  // odd group counts (K = 2560 -> 20 groups, K = 9728 -> 76): 5 / 10 waves divide them evenly
+    if (waves == 10 && TPW <= 4) {
+      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 10, PREROT, PD>), grid, dim3(640), 0, st, a);
+      return PARO_OK;
+    }
+    if (waves == 5) {
+      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 5, PREROT, PD>), grid, dim3(320), 0, st, a);
       return PARO_OK;
     }
   }
@@ -369,8 +384,12 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if (a.pd == 2) return launch_waves_pd<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
-  if (a.pd == 3) return launch_waves_pd<AT, TPW, MB, PREROT, 3>(a, waves, grid, st);
+  // PD 2 / 3 (deeper prefetch) measured slower on MI355X (see the table above); only PD 1 is built,
+  // plus two diagnostic variants of the M = 1 kernel (PARO_GEMV_PD = 11 / 12, tools/ablate_gemv.py).
+  if constexpr (MB == 1 && !PREROT) {
+    if (a.pd == 11) return launch_waves_pd<AT, TPW, MB, PREROT, 11>(a, waves, grid, st);
+    if (a.pd == 12) return launch_waves_pd<AT, TPW, MB, PREROT, 12>(a, waves, grid, st);
+  }
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

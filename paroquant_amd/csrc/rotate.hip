@@ -20,6 +20,15 @@ __global__ __launch_bounds__(64) void rotate_kernel(const void* __restrict__ x, 
                                                    const void* __restrict__ theta,
                                                    const void* __restrict__ scales, int rows, int hidden,
                                                    int krot, int gs, int x_dt, int p_dt) {
+  // blockIdx.z = merged partition: the same x is rotated with partition z's parameters into out[z]
+  // (parameters are [P, krot, hidden] / [P, krot, hidden/2] / [P, hidden]; 2-byte parameter types only)
+  if (blockIdx.z > 0) {
+    const int64_t pz = blockIdx.z;
+    idx += pz * krot * hidden;
+    theta = (const unsigned short*)theta + pz * krot * (hidden / 2);
+    if (scales) scales = (const unsigned short*)scales + pz * hidden;
+    out = (char*)out + pz * rows * hidden * (x_dt == PARO_DTYPE_F32 ? 4 : 2);
+  }
   constexpr int R = VW * NCH;
   __shared__ __attribute__((aligned(16))) float xr[R * 128];
   const int lane = threadIdx.x;
@@ -87,17 +96,19 @@ __global__ __launch_bounds__(64) void rotate_kernel(const void* __restrict__ x, 
 }
 
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
-                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st) {
+                  int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st,
+                  int nparts) {
   if (rows == 0) return PARO_OK;
   const unsigned spans = (unsigned)((hidden + 127) / 128);
+  const unsigned P = (unsigned)(nparts < 1 ? 1 : nparts);
   if (rows <= 1) {
-    hipLaunchKernelGGL((rotate_kernel<1, 1>), dim3(1, spans), dim3(64), 0, st, x, out, idx, theta, scales,
+    hipLaunchKernelGGL((rotate_kernel<1, 1>), dim3(1, spans, P), dim3(64), 0, st, x, out, idx, theta, scales,
                        (int)rows, (int)hidden, krot, gs, x_dt, p_dt);
   } else if (rows <= 4096) {
-    hipLaunchKernelGGL((rotate_kernel<4, 1>), dim3((unsigned)((rows + 3) / 4), spans), dim3(64), 0, st, x, out, idx,
+    hipLaunchKernelGGL((rotate_kernel<4, 1>), dim3((unsigned)((rows + 3) / 4), spans, P), dim3(64), 0, st, x, out, idx,
                        theta, scales, (int)rows, (int)hidden, krot, gs, x_dt, p_dt);
   } else {
-    hipLaunchKernelGGL((rotate_kernel<4, 2>), dim3((unsigned)((rows + 7) / 8), spans), dim3(64), 0, st, x, out, idx,
+    hipLaunchKernelGGL((rotate_kernel<4, 2>), dim3((unsigned)((rows + 7) / 8), spans, P), dim3(64), 0, st, x, out, idx,
                        theta, scales, (int)rows, (int)hidden, krot, gs, x_dt, p_dt);
   }
   return check_launch("paro_rotate");
@@ -119,5 +130,5 @@ extern "C" int paro_rotate(const void* x, void* out, const int16_t* idx_ij, cons
     return fail(PARO_ERR_INVALID, "rotate supports Float, Half, and BFloat16");
   if (!x || !out || !idx_ij || !theta) return fail(PARO_ERR_INVALID, "null pointer");
   return launch_rotate(x, out, idx_ij, theta, scales, rows, hidden, krot, group_size, x_dtype, param_dtype,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, 1);
 }

@@ -284,7 +284,7 @@ def get_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 def decode_workspace_bytes(K: int, N: int, n_parts: int, rows: int = 16) -> int:
     """Mirror of ``paro_linear_workspace_bytes`` for rows <= 16."""
-    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 4 + n_parts * rows * K * 2
+    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 8 + n_parts * rows * K * 2
 
 
 # --------------------------------------------------------------------------------------
