@@ -132,6 +132,9 @@ typedef struct paro_linear {
   const void* theta;                  /* fp16 [n_parts, krot, K/2]  (checkpoint layout) */
   const void* channel_scales;         /* fp16 [n_parts, K]          (checkpoint layout) */
   const void* bias;                   /* act_dtype [N] or NULL */
+  const void* rmat;                   /* optional: dense per-group rotation matrices, act_dtype
+                                         [n_parts][K/128][128 n][128 k] = (diag(cs) G_1..G_krot)^T, used by
+                                         the prefill pre-pass on the matrix cores; NULL = stage kernel */
 } paro_linear_t;
 
 /* Bytes of caller-provided scratch the fused ops may need for `rows` rows

@@ -56,6 +56,7 @@ class ParoLinearDesc(Structure):
         ("theta", c_void_p),
         ("channel_scales", c_void_p),
         ("bias", c_void_p),
+        ("rmat", c_void_p),
     ]
 
 

@@ -11,6 +11,8 @@
 //      unpacks to (16 + q) halves and feeds v_mfma_f32_16x16x32.  Scale and zero point are applied
 //      per (group, column) on the fp32 group result, exactly as in the GEMV:
 //          acc += s * (D_g - (16 + z) * sum_k x_k)
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace paro {
@@ -18,6 +20,8 @@ namespace paro {
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
                   int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 int validate_linear(const paro_linear_t* L);
+int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows, int64_t K, int nparts, int dt,
+                       hipStream_t st);
 
 struct GemmArgs {
   const u32x4* wq;
@@ -159,6 +163,159 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16 main kernel (v2): 256 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each
+// 128 rows x 64 columns = 8 x 4 MFMA tiles, 128 accumulator VGPRs).
+//   * A: the 256-row x 128-k tile of the current group goes global -> LDS directly
+//     (global_load_lds_dwordx4, no staging VGPRs), double buffered (2 x 64 KiB), one barrier per
+//     group.  The LDS image is lane-linear per wave-load, so the 16-slot XOR swizzle that makes the
+//     ds_read_b128 fragments conflict-free is applied to the SOURCE address (cdna guide rule 21).
+//   * B: four 1-KiB INT4 tiles per wave per group straight to VGPRs (next group prefetched), turned
+//     into exact fp16 weights in registers: (off + q) - (off + z) is exact, * s rounds once -- the
+//     reference's fp16 (q - z) * s dequant, bit for bit -- 13 packed-VALU ops per 8 weights, amortised
+//     over 8 row tiles (32 MFMA per 52 VALU).
+//   * accumulation runs through ALL groups in one MFMA chain per accumulator; no per-group epilogue.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM2 = 256;
+
+template <int WCOLS>  // column waves: 2 -> 256 x 128 tile, 4 waves; 4 -> 256 x 256 tile, 8 waves (2 per SIMD)
+__global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a) {
+  typedef Act<f16> A;
+  typedef A::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM2 * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = WCOLS * 2;            // waves per workgroup
+  constexpr int CBT = WCOLS * 4;           // column tiles per workgroup
+  constexpr int CPW = 64 / NW;             // A wave-loads (4 rows each) per wave per group
+  const int wr = wave / WCOLS, wc = wave % WCOLS;
+  const int cb = blockIdx.x;
+  const int row0 = blockIdx.y * BM2;
+
+  const int p = a.pt.part_of_cb(cb);
+  const int ltile0 = (cb - a.pt.cb_start[p]) * CBT + wc * 4;
+  const int tile0 = a.pt.tile_start[p] + ltile0;
+  const int nt = max(0, min(4, a.pt.tile_start[p + 1] - tile0));
+  const int ts0 = a.pt.szt_start[p] + ltile0;  // multiple of 4
+  const unsigned short* xp = a.xrot + (int64_t)p * a.rows * a.K;
+
+  const int n = lane & 15, mq = lane >> 4;
+  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;
+  // ragged partitions can push a wave's tiles past the padded scale/zero area: clamp (never stored)
+  const unsigned* szp = a.sz + ((int64_t)(min(ts0, a.pt.tsz - 4) >> 2) * 16 + n) * 4;
+
+  // --- A staging: wave w fills rows 64w .. 64w+63 (16 wave-loads of 4 rows).  Lane l lands on LDS slot
+  // (row = 4c + l/16, phys = l%16) and must therefore FETCH logical slot phys ^ (row & 15).
+  const int srow_in = lane >> 4, sphys = lane & 15;
+  const unsigned short* asrc[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int row = (wave * CPW + c) * 4 + srow_in;
+    const int grow = min(row0 + row, a.rows - 1);  // tail rows re-read the last valid row (never stored)
+    asrc[c] = xp + (int64_t)grow * a.K + ((sphys ^ (row & 15)) << 3);
+  }
+  auto issue_a = [&](int g, int buf) {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[c] + g * 128),
+                                       (__attribute__((address_space(3))) void*)(lds + buf * (BM2 * 256) + (wave * CPW + c) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  u32x4 qn[4];
+  u32x4 szn;
+  auto load_b = [&](int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // every wave stages A and joins every barrier, so out-of-range tiles (ragged partitions) are
+      // clamped to a valid tile and simply never stored
+      const int tt = min(tile0 + (j < nt ? j : 0), a.pt.tiles - 1);
+      qn[j] = *(a.wq + ((int64_t)tt * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
+    }
+    szn = *(const u32x4*)(szp + (int64_t)g * szrow);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = wr*128 + rt*16 + m', logical slot 4i + kb -> phys = (4i + kb) ^ m'
+  const int mrow = lane & 15;
+  const int abase = (wr * 128 + mrow) * 256;
+  int aoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = abase + (((4 * i + mq) ^ mrow) << 4);
+
+  {
+    issue_a(0, 0);
+    load_b(0);
+    for (int g = 0; g < a.G; ++g) {
+      u32x4 qc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qc[j] = qn[j];
+      const u32x4 szc = szn;
+      __syncthreads();  // A(g) has landed (the barrier drains the LDS-DMA), everyone left buffer (g+1)&1
+      if (g + 1 < a.G) {
+        issue_a(g + 1, (g + 1) & 1);
+        load_b(g + 1);
+      }
+      const unsigned char* abuf = lds + (g & 1) * (BM2 * 256);
+      // per-(tile, group) dequant constants as packed halves
+      f16x2 s2[4], c_hi[4], c_lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16 sh = __builtin_bit_cast(f16, (unsigned short)(szc[j] & 0xffffu));
+        const f16 zh = __builtin_bit_cast(f16, (unsigned short)(szc[j] >> 16));
+        s2[j] = (f16x2){sh, sh};
+        const f16 ch = (f16)(-1024.f) - zh, cl = (f16)(-64.f) - zh;  // exact: |.| <= 1039 integers
+        c_hi[j] = (f16x2){ch, ch};
+        c_lo[j] = (f16x2){cl, cl};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vec8 af[8];
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) af[rt] = *(const vec8*)(abuf + aoff[i] + rt * 4096);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned w4[4];
+          A::unpack_fast(qc[j][i], w4);
+          f16x2 h0 = (__builtin_bit_cast(f16x2, w4[0]) + c_hi[j]) * s2[j];
+          f16x2 h1 = (__builtin_bit_cast(f16x2, w4[1]) + c_lo[j]) * s2[j];
+          f16x2 h2 = (__builtin_bit_cast(f16x2, w4[2]) + c_hi[j]) * s2[j];
+          f16x2 h3 = (__builtin_bit_cast(f16x2, w4[3]) + c_lo[j]) * s2[j];
+          const u32x4 wv = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1),
+                            __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+          const vec8 bf = __builtin_bit_cast(vec8, wv);
+#pragma unroll
+          for (int rt = 0; rt < 8; ++rt) acc[rt][j] = A::mfma(af[rt], bf, acc[rt][j]);
+        }
+      }
+    }
+  }
+
+  // epilogue: D layout row = 4 * (lane >> 4) + r, col = lane & 15
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < nt) {
+      const int col = (tile0 + j) * 16 + n;
+      const float bv = a.bias ? A::to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + wr * 128 + rt * 16 + 4 * mq + r;
+          if (row < a.rows) a.y[(int64_t)row * a.N + col] = A::from_f32(acc[rt][j][r] + bv);
+        }
+    }
+  }
+}
+
 }  // namespace paro
 
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
@@ -174,8 +331,11 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES);
-  rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
-                     PARO_DTYPE_F16, st, L->n_parts);  // one launch, blockIdx.z = merged partition
+  if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
+    rc = launch_rotate_mfma(x, xrot, L->rmat, rows, L->K, L->n_parts, L->act_dtype, st);
+  else
+    rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
+                       PARO_DTYPE_F16, st, L->n_parts);  // one launch, blockIdx.z = merged partition
   if (rc != PARO_OK) return rc;
   GemmArgs a;
   a.wq = (const u32x4*)L->wq;
@@ -189,11 +349,24 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.rows = (int)rows;
   a.tstride = L->wq_order ? 1 : a.G;
   a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
-  const int64_t rb = (rows + BM - 1) / BM;
-  if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * BM);
+  // fp16: >= 256 rows -> 256 x 256 tile / 8 waves (measured 730-950 TFLOP/s incl. pre-pass at M = 8192,
+  // vs 560-810 for the 4-wave 256 x 128 tile); 128..255 rows -> 256 x 128; fewer (and bf16) -> v1 kernel.
+  // PARO_GEMM_VERSION = 1 | 2 | 3 forces one of them (A/B runs).
+  static const int env_v = getenv("PARO_GEMM_VERSION") ? atoi(getenv("PARO_GEMM_VERSION")) : 0;
+  const bool v2 = L->act_dtype == PARO_DTYPE_F16 && env_v != 1 && rows >= 128;
+  // the wide tile needs enough workgroups to cover the 256 CUs (narrow N x moderate M does not)
+  const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
+  const bool v2wide = v2 && (env_v == 3 || (env_v == 0 && rows >= 256 && wide_wgs >= 192));
+  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, v2wide ? 16 : BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
+  const int bm = v2 ? BM2 : BM;
+  const int64_t rb = (rows + bm - 1) / bm;
+  if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * bm);
   dim3 grid((unsigned)a.pt.cbs, (unsigned)rb);
-  if (L->act_dtype == PARO_DTYPE_F16)
+  if (v2wide)
+    hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);
+  else if (v2)
+    hipLaunchKernelGGL(gemm2_f16_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (L->act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(gemm_kernel<bf16>, grid, dim3(256), 0, st, a);

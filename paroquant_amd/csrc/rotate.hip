@@ -132,3 +132,96 @@ extern "C" int paro_rotate(const void* x, void* out, const int16_t* idx_ij, cons
   return launch_rotate(x, out, idx_ij, theta, scales, rows, hidden, krot, group_size, x_dtype, param_dtype,
                        (hipStream_t)stream, 1);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Prefill pre-pass on the matrix cores.  For many rows the 8 sparse Givens stages are cheaper as ONE
+// dense product per 128-channel group:  x_rot[:, g] = x[:, g] @ R'_g,  R'_g = diag(cs_g) * G_1 ... G_8
+// (128 x 128, built once at load time by running the stage kernel above on the scaled identity and
+// stored transposed/k-contiguous as rmat[p][g][n][k] in the activation dtype).  The stage kernel is
+// LDS-write bound (~2.3 TB/s of input); this one is HBM bound: 2*M*K*2 bytes per partition.
+//   grid (ceil(rows / 256), K / 128, P), 256 threads = 4 waves x 64 rows.
+//   X tile: global -> LDS by global_load_lds with the source-side XOR swizzle (as in gemm.hip);
+//   every wave pulls its 64 x 128 A fragments into registers, then walks the 8 column tiles of R'_g
+//   (B fragments straight from L2) and writes the fp16/bf16 result back through the same LDS tile
+//   so that the global stores are 16-byte, full-row coalesced.
+// ---------------------------------------------------------------------------------------------
+namespace paro {
+
+template <typename AT>
+__global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* __restrict__ x,
+                                                         unsigned short* __restrict__ out,
+                                                         const unsigned short* __restrict__ rmat, int rows, int K) {
+  typedef Act<AT> A;
+  typedef typename A::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * 256, g = blockIdx.y, p = blockIdx.z;
+  const int G = K >> 7;
+  const int n = lane & 15, mq = lane >> 4;
+
+  // stage X[row0 .. row0+255][g*128 .. +127]: wave w fills rows 64w .. 64w+63
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int row = wave * 64 + c * 4 + (lane >> 4);
+    const int grow = min(row0 + row, rows - 1);
+    const unsigned short* src = x + (int64_t)grow * K + g * 128 + (((lane & 15) ^ (row & 15)) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + (wave * 64 + c * 4) * 256), 16, 0, 0);
+  }
+  __syncthreads();
+
+  // A fragments of this wave's 64 rows (4 row tiles x 4 k-steps)
+  vec8 af[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int row = wave * 64 + rt * 16 + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[rt][i] = *(const vec8*)(lds + row * 256 + (((4 * i + mq) ^ (row & 15)) << 4));
+  }
+  __syncthreads();  // the tile is now free: it becomes the output staging buffer
+
+  const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;  // [n][k], k contiguous
+#pragma unroll 2
+  for (int ct = 0; ct < 8; ++ct) {
+    vec8 bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf[i] = *(const vec8*)(rp + (ct * 16 + n) * 128 + 32 * i + 8 * mq);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[i], d);
+      // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major 256 B)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 64 + rt * 16 + 4 * mq + r;
+        *(unsigned short*)(lds + row * 256 + (ct * 16 + n) * 2) = A::from_f32(d[r]);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned short* op = out + (int64_t)p * rows * K;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int row = (tid >> 4) + 16 * c;
+    if (row0 + row < rows)
+      *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * 256 + (tid & 15) * 16);
+  }
+}
+
+int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows, int64_t K, int nparts, int dt,
+                       hipStream_t st) {
+  if (rows == 0) return PARO_OK;
+  const int64_t rb = (rows + 255) / 256;
+  dim3 grid((unsigned)rb, (unsigned)(K / 128), (unsigned)nparts);
+  if (dt == PARO_DTYPE_F16)
+    hipLaunchKernelGGL(rotate_mfma_kernel<f16>, grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,
+                       (const unsigned short*)rmat, (int)rows, (int)K);
+  else
+    hipLaunchKernelGGL(rotate_mfma_kernel<bf16>, grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,
+                       (const unsigned short*)rmat, (int)rows, (int)K);
+  return check_launch("paro_rotate (mfma pre-pass)");
+}
+
+}  // namespace paro

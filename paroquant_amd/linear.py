@@ -78,15 +78,39 @@ class PackedParoWeights:
                                                      self.partition_sizes, self.wq_order)
         self.rot = torch.ops.paro.pack_rotation(self.pairs, self.theta)
         self.bias = bias
+        self._rmat = {}
         self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N, P))
+
+    def rotation_matrices(self, dtype: torch.dtype) -> torch.Tensor:
+        """Dense per-group rotation matrices for the prefill pre-pass on the matrix cores:
+        ``rmat[p, g, n, k] = (diag(cs) G_1 .. G_krot)[k, n]`` of group g -- obtained by pushing the scaled
+        identity through ``torch.ops.rotation.rotate`` (fp32) and rounding once.  Built lazily on the
+        first large-M call (decode-only users never pay the P*K*256 bytes)."""
+        r = self._rmat.get(dtype)
+        if r is None:
+            K, P = self.K, len(self.partition_sizes)
+            G = K // 128
+            eye = torch.zeros(128, G, 128, dtype=torch.float32, device=self.wq.device)
+            eye[torch.arange(128), :, torch.arange(128)] = 1.0
+            eye = eye.reshape(128, K)
+            mats = []
+            for p in range(P):
+                full = torch.ops.rotation.rotate(eye, self.pairs[p], self.theta[p].float(),
+                                                 self.channel_scales[p].float())          # [k, G*128 (n)]
+                mats.append(full.view(128, G, 128).permute(1, 2, 0))                        # [g, n, k]
+            r = torch.stack(mats).to(dtype).contiguous()
+            self._rmat[dtype] = r
+        return r
 
     def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self.bias if bias is None else bias
         if b is not None and b.dtype != x.dtype:
             b = b.to(x.dtype)
+        rows = x.numel() // self.K
+        rmat = self.rotation_matrices(x.dtype) if rows >= 256 else None
         return torch.ops.paro.w4a16_linear(x, self.wq, self.sz, self.rot, self.pairs, self.theta,
                                            self.channel_scales, b, self.partition_sizes, self.workspace,
-                                           self.wq_order)
+                                           self.wq_order, rmat)
 
     def nbytes(self) -> int:
         ts = [self.wq, self.sz, self.rot, self.channel_scales]

@@ -140,7 +140,7 @@ def _pack_rotation_fake(pairs, theta):
 
 
 def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, sz, rot, pairs,
-              theta, channel_scales, bias, wq_order: int = 0) -> nat.ParoLinearDesc:
+              theta, channel_scales, bias, wq_order: int = 0, rmat=None) -> nat.ParoLinearDesc:
     d = nat.ParoLinearDesc()
     d.K = K
     d.N = int(sum(partition_sizes))
@@ -159,6 +159,7 @@ def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torc
     d.theta = theta.data_ptr()
     d.channel_scales = channel_scales.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
+    d.rmat = rmat.data_ptr() if rmat is not None and rmat.numel() > 0 and rmat.dtype == act_dtype else None
     return d
 
 
@@ -183,7 +184,8 @@ def _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes):
 
 def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.Tensor, pairs: torch.Tensor,
                 theta: torch.Tensor, channel_scales: torch.Tensor, bias: Optional[torch.Tensor],
-                partition_sizes: Sequence[int], workspace: torch.Tensor, wq_order: int = 0) -> torch.Tensor:
+                partition_sizes: Sequence[int], workspace: torch.Tensor, wq_order: int = 0,
+                rmat: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = nat.load()
     partition_sizes = [int(s) for s in partition_sizes]
     _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes)
@@ -195,7 +197,7 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
     if rows == 0:
         return y.reshape(*x.shape[:-1], N)
     d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias,
-                  wq_order)
+                  wq_order, rmat)
     ws = workspace
     if rows > 16:
         # prefill: rotated activations live in a scratch buffer from torch's caching allocator
@@ -207,7 +209,8 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
     return y.reshape(*x.shape[:-1], N)
 
 
-def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace, wq_order=0):
+def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace, wq_order=0,
+                rmat=None):
     return x.new_empty((*x.shape[:-1], int(sum(partition_sizes))))
 
 
@@ -230,7 +233,7 @@ def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int
     return y.reshape(*x.shape[:-1], N)
 
 
-def w4a16_gemm_forced(x, pk, bias=None) -> torch.Tensor:
+def w4a16_gemm_forced(x, pk, bias=None, use_rmat: bool = True) -> torch.Tensor:
     """Direct call of ``paro_w4a16_gemm`` regardless of the row count (tests / benchmarks)."""
     lib = nat.load()
     _check_linear_args(x, pk.pairs, pk.theta, pk.channel_scales, bias, pk.partition_sizes)
@@ -239,7 +242,7 @@ def w4a16_gemm_forced(x, pk, bias=None) -> torch.Tensor:
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                  pk.channel_scales, bias, pk.wq_order)
+                  pk.channel_scales, bias, pk.wq_order, pk.rotation_matrices(x.dtype) if use_rmat else None)
     need = nat.PARO_WS_COUNTER_BYTES + len(pk.partition_sizes) * rows * K * 2
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(), need,
@@ -310,7 +313,8 @@ def _register() -> None:
     par.impl("pack_rotation", _pack_rotation_impl, "CUDA")
     torch.library.register_fake("paro::pack_rotation", _pack_rotation_fake, lib=par)
     par.define("w4a16_linear(Tensor x, Tensor wq, Tensor sz, Tensor rot, Tensor pairs, Tensor theta, "
-               "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace, int wq_order=0) -> Tensor")
+               "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace, int wq_order=0, "
+               "Tensor? rmat=None) -> Tensor")
     par.impl("w4a16_linear", _w4a16_impl, "CUDA")
     torch.library.register_fake("paro::w4a16_linear", _w4a16_fake, lib=par)
     _libs.append(par)

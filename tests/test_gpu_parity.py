@@ -437,3 +437,26 @@ def test_vllm_linear_method_contract(dev):
     ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
                                   L["channel_scales"], sizes, L["bias"], ideal=True)
     assert po.rel_err(_np(y), ideal) < TIGHT_F16
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_prefill_prepass_variants_agree(dev, dtype):
+    """Prefill pre-pass: dense per-group rotation on the matrix cores == the stage kernel (both vs oracle)."""
+    from paroquant_amd import ops
+    K, sizes, rows = 1024, [256, 128], 700          # 2 rotations, ragged row tail (700 = 2*256 + 188)
+    L = po.make_layer(808, K, sizes)
+    pk = _packed(L, dev)
+    x = torch.randn(rows, K, device=dev).to(dtype)
+    y_m = ops.w4a16_gemm_forced(x, pk, use_rmat=True)
+    y_s = ops.w4a16_gemm_forced(x, pk, use_rmat=False)
+    ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, None, ideal=True)
+    tol = TIGHT_F16 if dtype == torch.float16 else TIGHT_BF16
+    assert po.rel_err(_np(y_m), ideal) < tol and po.rel_err(_np(y_s), ideal) < tol
+    assert po.rel_err(_np(y_m), _np(y_s)) < tol
+    # the dense matrices are orthogonal up to the channel scales: R'_g^T R'_g = diag(cs^2)
+    R = pk.rotation_matrices(torch.float32)          # [P, G, n, k]
+    cs = pk.channel_scales.float().view(len(sizes), K // 128, 128)
+    gram = torch.einsum("pgnk,pgnl->pgkl", R, R)
+    eye = torch.diag_embed(cs * cs)
+    assert (gram - eye).abs().max().item() < 5e-3
