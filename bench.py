@@ -68,11 +68,21 @@ def layer_shapes(model: str, tp: int = 1):
     ]
 
 
+def synth_pairs(rng: np.random.Generator, krot: int, K: int) -> np.ndarray:
+    """Synthetic ``pairs``: an independent random perfect matching (randperm(128)) per (stage, group) --
+    the kernel contract is "any permutation" (reference dummy init, optim/qlinear.py:51-53)."""
+    G = K // 128
+    out = np.empty((krot, G, 128), dtype=np.int16)
+    for r in range(krot):
+        for g in range(G):
+            out[r, g] = rng.permutation(128).astype(np.int16)
+    return out.reshape(krot, K)
+
+
 def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None):
     """Random layer in checkpoint format (SURVEY section 8d synthetic inputs), unit gain, repacked by the
     product path (torch.ops.paro.repack_awq)."""
     from paroquant_amd.linear import PackedParoWeights
-    from oracle import paro_oracle as po   # bench-only: pair generator for the synthetic inputs
     N = sum(sizes)
     P = len(sizes)
     G = K // 128
@@ -82,7 +92,7 @@ def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None):
     scales = ((torch.rand(G, N, device=dev, generator=gen) + 0.5) * gain).half()
     theta = (torch.randn(P, 8, K // 2, device=dev, generator=gen) * 0.1).half()
     rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=dev).item()))
-    pairs = torch.from_numpy(np.stack([po.random_pairs(rng, 8, K) for _ in range(P)])).to(dev)
+    pairs = torch.from_numpy(np.stack([synth_pairs(rng, 8, K) for _ in range(P)])).to(dev)
     cs = (torch.rand(P, 1, K, device=dev, generator=gen) * 1.5 + 0.5).half()
     return PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes, wq_order=wq_order)
 
@@ -181,8 +191,7 @@ def per_shape_table(model: str, dev, reps: int = 400):
 
 def cpu_baseline(model: str, budget_s: float = 20.0):
     """Time the C port of the reference algorithm on ONE decoder layer (1/n_layers of a step)."""
-    from oracle import paro_cpu as pc
-    from oracle import paro_oracle as po
+    from oracle import paro_cpu as pc   # the ONLY use of oracle/ in this file: the CPU baseline leg
     _, _, _, _, L = MODELS[model]
     rng = np.random.default_rng(0)
     layers = []
@@ -193,7 +202,7 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
             qzeros=rng.integers(-2**31, 2**31 - 1, size=(G, N // 8), dtype=np.int64).astype(np.int32),
             scales=rng.uniform(0.002, 0.02, size=(G, N)).astype(np.float16),
             theta=(rng.standard_normal((P, 8, K // 2)) * 0.1).astype(np.float16),
-            pairs=np.stack([po.random_pairs(rng, 8, K) for _ in range(P)]),
+            pairs=np.stack([synth_pairs(rng, 8, K) for _ in range(P)]),
             channel_scales=rng.uniform(0.5, 2.0, size=(P, 1, K)).astype(np.float16), sizes=sizes, K=K))
     xs = [rng.standard_normal((1, l["K"])).astype(np.float16) for l in layers]
     pc.load()
@@ -272,9 +281,14 @@ def main():
     us_per_launch = ev_ms * 1e3 / (args.steps * launches)
     bytes_per_launch = stack.bytes_per_step / launches
     achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s
+    traffic = None   # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/)
+    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_bench_{model}.json")
+    if os.path.exists(pmc_file) and not tp_mode and stack.n_layers == MODELS[model][4]:
+        with open(pmc_file) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "paro::gemv_kernel (fused rotate+INT4 GEMV, all launches of the step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
                 "launches_per_step": launches,
                 "note": "launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps)"}
