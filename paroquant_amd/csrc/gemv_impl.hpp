@@ -66,7 +66,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef float V __attribute__((ext_vector_type(VW)));
   constexpr int XR_FLOATS = PREROT ? 0 : MB * 128;
   constexpr int XH_HALVES = PREROT ? 0 : (MB + 1) * kXhStride;  // + one all-zero row for unused MFMA rows
-  constexpr int WAVE_BYTES = XR_FLOATS * 4 + ((XH_HALVES * 2 + 15) / 16) * 16;
+  constexpr int REGION_BYTES = XR_FLOATS * 4 + ((XH_HALVES * 2 + 15) / 16) * 16;  // rotation state + fragment rows of one unit
+  constexpr int WAVE_BYTES = (PDIST == 4 ? 2 : 1) * REGION_BYTES;
   constexpr int RED_FLOATS = WAVES * TPW * MR * 64;
   constexpr int LDS_BYTES = (WAVES * WAVE_BYTES > RED_FLOATS * 4 ? WAVES * WAVE_BYTES : RED_FLOATS * 4) + 16;
   constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;  // 16-byte scale/zero vectors per unit
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   unsigned short* xh = (unsigned short*)(lds + wave * WAVE_BYTES + XR_FLOATS * 4);
   if constexpr (!PREROT) {
     for (int c = lane; c < kXhStride; c += 64) xh[MB * kXhStride + c] = 0;  // zero row
+    if constexpr (PDIST == 4)
+      for (int c = lane; c < kXhStride; c += 64) xh[REGION_BYTES / 2 + MB * kXhStride + c] = 0;
   }
 
   const int n = lane & 15, mq = lane >> 4;
@@ -272,6 +275,139 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   };
 
+  // ---- PDIST 4: units are processed in PAIRS whose rotations are interleaved stage by stage.  With 8-wave
+  // workgroups the 8-stage rotation is a dependent LDS chain (~150-200 cycles per stage) rather than LDS
+  // throughput, so two chains in flight per wave take the time of one.
+  if constexpr (PDIST == 4 && !PREROT) {
+    float* xrB = (float*)(lds + wave * WAVE_BYTES + REGION_BYTES);
+    unsigned short* xhB = (unsigned short*)(lds + wave * WAVE_BYTES + REGION_BYTES + XR_FLOATS * 4);
+    auto seed = [&](float* xs, const PBuf& pb) {
+      const float c0 = f16_bits_to_f32(pb.csv & 0xffffu), c1 = f16_bits_to_f32(pb.csv >> 16);
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        const int ch = r / VW, v = r % VW;
+        const unsigned xv = r < a.rows ? pb.xv[r] : 0u;
+        xs[(ch * 128 + 2 * lane) * VW + v] = A::to_f32(xv & 0xffffu) * c0;
+        xs[(ch * 128 + 2 * lane + 1) * VW + v] = A::to_f32(xv >> 16) * c1;
+      }
+    };
+    auto stage = [&](float* xs, unsigned w) {
+      const int i = (int)(w & 0xffu), j = (int)((w >> 8) & 0xffu);
+      float s, c;
+      fast_sincos(f16_bits_to_f32(w >> 16), s, c);
+      V va[NCH], vb[NCH];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        va[ch] = *(const V*)(xs + (ch * 128 + i) * VW);
+        vb[ch] = *(const V*)(xs + (ch * 128 + j) * VW);
+      }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        *(V*)(xs + (ch * 128 + i) * VW) = va[ch] * c + vb[ch] * s;
+        *(V*)(xs + (ch * 128 + j) * VW) = vb[ch] * c - va[ch] * s;
+      }
+    };
+    auto finish = [&](const float* xs, unsigned short* hs, vec8 (&af)[4], f32x4& sx, f32x4& so) {
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        const int ch = r / VW, v = r % VW;
+        const float v0 = xs[(ch * 128 + 2 * lane) * VW + v];
+        const float v1 = xs[(ch * 128 + 2 * lane + 1) * VW + v];
+        *(unsigned*)(hs + r * kXhStride + 2 * lane) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const unsigned short* afrag = hs + (avalid ? brow : MB) * kXhStride + 8 * mq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
+      const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+      const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
+      sx = (f32x4){0.f, 0.f, 0.f, 0.f};
+      so = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
+        so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
+      }
+    };
+    auto consume = [&](const TBuf& t, const vec8 (&af)[4], const f32x4& sx, const f32x4& so) {
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned w4[4];
+          A::unpack_fast(t.q[j][i], w4);
+          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+        }
+        const unsigned szw = t.sz[j / 4][j % 4];
+        const float s = f16_bits_to_f32(szw & 0xffffu);
+        const float zf = f16_bits_to_f32(szw >> 16);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
+      }
+    };
+    PBuf pA, pB, pA2, pB2;
+    TBuf tA, tB, tA2, tB2;
+    // one pair; HASB: the pair has a second unit; NEXT: 0 = nothing follows, 1 = one more unit, 2 = a full pair
+    auto pair = [&](auto hasb_tag, auto next_tag, int gnA, int gnB) {
+      constexpr bool HASB = decltype(hasb_tag)::value;
+      constexpr int NEXT = decltype(next_tag)::value;
+      if constexpr (NEXT >= 1) load_p(pA2, gnA);
+      if constexpr (NEXT >= 2) load_p(pB2, gnB);
+      seed(xr, pA);
+      if constexpr (HASB) seed(xrB, pB);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < a.krot) {
+          stage(xr, r < 4 ? pA.r0[r & 3] : pA.r1[r & 3]);
+          if constexpr (HASB) stage(xrB, r < 4 ? pB.r0[r & 3] : pB.r1[r & 3]);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      vec8 afA[4], afB[4];
+      f32x4 sxA, soA, sxB, soB;
+      finish(xr, xh, afA, sxA, soA);
+      if constexpr (HASB) finish(xrB, xhB, afB, sxB, soB);
+      if constexpr (NEXT >= 1) load_t(tA2, gnA);
+      consume(tA, afA, sxA, soA);
+      if constexpr (NEXT >= 2) load_t(tB2, gnB);
+      if constexpr (HASB) consume(tB, afB, sxB, soB);
+      if constexpr (NEXT >= 1) {
+        pA = pA2;
+        tA = tA2;
+      }
+      if constexpr (NEXT >= 2) {
+        pB = pB2;
+        tB = tB2;
+      }
+    };
+    const int g0 = g_begin + wave;
+    const std::true_type yes{};
+    const std::false_type no{};
+    const std::integral_constant<int, 0> n0{};
+    const std::integral_constant<int, 1> n1{};
+    const std::integral_constant<int, 2> n2{};
+    if (g0 + WAVES < g_end) {        // at least one full pair
+      load_p(pA, g0);
+      load_p(pB, g0 + WAVES);
+      load_t(tA, g0);
+      load_t(tB, g0 + WAVES);
+      int g = g0;
+      for (; g + 3 * WAVES < g_end; g += 2 * WAVES) pair(yes, n2, g + 2 * WAVES, g + 3 * WAVES);
+      if (g + 2 * WAVES < g_end) {   // a single unit follows the current pair
+        pair(yes, n1, g + 2 * WAVES, 0);
+        pair(no, n0, 0, 0);
+      } else {
+        pair(yes, n0, 0, 0);
+      }
+    } else if (g0 < g_end) {
+      load_p(pA, g0);
+      load_t(tA, g0);
+      pair(no, n0, 0, 0);
+    }
+  } else
   {
     const int g0 = g_begin + wave;
     const std::true_type yes{};
@@ -386,6 +522,15 @@ template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   // PD 2 / 3 (deeper prefetch) measured slower on MI355X (see the table above); only PD 1 is built,
   // plus two diagnostic variants of the M = 1 kernel (PARO_GEMV_PD = 11 / 12, tools/ablate_gemv.py).
+  // PD 4 (pairs of units with interleaved rotation chains) is correct but measured slower than PD 1 on
+  // every Llama-3-8B / Qwen3-4B shape (down_proj 12.2 vs 10.9 us, qkv 8.5 vs 7.7 us): the staggered issue
+  // of PD 1 (tiles of unit n+1 requested only after unit n's rotation) is what overlaps rotation with the
+  // HBM burst.  Not instantiated; build with -DPARO_GEMV_PAIRED to A/B it again.
+#ifdef PARO_GEMV_PAIRED
+  if constexpr (MB <= 4 && !PREROT && TPW <= 4) {
+    if (a.pd == 4) return launch_waves_pd<AT, TPW, MB, PREROT, 4>(a, waves, grid, st);
+  }
+#endif
   if constexpr (MB == 1 && !PREROT) {
     if (a.pd == 11) return launch_waves_pd<AT, TPW, MB, PREROT, 11>(a, waves, grid, st);
     if (a.pd == 12) return launch_waves_pd<AT, TPW, MB, PREROT, 12>(a, waves, grid, st);
