@@ -101,10 +101,15 @@ int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols);
 int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
                     int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz, void* stream);
 
-/* Rotation parameters -> one word per (partition, group, pair lane, stage):
- *   out_rot uint32 [n_parts][K/128][64][8]:  i | j << 8 | theta_fp16_bits << 16,
- * (i, j) = pairs[p, r, 128g + 2l], pairs[p, r, 128g + 2l + 1], theta = theta[p, r, 64g + l]
- * (indexing of rotation.cuh:126-127).  Stages r >= krot are filled with the identity (2l, 2l+1, 0).
+/* Rotation parameters -> two coefficient words per (partition, group, stage, pair lane):
+ *   out_rot uint32 [n_parts][K/128][4 stage pairs][64 lanes][4] = {cos_2q, sin_2q, cos_2q+1, sin_2q+1}
+ * cos / sin of theta (libm accuracy, computed once here instead of in every launch) as fp32 words whose
+ * low 9 bits are replaced by 4 * i (cos word) and 4 * j (sin word): the float nearest to the true value
+ * among those (relative error <= 2^-15, below the kernel's single final rounding), with
+ * (i, j) = pairs[p, r, 128g + 2e], pairs[p, r, 128g + 2e + 1], theta = theta[p, r, 64g + e]
+ * (indexing of rotation.cuh:126-127).  The 64 pairs of a stage are assigned to lanes -- and oriented,
+ * (i, j, theta) == (j, i, -theta) -- so that each 32-lane half touches 32 distinct LDS banks with its i
+ * and with its j.  Stages r >= krot are filled with the identity.
  * Requires krot <= 8 (larger krot uses the unfused rotate + GEMV route). */
 int64_t paro_packed_rot_bytes(int64_t K, int n_parts);
 int paro_pack_rotation(const int16_t* pairs, const void* theta, int64_t K, int n_parts, int krot, void* out_rot,

@@ -9,8 +9,8 @@
 //   * work unit = (128-channel quantisation group g) x (TPW column tiles of 16 outputs).
 //     A 64-lane wavefront owns one unit at a time: 64 lanes == the 64 Givens pairs of the
 //     group, so the wave rotates ITS OWN slice of x in wave-private LDS with no workgroup
-//     barrier.  All 8 stages' coefficients arrive as two 16-byte loads per lane
-//     (paro_pack_rotation), requested BEFORE the unit's INT4 tiles so that waiting for them
+//     barrier.  All 8 stages' coefficients (cos / sin words that also carry the LDS offsets of the
+//     pair) arrive as four coalesced 16-byte loads per lane (paro_pack_rotation), requested BEFORE the unit's INT4 tiles so that waiting for them
 //     does not wait for the tiles (vmcnt retires in order); the rotation then runs while
 //     the tiles (non-temporal, 1 KiB per wave-load, straight to VGPRs) are in flight.
 //   * the group loop is software-pipelined: unit n+1's coefficients and tiles are requested
@@ -48,53 +48,80 @@ struct GemvArgs {
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int flags;                             // debug (PARO_GEMV_FLAGS): 16 = return at kernel entry (launch floor)
-  int pd;                                // software-pipeline distance in units (1 or 2)
+  int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31)
   PartTable pt;
 };
 
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
-template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>  // PD = prefetch distance in units (1 or 2)
+// PD: 1 = the shipping kernel; 11 / 21 / 31 = diagnostic builds of the M = 1 kernel (tools/ablate_gemv.py,
+// tools/timeline_gemv.py): 11 skips the rotation stages, 21 also the unpack + MFMA (pure stream), 31 records
+// s_memtime phase stamps per workgroup / per wave into the workspace.
+// Deeper prefetch (coefficients / tiles two units ahead) and pairs of units with interleaved rotation
+// chains were built and measured SLOWER on every Llama-3-8B / Qwen3-4B shape ("what did not
+// work"): more bulk loads in flight only lengthen the queue the small coefficient loads wait in.
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
-  constexpr int PDIST = PD % 10;   // pipeline distance variant
-  constexpr int DIAG = PD / 10;    // diagnostics (tools/ablate): 1 = no rotation stages, 2 = also no unpack/MFMA (pure stream)
+  constexpr int DIAG = PD / 10;
   constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile
   constexpr int VW = MB >= 4 ? 4 : MB;                  // LDS vector width of the rotation state
+  constexpr int LOGVW = VW == 4 ? 2 : (VW == 2 ? 1 : 0);
   constexpr int NCH = MB / VW;
   typedef float V __attribute__((ext_vector_type(VW)));
-  constexpr int XR_FLOATS = PREROT ? 0 : MB * 128;
-  constexpr int XH_HALVES = PREROT ? 0 : (MB + 1) * kXhStride;  // + one all-zero row for unused MFMA rows
-  constexpr int REGION_BYTES = XR_FLOATS * 4 + ((XH_HALVES * 2 + 15) / 16) * 16;  // rotation state + fragment rows of one unit
-  constexpr int WAVE_BYTES = (PDIST == 4 ? 2 : 1) * REGION_BYTES;
+  typedef __attribute__((address_space(3))) V LdsV;
+  // LDS: [WAVES] fp32 rotation states (MB x 128 floats, 512-byte aligned so that a coefficient word's
+  // low bits OR straight into the address), then [WAVES] fragment-row blocks (MB rows + one zero row).
+  constexpr int XR_BYTES = PREROT ? 0 : MB * 512;
+  constexpr int XH_BYTES = PREROT ? 0 : (((MB + 1) * kXhStride * 2 + 15) / 16) * 16;
   constexpr int RED_FLOATS = WAVES * TPW * MR * 64;
-  constexpr int LDS_BYTES = (WAVES * WAVE_BYTES > RED_FLOATS * 4 ? WAVES * WAVE_BYTES : RED_FLOATS * 4) + 16;
+  constexpr int WORK_BYTES = WAVES * (XR_BYTES + XH_BYTES);
+  constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + 16;
   constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;  // 16-byte scale/zero vectors per unit
   constexpr int SZW = TPW < 4 ? TPW : 4;
   typedef unsigned SZV __attribute__((ext_vector_type(SZW)));
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ __attribute__((aligned(512))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x, ks = blockIdx.y;
-  if (a.flags & 16) return;  // ablation: launch floor
+  // Pin every argument the first loads need into SGPRs right here: the compiler then fetches the argument
+  // block with ONE batch of scalar loads and one wait instead of sinking them into three dependent
+  // rounds (each a scalar-cache miss at kernel start).
+  asm volatile("" ::"s"(a.wq), "s"(a.sz), "s"(a.rot), "s"(a.cs), "s"(a.x), "s"(a.K), "s"(a.G), "s"(a.rows),
+               "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts));
+  // DIAG 3: wave 0 of every workgroup timestamps its phases (s_memtime, shader clock) into a.slabs
+  unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (DIAG == 3) ts[0] = __builtin_amdgcn_s_memtime();
 
-  const int p = a.pt.part_of_cb(cb);
-  const int ltile0 = (cb - a.pt.cb_start[p]) * TPW;
-  const int tile0 = a.pt.tile_start[p] + ltile0;
-  const int nt = min(TPW, a.pt.tile_start[p + 1] - tile0);
-  const int ts0 = a.pt.szt_start[p] + ltile0;
+  // Partition lookup with compile-time kernarg offsets only (select chain, no data-dependent s_load):
+  // the whole argument block is then fetched in ONE batch of scalar loads instead of six dependent
+  // round trips (measured: 2300 cycles from workgroup start to the first global load before this).
+  int p = 0, p_cb0 = a.pt.cb_start[0], p_t0 = a.pt.tile_start[0], p_t1 = a.pt.tile_start[1], p_sz0 = a.pt.szt_start[0];
+#pragma unroll
+  for (int q = 1; q < PARO_MAX_PARTS; ++q) {
+    const bool in = q < a.pt.nparts && cb >= a.pt.cb_start[q];
+    p = in ? q : p;
+    p_cb0 = in ? a.pt.cb_start[q] : p_cb0;
+    p_t0 = in ? a.pt.tile_start[q] : p_t0;
+    p_t1 = in ? a.pt.tile_start[q + 1] : p_t1;
+    p_sz0 = in ? a.pt.szt_start[q] : p_sz0;
+  }
+  const int ltile0 = (cb - p_cb0) * TPW;
+  const int tile0 = p_t0 + ltile0;
+  const int nt = min(TPW, p_t1 - tile0);
+  const int ts0 = p_sz0 + ltile0;
   const int g_begin = ks * a.gps;
   const int g_end = min(a.G, g_begin + a.gps);
 
-  float* xr = (float*)(lds + wave * WAVE_BYTES);
-  unsigned short* xh = (unsigned short*)(lds + wave * WAVE_BYTES + XR_FLOATS * 4);
+  float* xr = (float*)(lds + wave * XR_BYTES);
+  unsigned short* xh = (unsigned short*)(lds + WAVES * XR_BYTES + wave * XH_BYTES);
+  // LDS byte address of this wave's rotation state (wave-uniform, low 9 bits zero)
+  const unsigned xr_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(wave * XR_BYTES);
   if constexpr (!PREROT) {
     for (int c = lane; c < kXhStride; c += 64) xh[MB * kXhStride + c] = 0;  // zero row
-    if constexpr (PDIST == 4)
-      for (int c = lane; c < kXhStride; c += 64) xh[REGION_BYTES / 2 + MB * kXhStride + c] = 0;
   }
 
   const int n = lane & 15, mq = lane >> 4;
@@ -112,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
     unsigned csv;
-    u32x4 r0, r1;
+    u32x4 rc[PREROT ? 1 : 4];   // stages 2q, 2q+1: {cos | 4i, sin | 4j, cos | 4i, sin | 4j}
     u32x4 xa[PREROT ? 4 : 1];
   };
   struct TBuf {
@@ -131,9 +158,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         if (avalid) b.xa[i] = *(const u32x4*)(xrot_p + (int64_t)brow * a.K + g * 128 + 32 * i + 8 * mq);
       }
     } else {
-      const u32x4* rp = (const u32x4*)(a.rot + (((int64_t)p * a.G + g) * 64 + lane) * 8);
-      b.r0 = rp[0];
-      b.r1 = rp[1];
+      // 4 coalesced 1-KiB wave loads: [p][g][stage pair][lane] x 16 bytes (paro_pack_rotation)
+      const u32x4* rp = (const u32x4*)a.rot + ((int64_t)p * a.G + g) * 256 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b.rc[q] = rp[q * 64];
       b.csv = *(const unsigned*)(a.cs + (int64_t)p * a.K + g * 128 + 2 * lane);
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
@@ -156,22 +184,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int v = 0; v < NSZ; ++v) b.sz[v] = *(const SZV*)(sp + v * 64);
   };
 
-  PBuf pc, pn, pn2;
-  TBuf tc, tn, tn2;
+  PBuf pc, pn;
+  TBuf tc, tn;
 
   // One work unit: rotate group g's slice of x (coefficients in pc), then consume its tiles (tc).
-  // Software pipeline.  PFP: request coefficients of unit gp (before this unit's rotation); PFT:
-  // request tiles of unit gt (before this unit's tiles are consumed).  Coefficients are always
-  // requested before the tiles of the same unit (in-order vmcnt: a wait for coefficients never waits
-  // for younger tile loads).  PD selects the distances (measured, MI355X, same box, Llama-3-8B shapes):
-  //   PD 1: coefficients +1, tiles +1            gate_up 15.5 us  o_proj 6.9 us
-  //   PD 2: coefficients +2, tiles +2            gate_up 16.9 us  o_proj 7.8 us  (more bulk loads in
-  //         flight only lengthen the queue the small coefficient loads wait in)
-  //   PD 3: coefficients +2, tiles +1
+  // Software pipeline, distance 1.  PFP: request the NEXT unit's coefficients before this unit's
+  // rotation; PFT: request the next unit's tiles before this unit's tiles are consumed.  Coefficients
+  // are always requested before the tiles of the same unit (in-order vmcnt: a wait for coefficients
+  // never waits for younger tile loads).
   auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt) {
     constexpr bool PFP = decltype(pfp_tag)::value;
     constexpr bool PFT = decltype(pft_tag)::value;
-    if constexpr (PFP) load_p(pn2, gp);
+    if constexpr (PFP) load_p(pn, gp);
 
     // ---- A fragments of this group (4 x K=32)
     vec8 af[4];
@@ -188,23 +212,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         xr[(ch * 128 + 2 * lane + 1) * VW + v] = A::to_f32(xv >> 16) * c1;
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = __builtin_amdgcn_s_memtime(); }   // coefficients + x arrived
+      // Givens stages.  Lane l owns one pair per stage; cos / sin come ready-made from the packed
+      // words (computed once at load time with libm accuracy), whose low 9 bits are the LDS byte
+      // offsets of the pair's two channels: 2 address ops + 4 FMA-class ops + 4 DS ops per stage and row
+      // vector.  (The first version decoded (i, j, theta) and ran v_sin / v_cos here: 22 issue slots per
+      // stage -- the per-workgroup timeline showed every wave VALU-bound on exactly that.)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        if (DIAG == 0 && r < a.krot) {
-          const unsigned w = r < 4 ? pc.r0[r & 3] : pc.r1[r & 3];
-          const int i = (int)(w & 0xffu), j = (int)((w >> 8) & 0xffu);
-          float s, c;
-          fast_sincos(f16_bits_to_f32(w >> 16), s, c);
+        if ((DIAG == 0 || DIAG == 3) && r < a.krot) {
+          const unsigned wc = pc.rc[r >> 1][2 * (r & 1)], wsn = pc.rc[r >> 1][2 * (r & 1) + 1];
+          const float c = __builtin_bit_cast(float, wc), s = __builtin_bit_cast(float, wsn);
+          const unsigned ai = ((wc & 0x1fcu) << LOGVW) | xr_lds;
+          const unsigned aj = ((wsn & 0x1fcu) << LOGVW) | xr_lds;
           V va[NCH], vb[NCH];
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            va[ch] = *(const V*)(xr + (ch * 128 + i) * VW);
-            vb[ch] = *(const V*)(xr + (ch * 128 + j) * VW);
+            va[ch] = *(const LdsV*)(size_t)(ai + ch * 512 * VW);
+            vb[ch] = *(const LdsV*)(size_t)(aj + ch * 512 * VW);
           }
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            *(V*)(xr + (ch * 128 + i) * VW) = va[ch] * c + vb[ch] * s;
-            *(V*)(xr + (ch * 128 + j) * VW) = vb[ch] * c - va[ch] * s;
+            *(LdsV*)(size_t)(ai + ch * 512 * VW) = va[ch] * c + vb[ch] * s;
+            *(LdsV*)(size_t)(aj + ch * 512 * VW) = vb[ch] * c - va[ch] * s;
           }
           // a wave's DS operations execute in issue order, so the next stage's reads see these
           // writes; the barrier only stops the compiler from reordering across stages
@@ -237,7 +267,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         so = A::mfma(af[i], fb, so);
       }
     }
-    if constexpr (PFT) load_t(tn2, gt);
+    if constexpr (PFT) load_t(tn, gt);
+    if constexpr (DIAG == 3) { if (ts[3] == 0) ts[3] = __builtin_amdgcn_s_memtime(); }     // first rotation + fragments done
 
     // ---- per tile: unpack -> 4 MFMA -> scale / zero point on the fp32 result
 #pragma unroll
@@ -260,195 +291,46 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
     }
-    if constexpr (PDIST == 1) {
-      if constexpr (PFP) pc = pn2;
-      if constexpr (PFT) tc = tn2;
-    } else {
-      pc = pn;
-      if constexpr (PFP) pn = pn2;
-      if constexpr (PDIST == 2) {
-        tc = tn;
-        if constexpr (PFT) tn = tn2;
-      } else if constexpr (PFT) {
-        tc = tn2;
-      }
+    if constexpr (DIAG == 3) {
+      if (acc[0][0] != 12345.678f && ts[4] == 0) ts[4] = __builtin_amdgcn_s_memtime();     // first unit's tiles consumed
     }
+    if constexpr (PFP) pc = pn;
+    if constexpr (PFT) tc = tn;
   };
 
-  // ---- PDIST 4: units are processed in PAIRS whose rotations are interleaved stage by stage.  With 8-wave
-  // workgroups the 8-stage rotation is a dependent LDS chain (~150-200 cycles per stage) rather than LDS
-  // throughput, so two chains in flight per wave take the time of one.
-  if constexpr (PDIST == 4 && !PREROT) {
-    float* xrB = (float*)(lds + wave * WAVE_BYTES + REGION_BYTES);
-    unsigned short* xhB = (unsigned short*)(lds + wave * WAVE_BYTES + REGION_BYTES + XR_FLOATS * 4);
-    auto seed = [&](float* xs, const PBuf& pb) {
-      const float c0 = f16_bits_to_f32(pb.csv & 0xffffu), c1 = f16_bits_to_f32(pb.csv >> 16);
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        const int ch = r / VW, v = r % VW;
-        const unsigned xv = r < a.rows ? pb.xv[r] : 0u;
-        xs[(ch * 128 + 2 * lane) * VW + v] = A::to_f32(xv & 0xffffu) * c0;
-        xs[(ch * 128 + 2 * lane + 1) * VW + v] = A::to_f32(xv >> 16) * c1;
-      }
-    };
-    auto stage = [&](float* xs, unsigned w) {
-      const int i = (int)(w & 0xffu), j = (int)((w >> 8) & 0xffu);
-      float s, c;
-      fast_sincos(f16_bits_to_f32(w >> 16), s, c);
-      V va[NCH], vb[NCH];
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        va[ch] = *(const V*)(xs + (ch * 128 + i) * VW);
-        vb[ch] = *(const V*)(xs + (ch * 128 + j) * VW);
-      }
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        *(V*)(xs + (ch * 128 + i) * VW) = va[ch] * c + vb[ch] * s;
-        *(V*)(xs + (ch * 128 + j) * VW) = vb[ch] * c - va[ch] * s;
-      }
-    };
-    auto finish = [&](const float* xs, unsigned short* hs, vec8 (&af)[4], f32x4& sx, f32x4& so) {
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        const int ch = r / VW, v = r % VW;
-        const float v0 = xs[(ch * 128 + 2 * lane) * VW + v];
-        const float v1 = xs[(ch * 128 + 2 * lane + 1) * VW + v];
-        *(unsigned*)(hs + r * kXhStride + 2 * lane) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const unsigned short* afrag = hs + (avalid ? brow : MB) * kXhStride + 8 * mq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
-      const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
-      const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
-      sx = (f32x4){0.f, 0.f, 0.f, 0.f};
-      so = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
-        so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
-      }
-    };
-    auto consume = [&](const TBuf& t, const vec8 (&af)[4], const f32x4& sx, const f32x4& so) {
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned w4[4];
-          A::unpack_fast(t.q[j][i], w4);
-          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
-          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
-        }
-        const unsigned szw = t.sz[j / 4][j % 4];
-        const float s = f16_bits_to_f32(szw & 0xffffu);
-        const float zf = f16_bits_to_f32(szw >> 16);
-#pragma unroll
-        for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
-      }
-    };
-    PBuf pA, pB, pA2, pB2;
-    TBuf tA, tB, tA2, tB2;
-    // one pair; HASB: the pair has a second unit; NEXT: 0 = nothing follows, 1 = one more unit, 2 = a full pair
-    auto pair = [&](auto hasb_tag, auto next_tag, int gnA, int gnB) {
-      constexpr bool HASB = decltype(hasb_tag)::value;
-      constexpr int NEXT = decltype(next_tag)::value;
-      if constexpr (NEXT >= 1) load_p(pA2, gnA);
-      if constexpr (NEXT >= 2) load_p(pB2, gnB);
-      seed(xr, pA);
-      if constexpr (HASB) seed(xrB, pB);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (r < a.krot) {
-          stage(xr, r < 4 ? pA.r0[r & 3] : pA.r1[r & 3]);
-          if constexpr (HASB) stage(xrB, r < 4 ? pB.r0[r & 3] : pB.r1[r & 3]);
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      vec8 afA[4], afB[4];
-      f32x4 sxA, soA, sxB, soB;
-      finish(xr, xh, afA, sxA, soA);
-      if constexpr (HASB) finish(xrB, xhB, afB, sxB, soB);
-      if constexpr (NEXT >= 1) load_t(tA2, gnA);
-      consume(tA, afA, sxA, soA);
-      if constexpr (NEXT >= 2) load_t(tB2, gnB);
-      if constexpr (HASB) consume(tB, afB, sxB, soB);
-      if constexpr (NEXT >= 1) {
-        pA = pA2;
-        tA = tA2;
-      }
-      if constexpr (NEXT >= 2) {
-        pB = pB2;
-        tB = tB2;
-      }
-    };
-    const int g0 = g_begin + wave;
-    const std::true_type yes{};
-    const std::false_type no{};
-    const std::integral_constant<int, 0> n0{};
-    const std::integral_constant<int, 1> n1{};
-    const std::integral_constant<int, 2> n2{};
-    if (g0 + WAVES < g_end) {        // at least one full pair
-      load_p(pA, g0);
-      load_p(pB, g0 + WAVES);
-      load_t(tA, g0);
-      load_t(tB, g0 + WAVES);
-      int g = g0;
-      for (; g + 3 * WAVES < g_end; g += 2 * WAVES) pair(yes, n2, g + 2 * WAVES, g + 3 * WAVES);
-      if (g + 2 * WAVES < g_end) {   // a single unit follows the current pair
-        pair(yes, n1, g + 2 * WAVES, 0);
-        pair(no, n0, 0, 0);
-      } else {
-        pair(yes, n0, 0, 0);
-      }
-    } else if (g0 < g_end) {
-      load_p(pA, g0);
-      load_t(tA, g0);
-      pair(no, n0, 0, 0);
-    }
-  } else
   {
     const int g0 = g_begin + wave;
     const std::true_type yes{};
     const std::false_type no{};
-    if (PDIST == 2 && g0 + WAVES < g_end) {  // >= 2 units: both units' coefficients, then both units' tiles, up front
-      load_p(pc, g0);
-      load_p(pn, g0 + WAVES);
-      load_t(tc, g0);
-      load_t(tn, g0 + WAVES);
-      for (int g = g0; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + 2 * WAVES);
-      step(no, no, 0, 0);
-      step(no, no, 0, 0);
-    } else if (PDIST == 3 && g0 + WAVES < g_end) {
-      load_p(pc, g0);
-      load_p(pn, g0 + WAVES);
-      load_t(tc, g0);
-      int g = g0;
-      for (; g + 2 * WAVES < g_end; g += WAVES) step(yes, yes, g + 2 * WAVES, g + WAVES);
-      step(no, yes, 0, g + WAVES);
-      step(no, no, 0, 0);
-    } else if (PDIST == 1 && g0 < g_end) {  // distance 1: the next unit is requested while this one is processed
-      load_p(pc, g0);
-      load_t(tc, g0);
-      int g = g0;
-      for (; g + WAVES < g_end; g += WAVES) step(yes, yes, g + WAVES, g + WAVES);
-      step(no, no, 0, 0);
-    } else if (g0 < g_end) {
-      load_p(pc, g0);
-      load_t(tc, g0);
-      step(no, no, 0, 0);
+    // The first unit's loads are issued unconditionally (group index clamped) BEFORE any branch, so the
+    // compiler fetches the whole argument block in one scalar batch at kernel entry.  A wave without
+    // work (fewer groups than waves) runs one clamped unit and discards it.
+    const bool has_work = g0 < g_end;
+    const int gf = has_work ? g0 : a.G - 1;
+    load_p(pc, gf);
+    load_t(tc, gf);
+    if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
+    for (int g = gf; g + WAVES < g_end; g += WAVES) step(yes, yes, g + WAVES, g + WAVES);
+    step(no, no, 0, 0);
+    if (!has_work) {
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < MR; ++r) acc[j][r] = 0.f;
     }
   }
 
+  if constexpr (DIAG == 3) ts[5] = acc[0][0] != 12345.678f ? __builtin_amdgcn_s_memtime() : 0;  // all units done
   // ---- reduce the workgroup's waves (different groups, same columns) through LDS
   __syncthreads();
+  if constexpr (DIAG == 3) ts[7] = __builtin_amdgcn_s_memtime();   // every wave of the workgroup has finished its units
   float* red = (float*)lds;
 #pragma unroll
   for (int j = 0; j < TPW; ++j)
 #pragma unroll
     for (int r = 0; r < MR; ++r) red[((wave * TPW + j) * MR + r) * 64 + lane] = acc[j][r];
   __syncthreads();
+  if constexpr (DIAG == 3) ts[8] = __builtin_amdgcn_s_memtime();   // partials staged
 
   const bool direct = (a.ksplit == 1);
   for (int e = tid; e < TPW * MR * 64; e += WAVES * 64) {
@@ -486,6 +368,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     }
   }
+  if constexpr (DIAG == 3) {
+    ts[6] = __builtin_amdgcn_s_memtime();
+    // 48 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], then (start, units done) of every wave
+    if (a.slabs) {
+      unsigned long long* dbg = a.slabs + ((int64_t)(ks * gridDim.x + cb)) * 48;
+      if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dbg[k] = ts[k];
+        dbg[9] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
+      }
+      if (lane == 0 && wave < 16) { dbg[10 + 2 * wave] = ts[0]; dbg[11 + 2 * wave] = ts[5]; }
+    }
+  }
 }
 
 // ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
@@ -520,20 +416,11 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  // PD 2 / 3 (deeper prefetch) measured slower on MI355X (see the table above); only PD 1 is built,
-  // plus two diagnostic variants of the M = 1 kernel (PARO_GEMV_PD = 11 / 12, tools/ablate_gemv.py).
-  // PD 4 (pairs of units with interleaved rotation chains) is correct but measured slower than PD 1 on
-  // every Llama-3-8B / Qwen3-4B shape (down_proj 12.2 vs 10.9 us, qkv 8.5 vs 7.7 us): the staggered issue
-  // of PD 1 (tiles of unit n+1 requested only after unit n's rotation) is what overlaps rotation with the
-  // HBM burst.  Not instantiated; build with -DPARO_GEMV_PAIRED to A/B it again.
-#ifdef PARO_GEMV_PAIRED
-  if constexpr (MB <= 4 && !PREROT && TPW <= 4) {
-    if (a.pd == 4) return launch_waves_pd<AT, TPW, MB, PREROT, 4>(a, waves, grid, st);
-  }
-#endif
+  // only PD 1 ships; PARO_GEMV_PD = 11 / 21 / 31 select the diagnostic builds of the M = 1 kernel
   if constexpr (MB == 1 && !PREROT) {
     if (a.pd == 11) return launch_waves_pd<AT, TPW, MB, PREROT, 11>(a, waves, grid, st);
-    if (a.pd == 12) return launch_waves_pd<AT, TPW, MB, PREROT, 12>(a, waves, grid, st);
+    if (a.pd == 21) return launch_waves_pd<AT, TPW, MB, PREROT, 21>(a, waves, grid, st);
+    if (a.pd == 31) return launch_waves_pd<AT, TPW, MB, PREROT, 31>(a, waves, grid, st);
   }
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }

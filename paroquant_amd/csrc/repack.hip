@@ -57,6 +57,25 @@ __global__ __launch_bounds__(256) void pack_sz_kernel(const unsigned* __restrict
   out[(((int64_t)g * (pt.tsz / 4) + (ts >> 2)) * 16 + n) * 4 + (ts & 3)] = s | (zf << 16);
 }
 
+// One rotation coefficient word: the fp32 value NEAREST to `v` whose low 9 bits equal `4 * channel`
+// (the LDS byte offset of the channel's fp32 state).  The GEMV uses the word as the float directly
+// (relative error <= 2^-15, below the single final rounding to fp16 / bf16) and masks 0x1fc for the address.
+__device__ __forceinline__ unsigned coef_word(float v, unsigned channel) {
+  const unsigned lo = (channel & 127u) * 4u;
+  const unsigned b = (__builtin_bit_cast(unsigned, v) & ~0x1ffu) | lo;
+  unsigned best = b;
+  float err = fabsf(__builtin_bit_cast(float, b) - v);
+  if ((b & 0x7fffffffu) >= 0x200u) {
+    const float e = fabsf(__builtin_bit_cast(float, b - 0x200u) - v);
+    if (e < err) { err = e; best = b - 0x200u; }
+  }
+  {
+    const float e = fabsf(__builtin_bit_cast(float, b + 0x200u) - v);
+    if (e < err) { err = e; best = b + 0x200u; }
+  }
+  return best;
+}
+
 // One thread per (partition, group, stage): pack that stage's 64 Givens pairs into lane words
 //   i | j << 8 | theta_fp16 << 16
 // and, because WHICH lane applies a pair and the pair's orientation are free
@@ -78,9 +97,13 @@ __global__ __launch_bounds__(64) void pack_rot_kernel(const int16_t* __restrict_
   const int r = (int)(gid & 7);
   const int g = (int)((gid >> 3) % G);
   const int p = (int)((gid >> 3) / G);
-  unsigned* o = out + ((int64_t)p * G + g) * 512 + r;  // + lane * 8
+  // [p][g][stage pair q = r >> 1][lane][4 words]: words 2 * (r & 1) + {0, 1} of the lane's 16-byte chunk
+  unsigned* o = out + (((int64_t)p * G + g) * 4 + (r >> 1)) * 256 + 2 * (r & 1);  // + lane * 4
   if (r >= krot) {
-    for (int l = 0; l < 64; ++l) o[l * 8] = (unsigned)(2 * l) | ((unsigned)(2 * l + 1) << 8);  // identity stage
+    for (int l = 0; l < 64; ++l) {  // identity stage (never executed: the kernels stop at krot)
+      o[l * 4] = coef_word(1.0f, 2 * l);
+      o[l * 4 + 1] = coef_word(0.0f, 2 * l + 1);
+    }
     return;
   }
   const int64_t pb = (int64_t)p * krot + r;
@@ -178,9 +201,12 @@ __global__ __launch_bounds__(64) void pack_rot_kernel(const int16_t* __restrict_
   }
   for (int e = 0; e < 64; ++e) {
     const unsigned i = (unsigned short)pr[2 * e] & 0xffu, j = (unsigned short)pr[2 * e + 1] & 0xffu;
-    const unsigned t = th[e];
     const int lane = next[half[e]]++;
-    o[lane * 8] = flip[e] ? (j | (i << 8) | ((t ^ 0x8000u) << 16)) : (i | (j << 8) | (t << 16));
+    float sn, cs;
+    sincosf(f16_bits_to_f32(th[e]), &sn, &cs);   // accurate libm sincos, once, at load time
+    // (i, j, theta) == (j, i, -theta): the orientation chosen above only swaps the roles and the sign of sin
+    o[lane * 4] = coef_word(cs, flip[e] ? j : i);
+    o[lane * 4 + 1] = coef_word(flip[e] ? -sn : sn, flip[e] ? i : j);
   }
 }
 
@@ -223,7 +249,7 @@ extern "C" int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* p
 
 extern "C" int64_t paro_packed_rot_bytes(int64_t K, int n_parts) {
   if (K <= 0 || K % 128 != 0 || n_parts < 1 || n_parts > PARO_MAX_PARTS) return -1;
-  return (int64_t)n_parts * (K / 128) * 64 * 8 * 4;
+  return (int64_t)n_parts * (K / 128) * 64 * 8 * 8;
 }
 
 extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,

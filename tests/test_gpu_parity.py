@@ -153,24 +153,29 @@ def test_repack_dequant_bit_exact(dev, K, sizes):
             assert np.array([wv >> 16], dtype=np.uint16).view(np.float16)[0] == int(z[g, col])
         col0 += s_
         ts0 += (s_ // 16 + 7) // 8 * 8
-    # rotation words: i | j << 8 | theta bits << 16
+    # rotation coefficient words: [p][g][stage pair][lane]{cos | 4i, sin | 4j, cos | 4i, sin | 4j}
     rot = torch.ops.paro.pack_rotation(_t(L["pairs"], dev), _t(L["theta"], dev)).cpu().numpy().view(np.uint32)
-    rot = rot.reshape(len(sizes), K // 128, 64, 8)
+    rot = rot.reshape(len(sizes), K // 128, 4, 64, 4)
     # Each stage holds the same 64 (i, j, theta) rotations as the checkpoint -- possibly re-ordered over
     # the lanes and re-oriented ((i, j, theta) == (j, i, -theta)) -- arranged so that within each 32-lane
     # half all i are distinct mod 32 and all j are distinct mod 32 (bank-conflict-free LDS schedule).
+    # cos / sin are fp32 words whose low 9 bits carry 4 * channel: within 2^-15 relative of the true value.
     for pp in range(len(sizes)):
         for r in range(8):
-            w = rot[pp, g, :, r]
-            i, j, th = w & 0xff, (w >> 8) & 0xff, (w >> 16).astype(np.uint16)
-            got = set()
-            for a, b, t in zip(i.tolist(), j.tolist(), th.tolist()):
-                got.add((a, b, t))
-                got.add((b, a, t ^ 0x8000))
+            wc, ws = rot[pp, g, r >> 1, :, 2 * (r & 1)], rot[pp, g, r >> 1, :, 2 * (r & 1) + 1]
+            i, j = (wc & 0x1ff) >> 2, (ws & 0x1ff) >> 2
+            assert not np.any(wc & 3) and not np.any(ws & 3)
+            c, sn = wc.view(np.float32).astype(np.float64), ws.view(np.float32).astype(np.float64)
+            got = {}
+            for a, b, cc, ss in zip(i.tolist(), j.tolist(), c.tolist(), sn.tolist()):
+                got[(a, b)] = (cc, ss)
+                got[(b, a)] = (cc, -ss)
             pr = L["pairs"][pp, r, g * 128:(g + 1) * 128].astype(np.int64)
-            tb = L["theta"][pp, r, g * 64:(g + 1) * 64].view(np.uint16)
+            th = L["theta"][pp, r, g * 64:(g + 1) * 64].astype(np.float64)
             for e in range(64):
-                assert (int(pr[2 * e]), int(pr[2 * e + 1]), int(tb[e])) in got
+                cc, ss = got[(int(pr[2 * e]), int(pr[2 * e + 1]))]
+                assert abs(cc - np.cos(th[e])) <= 2.0 ** -15 * abs(np.cos(th[e])) + 1e-30
+                assert abs(ss - np.sin(th[e])) <= 2.0 ** -15 * abs(np.sin(th[e])) + 1e-30
             assert sorted(np.concatenate([i, j]).tolist()) == list(range(128))
             for h in (slice(0, 32), slice(32, 64)):
                 assert len(set((i[h] % 32).tolist())) == 32 and len(set((j[h] % 32).tolist())) == 32
