@@ -101,16 +101,25 @@ int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols);
 int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
                     int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz, void* stream);
 
-/* Rotation parameters -> two coefficient words per (partition, group, stage, pair lane):
- *   out_rot uint32 [n_parts][K/128][4 stage pairs][64 lanes][4] = {cos_2q, sin_2q, cos_2q+1, sin_2q+1}
- * cos / sin of theta (libm accuracy, computed once here instead of in every launch) as fp32 words whose
- * low 9 bits are replaced by 4 * i (cos word) and 4 * j (sin word): the float nearest to the true value
- * among those (relative error <= 2^-15, below the kernel's single final rounding), with
- * (i, j) = pairs[p, r, 128g + 2e], pairs[p, r, 128g + 2e + 1], theta = theta[p, r, 64g + e]
- * (indexing of rotation.cuh:126-127).  The 64 pairs of a stage are assigned to lanes -- and oriented,
- * (i, j, theta) == (j, i, -theta) -- so that each 32-lane half touches 32 distinct LDS banks with its i
- * and with its j.  Stages r >= krot are filled with the identity.
- * Requires krot <= 8 (larger krot uses the unfused rotate + GEMV route). */
+/* Rotation parameters -> the register EXCHANGE SCHEDULE of every (partition, group), 3072 bytes each:
+ *   out_rot uint32 [n_parts][K/128][3][64 lanes][4]
+ * The fused GEMV keeps a group's rotation state in registers: lane l holds both members (A, B) of one
+ * pair of the current stage; a stage is  keep' = P A + Q B,  give' = P B - Q A,  after which the lane
+ * keeps keep' and fetches the give' of ONE other lane (ds_bpermute).  Which member a lane keeps, the
+ * (i, j) orientation and running signs are folded here into (P, Q) = (cos a, sin a),
+ * a in {+-theta + k pi/2}  (xi' = c xi + s xj, xj' = c xj - s xi, rotation.cuh:53-56;
+ * (i, j) = pairs[p, r, 128g + 2e], pairs[p, r, 128g + 2e + 1], theta = theta[p, r, 64g + e],
+ * rotation.cuh:126-127), stored as signed 16-bit fixed point in units of 2^-14 (absolute error
+ * <= 3.1e-5; +-1 and 0 exact):
+ *   chunk 0 / 1 : stage words t = 0..3 / 4..7 :  Q << 16 | P
+ *   chunk 2     : {4 * src_lane of stages 0..3, one byte each; the same for stages 4..7;
+ *                  final Q << 16 | P;  2 ch_a | 2 ch_b << 8 | (sigma < 0) << 31}
+ *                 final stage: out[ch_a] = P A + Q B, out[ch_b] = sigma (P B - Q A)
+ * Stage t = 0 is the identity on the natural layout (channels 2l, 2l+1), stage t >= 1 is checkpoint
+ * stage t - 1, the last checkpoint stage is the final one.
+ * Requires krot <= 8 (larger krot uses the unfused rotate + GEMV route).
+ * One-time load step: synchronises `stream` to report stages that are not perfect matchings of their
+ * 128 channels (PARO_ERR_INVALID "illegal pair", as optim/rotation.py:36-37 raises at conversion). */
 int64_t paro_packed_rot_bytes(int64_t K, int n_parts);
 int paro_pack_rotation(const int16_t* pairs, const void* theta, int64_t K, int n_parts, int krot, void* out_rot,
                        void* stream);
@@ -154,7 +163,7 @@ int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
 /* Decode / small-batch path (rows <= 16): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in {1,2,4,8}; ksplit >= 1;
- * waves per workgroup in {4,5,8,10,16}.  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
+ * waves per workgroup in {4,8,16}.  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
  * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows, pre-pass above). */
 int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);

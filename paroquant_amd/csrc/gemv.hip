@@ -134,7 +134,7 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   static const int env_flags = getenv("PARO_GEMV_FLAGS") ? atoi(getenv("PARO_GEMV_FLAGS")) : 0;
   a.flags = env_flags;
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
-  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31) ? env_pd : 1;
+  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
@@ -146,7 +146,7 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
-  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)a.pt.cbs * 384)
+  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)a.pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
   if (mode == 1) {
     unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);

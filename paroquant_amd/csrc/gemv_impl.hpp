@@ -8,8 +8,8 @@
 // Mapping (CDNA4-first, not a warp-tiled port):
 //   * work unit = (128-channel quantisation group g) x (TPW column tiles of 16 outputs).
 //     A 64-lane wavefront owns one unit at a time: 64 lanes == the 64 Givens pairs of the
-//     group, so the wave rotates ITS OWN slice of x in wave-private LDS with no workgroup
-//     barrier.  All 8 stages' coefficients (cos / sin words that also carry the LDS offsets of the
+//     group, so the wave rotates ITS OWN slice of x in its registers (one cross-lane fetch per
+//     stage, see the stage loop) with no workgroup barrier.  All 8 stages' coefficients (cos / sin words that also carry the LDS offsets of the
 //     pair) arrive as four coalesced 16-byte loads per lane (paro_pack_rotation), requested BEFORE the unit's INT4 tiles so that waiting for them
 //     does not wait for the tiles (vmcnt retires in order); the rotation then runs while
 //     the tiles (non-temporal, 1 KiB per wave-load, straight to VGPRs) are in flight.
@@ -48,40 +48,34 @@ struct GemvArgs {
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int flags;                             // debug (PARO_GEMV_FLAGS): 16 = return at kernel entry (launch floor)
-  int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31)
+  int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
   PartTable pt;
 };
 
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
-// PD: 1 = the shipping kernel; 11 / 21 / 31 = diagnostic builds of the M = 1 kernel (tools/ablate_gemv.py,
-// tools/timeline_gemv.py): 11 skips the rotation stages, 21 also the unpack + MFMA (pure stream), 31 records
-// s_memtime phase stamps per workgroup / per wave into the workspace.
-// Deeper prefetch (coefficients / tiles two units ahead) and pairs of units with interleaved rotation
-// chains were built and measured SLOWER on every Llama-3-8B / Qwen3-4B shape ("what did not
-// work"): more bulk loads in flight only lengthen the queue the small coefficient loads wait in.
+// PD: 1 = the shipping kernel; 11 / 21 / 31 / 41 / 51 / 61 = diagnostic builds of the M = 1 kernel (make DIAG=1;
+// tools/ablate_gemv.py, tools/timeline_gemv.py): 11 skips schedule + stages, 21 also the unpack + MFMA (pure
+// stream), 41 fetches the schedule but does not run the stages, 51 runs the stages without the cross-lane
+// fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps.
 template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
   constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile
-  constexpr int VW = MB >= 4 ? 4 : MB;                  // LDS vector width of the rotation state
-  constexpr int LOGVW = VW == 4 ? 2 : (VW == 2 ? 1 : 0);
-  constexpr int NCH = MB / VW;
-  typedef float V __attribute__((ext_vector_type(VW)));
-  typedef __attribute__((address_space(3))) V LdsV;
-  // LDS: [WAVES] fp32 rotation states (MB x 128 floats, 512-byte aligned so that a coefficient word's
-  // low bits OR straight into the address), then [WAVES] fragment-row blocks (MB rows + one zero row).
-  constexpr int XR_BYTES = PREROT ? 0 : MB * 512;
-  constexpr int XH_BYTES = PREROT ? 0 : (((MB + 1) * kXhStride * 2 + 15) / 16) * 16;
+  // LDS: per wave only the fragment-row block (MB rows + one zero row) that transposes the rotated
+  // slice into MFMA A-fragment order; the rotation state itself lives in registers.
+  constexpr int XH_HALVES = PREROT ? 0 : (((MB + 1) * kXhStride + 7) / 8) * 8;
+  constexpr int XH_BYTES = XH_HALVES * 2;
   constexpr int RED_FLOATS = WAVES * TPW * MR * 64;
-  constexpr int WORK_BYTES = WAVES * (XR_BYTES + XH_BYTES);
-  constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + 16;
+  constexpr int WORK_BYTES = WAVES * XH_BYTES;
+  constexpr int EX_BYTES = (PD / 10 == 6) ? WAVES * 256 : 0;   // diagnostic exchange slots
+  constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16;
   constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;  // 16-byte scale/zero vectors per unit
   constexpr int SZW = TPW < 4 ? TPW : 4;
   typedef unsigned SZV __attribute__((ext_vector_type(SZW)));
-  __shared__ __attribute__((aligned(512))) unsigned char lds[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,9 +86,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // rounds (each a scalar-cache miss at kernel start).
   asm volatile("" ::"s"(a.wq), "s"(a.sz), "s"(a.rot), "s"(a.cs), "s"(a.x), "s"(a.K), "s"(a.G), "s"(a.rows),
                "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts));
-  // DIAG 3: wave 0 of every workgroup timestamps its phases (s_memtime, shader clock) into a.slabs
+  // DIAG 3: phase stamps (s_memtime, shader clock) into a.slabs
   unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (DIAG == 3) ts[0] = __builtin_amdgcn_s_memtime();
+  // a stamp that cannot be scheduled before `dep` exists (s_memtime alone has no data dependencies and
+  // floats above the s_waitcnt it is meant to follow)
+  auto stamp_after = [](float dep) -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+  };
 
   // Partition lookup with compile-time kernarg offsets only (select chain, no data-dependent s_load):
   // the whole argument block is then fetched in ONE batch of scalar loads instead of six dependent
@@ -116,10 +117,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int g_begin = ks * a.gps;
   const int g_end = min(a.G, g_begin + a.gps);
 
-  float* xr = (float*)(lds + wave * XR_BYTES);
-  unsigned short* xh = (unsigned short*)(lds + WAVES * XR_BYTES + wave * XH_BYTES);
-  // LDS byte address of this wave's rotation state (wave-uniform, low 9 bits zero)
-  const unsigned xr_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)(wave * XR_BYTES);
+  unsigned short* xh = (unsigned short*)(lds + wave * XH_BYTES);
   if constexpr (!PREROT) {
     for (int c = lane; c < kXhStride; c += 64) xh[MB * kXhStride + c] = 0;  // zero row
   }
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
     unsigned csv;
-    u32x4 rc[PREROT ? 1 : 4];   // stages 2q, 2q+1: {cos | 4i, sin | 4j, cos | 4i, sin | 4j}
+    u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 : 1];
   };
   struct TBuf {
@@ -158,10 +156,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         if (avalid) b.xa[i] = *(const u32x4*)(xrot_p + (int64_t)brow * a.K + g * 128 + 32 * i + 8 * mq);
       }
     } else {
-      // 4 coalesced 1-KiB wave loads: [p][g][stage pair][lane] x 16 bytes (paro_pack_rotation)
-      const u32x4* rp = (const u32x4*)a.rot + ((int64_t)p * a.G + g) * 256 + lane;
+      // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
+      const u32x4* rp = (const u32x4*)a.rot + ((int64_t)p * a.G + g) * 192 + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b.rc[q] = rp[q * 64];
+      for (int q = 0; q < 3; ++q) b.rc[q] = rp[q * 64];
       b.csv = *(const unsigned*)(a.cs + (int64_t)p * a.K + g * 128 + 2 * lane);
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
@@ -170,9 +168,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
     }
   };
-  // Every load below is unconditional (ragged column blocks re-read their last tile and mask it
-  // later) so that the compiler's vmcnt bookkeeping is exact: the wait in front of the rotation
-  // covers only the coefficient loads and leaves the tile loads in flight.
+  // Every load is unconditional (ragged column blocks re-read their last tile and mask it later; waves
+  // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
+  // for coefficients never waits for the younger tile loads (vmcnt retires in order).
   auto load_t = [&](TBuf& b, int g) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -184,76 +182,78 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int v = 0; v < NSZ; ++v) b.sz[v] = *(const SZV*)(sp + v * 64);
   };
 
-  PBuf pc, pn;
-  TBuf tc, tn;
-
-  // One work unit: rotate group g's slice of x (coefficients in pc), then consume its tiles (tc).
-  // Software pipeline, distance 1.  PFP: request the NEXT unit's coefficients before this unit's
-  // rotation; PFT: request the next unit's tiles before this unit's tiles are consumed.  Coefficients
-  // are always requested before the tiles of the same unit (in-order vmcnt: a wait for coefficients
-  // never waits for younger tile loads).
-  auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt) {
-    constexpr bool PFP = decltype(pfp_tag)::value;
-    constexpr bool PFT = decltype(pft_tag)::value;
-    if constexpr (PFP) load_p(pn, gp);
-
-    // ---- A fragments of this group (4 x K=32)
-    vec8 af[4];
-    if constexpr (PREROT) {
+  // ---- rotation pieces (state in REGISTERS: lane l holds both members (A, B) of one pair of the stage)
+  // The packed coefficients are 16-bit integers in units of 2^-14.  They are used AS integers (two
+  // converts, no scaling op: the rotation is replicated in every workgroup and VALU-issue bound), so the
+  // state grows by 2^14 per stage; exact power-of-two bookkeeping keeps it in range: the state starts at
+  // 2^-63 x, and the final stage's coefficients carry 2^(49 - 14 krot).
+  // start: channels 2l, 2l+1 of the group (one coalesced load), times their channel scales
+  auto seed = [&](const PBuf& b, float (&sa)[MB], float (&sb)[MB]) {
+    const float c0 = f16_bits_to_f32(b.csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(b.csv >> 16) * 0x1p-63f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
-    } else {
-      const float c0 = f16_bits_to_f32(pc.csv & 0xffffu), c1 = f16_bits_to_f32(pc.csv >> 16);
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        const int ch = r / VW, v = r % VW;
-        const unsigned xv = r < a.rows ? pc.xv[r] : 0u;
-        xr[(ch * 128 + 2 * lane) * VW + v] = A::to_f32(xv & 0xffffu) * c0;
-        xr[(ch * 128 + 2 * lane + 1) * VW + v] = A::to_f32(xv >> 16) * c1;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = __builtin_amdgcn_s_memtime(); }   // coefficients + x arrived
-      // Givens stages.  Lane l owns one pair per stage; cos / sin come ready-made from the packed
-      // words (computed once at load time with libm accuracy), whose low 9 bits are the LDS byte
-      // offsets of the pair's two channels: 2 address ops + 4 FMA-class ops + 4 DS ops per stage and row
-      // vector.  (The first version decoded (i, j, theta) and ran v_sin / v_cos here: 22 issue slots per
-      // stage -- the per-workgroup timeline showed every wave VALU-bound on exactly that.)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if ((DIAG == 0 || DIAG == 3) && r < a.krot) {
-          const unsigned wc = pc.rc[r >> 1][2 * (r & 1)], wsn = pc.rc[r >> 1][2 * (r & 1) + 1];
-          const float c = __builtin_bit_cast(float, wc), s = __builtin_bit_cast(float, wsn);
-          const unsigned ai = ((wc & 0x1fcu) << LOGVW) | xr_lds;
-          const unsigned aj = ((wsn & 0x1fcu) << LOGVW) | xr_lds;
-          V va[NCH], vb[NCH];
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            va[ch] = *(const LdsV*)(size_t)(ai + ch * 512 * VW);
-            vb[ch] = *(const LdsV*)(size_t)(aj + ch * 512 * VW);
-          }
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            *(LdsV*)(size_t)(ai + ch * 512 * VW) = va[ch] * c + vb[ch] * s;
-            *(LdsV*)(size_t)(aj + ch * 512 * VW) = vb[ch] * c - va[ch] * s;
-          }
-          // a wave's DS operations execute in issue order, so the next stage's reads see these
-          // writes; the barrier only stops the compiler from reordering across stages
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      // fp32 state -> activation-dtype fragment rows (one rounding), lane l converts channels 2l, 2l+1
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        const int ch = r / VW, v = r % VW;
-        const float v0 = xr[(ch * 128 + 2 * lane) * VW + v];
-        const float v1 = xr[(ch * 128 + 2 * lane + 1) * VW + v];
-        *(unsigned*)(xh + r * kXhStride + 2 * lane) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const unsigned short* afrag = xh + (avalid ? brow : MB) * kXhStride + 8 * mq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
+    for (int r = 0; r < MB; ++r) {
+      const unsigned xv = r < a.rows ? b.xv[r] : 0u;
+      sa[r] = A::to_f32(xv & 0xffffu) * c0;
+      sb[r] = A::to_f32(xv >> 16) * c1;
     }
+  };
+  const float final_scale = __builtin_ldexpf(1.0f, 49 - 14 * a.krot);
+  // Stage t: keep' = P A + Q B, give' = P B - Q A, then ONE cross-lane fetch: the lane keeps keep' and
+  // pulls the give' of lane `src` (ds_bpermute_b32: no LDS memory, no bank conflicts).  Which member is
+  // kept, the pair orientation and the running signs are folded into (P, Q) at load time (repack.hip).
+  // Stage 0 is the identity that moves the natural layout into the first checkpoint stage's pairs.
+  auto stage = [&](const PBuf& b, int t, float (&sa)[MB], float (&sb)[MB]) {
+    const unsigned w = b.rc[t >> 2][t & 3];
+    const unsigned sw = b.rc[2][t >> 2];
+    const float P = (float)(int)(short)(w & 0xffffu), Q = (float)((int)w >> 16);
+    const int src = (int)((sw >> (8 * (t & 3))) & 0xffu);   // 4 * source lane
+#pragma unroll
+    for (int r = 0; r < MB; ++r) {
+      const float keep = __builtin_fmaf(P, sa[r], Q * sb[r]);
+      const float give = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+      if constexpr (DIAG == 5) {          // diagnostic: no cross-lane fetch at all (wrong results)
+        sb[r] = give;
+      } else if constexpr (DIAG == 6) {   // diagnostic: the exchange through LDS memory (write own slot, read the source's)
+        float* ex = (float*)(lds + LDS_BYTES - 16) - (wave + 1) * 64;
+        ex[lane] = give;
+        __builtin_amdgcn_wave_barrier();
+        sb[r] = *(const float*)((const char*)ex + src);
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        sb[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, give)));
+      }
+      sa[r] = keep;
+    }
+  };
+  // last checkpoint stage in place: out[a] = P A + Q B, out[b] = sigma (P B - Q A); ONE rounding to the
+  // activation dtype, scattered to the channels' places in the fragment rows of unit slot `xs`
+  auto finish = [&](const PBuf& b, unsigned short* xs, const float (&sa)[MB], const float (&sb)[MB]) {
+    const unsigned w0 = b.rc[2][2], w1 = b.rc[2][3];
+    const float P = (float)(int)(short)(w0 & 0xffffu) * final_scale, Q = (float)((int)w0 >> 16) * final_scale;
+    unsigned oa = w1 & 0xfeu, ob = (w1 >> 8) & 0xfeu;   // byte offsets of the two channels in a fragment row
+    const unsigned flip = w1 & 0x80000000u;
+    if constexpr (DIAG == 1 || DIAG == 2 || DIAG == 4) { oa = 4 * lane; ob = 4 * lane + 2; }
+#pragma unroll
+    for (int r = 0; r < MB; ++r) {
+      float o1 = sa[r], o2 = sb[r];
+      if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
+        o1 = __builtin_fmaf(P, sa[r], Q * sb[r]);
+        const float d = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+        o2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ flip);
+      }
+      *(unsigned short*)((unsigned char*)(xs + r * kXhStride) + oa) = A::from_f32(o1);
+      *(unsigned short*)((unsigned char*)(xs + r * kXhStride) + ob) = A::from_f32(o2);
+    }
+  };
+  auto touch = [&](const PBuf& b, float (&sa)[MB]) {   // DIAG 4: the schedule words are waited for, the stages not run
+    unsigned acc_w = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc_w ^= b.rc[q][0] ^ b.rc[q][1] ^ b.rc[q][2] ^ b.rc[q][3];
+    sa[0] += (acc_w == 0x12345u) ? 1.f : 0.f;
+  };
+
+  // ---- consume one unit's tiles: fragments from LDS (or registers), sums, unpack -> MFMA -> scale / zero
+  auto consume = [&](const vec8 (&af)[4], const TBuf& t) {
     // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in)
     f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
     {
@@ -267,39 +267,76 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         so = A::mfma(af[i], fb, so);
       }
     }
-    if constexpr (PFT) load_t(tn, gt);
-    if constexpr (DIAG == 3) { if (ts[3] == 0) ts[3] = __builtin_amdgcn_s_memtime(); }     // first rotation + fragments done
-
-    // ---- per tile: unpack -> 4 MFMA -> scale / zero point on the fp32 result
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       f32x4 d = {0.f, 0.f, 0.f, 0.f};
       if constexpr (DIAG == 2) {
-        d[0] = __builtin_bit_cast(float, (tc.q[j][0] ^ tc.q[j][1] ^ tc.q[j][2] ^ tc.q[j][3]) & 0x3fffffffu);
+        d[0] = __builtin_bit_cast(float, (t.q[j][0] ^ t.q[j][1] ^ t.q[j][2] ^ t.q[j][3]) & 0x3fffffffu);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           unsigned w4[4];
-          A::unpack_fast(tc.q[j][i], w4);
+          A::unpack_fast(t.q[j][i], w4);
           const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
           d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
         }
       }
-      const unsigned szw = tc.sz[j / 4][j % 4];
+      const unsigned szw = t.sz[j / 4][j % 4];
       const float s = f16_bits_to_f32(szw & 0xffffu);
       const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
       for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
     }
-    if constexpr (DIAG == 3) {
-      if (acc[0][0] != 12345.678f && ts[4] == 0) ts[4] = __builtin_amdgcn_s_memtime();     // first unit's tiles consumed
-    }
-    if constexpr (PFP) pc = pn;
-    if constexpr (PFT) tc = tn;
+  };
+  auto frags_from_lds = [&](const unsigned short* xs, vec8 (&af)[4]) {
+    const unsigned short* afrag = xs + (avalid ? brow : MB) * kXhStride + 8 * mq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
   };
 
+  const int g0 = g_begin + wave;
   {
-    const int g0 = g_begin + wave;
+    // One unit at a time, distance-1 software pipeline.
+    // (Tried and measured equal or slower, MI355X, every Llama-3-8B / Qwen3-4B shape: deeper prefetch;
+    // all of a wave's 2..4 units rotated together with interleaved stage chains and every load issued up
+    // front -- the rotation then is VALU-issue bound (7 issue slots per unit and stage, replicated in every
+    // workgroup), not latency bound, so overlapping the chains buys nothing; a workgroup barrier between
+    // the coefficient and the tile requests.  See DESIGN.md "what did not work".)
+    PBuf pc, pn;
+    TBuf tc, tn;
+    // PFP: request the NEXT unit's coefficients before this unit's rotation; PFT: request the next
+    // unit's tiles before this unit's tiles are consumed.  Coefficients are always requested before
+    // the tiles of the same unit.
+    auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt) {
+      constexpr bool PFP = decltype(pfp_tag)::value;
+      constexpr bool PFT = decltype(pft_tag)::value;
+      if constexpr (PFP) load_p(pn, gp);
+      vec8 af[4];
+      if constexpr (PREROT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
+      } else {
+        float sa[MB], sb[MB];
+        seed(pc, sa, sb);
+        if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = stamp_after(sa[0] + sb[0]); }
+        if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            if (t < a.krot) stage(pc, t, sa, sb);
+          }
+        }
+        if constexpr (DIAG == 4) touch(pc, sa);
+        if constexpr (DIAG == 3) { if (ts[9] == 0) ts[9] = stamp_after(sa[0] + sb[0]); }
+        finish(pc, xh, sa, sb);
+        __builtin_amdgcn_wave_barrier();
+        frags_from_lds(xh, af);
+      }
+      if constexpr (PFT) load_t(tn, gt);
+      consume(af, tc);
+      if constexpr (DIAG == 3) { if (ts[4] == 0) ts[4] = stamp_after(acc[0][0]); }
+      if constexpr (PFP) pc = pn;
+      if constexpr (PFT) tc = tn;
+    };
     const std::true_type yes{};
     const std::false_type no{};
     // The first unit's loads are issued unconditionally (group index clamped) BEFORE any branch, so the
@@ -320,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   }
 
-  if constexpr (DIAG == 3) ts[5] = acc[0][0] != 12345.678f ? __builtin_amdgcn_s_memtime() : 0;  // all units done
+  if constexpr (DIAG == 3) ts[5] = stamp_after(acc[0][0]);  // all units done
   // ---- reduce the workgroup's waves (different groups, same columns) through LDS
   __syncthreads();
   if constexpr (DIAG == 3) ts[7] = __builtin_amdgcn_s_memtime();   // every wave of the workgroup has finished its units
@@ -370,16 +407,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   }
   if constexpr (DIAG == 3) {
     ts[6] = __builtin_amdgcn_s_memtime();
-    // 48 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], then (start, units done) of every wave
+    // 80 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], stages done [10], then
+    // (start, first coefficients arrived, first unit done, all units done) of every wave from [16]
     if (a.slabs) {
-      unsigned long long* dbg = a.slabs + ((int64_t)(ks * gridDim.x + cb)) * 48;
+      unsigned long long* dbg = a.slabs + ((int64_t)(ks * gridDim.x + cb)) * 80;
       if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) dbg[k] = ts[k];
+        dbg[10] = ts[9];
         dbg[9] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
                  ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
       }
-      if (lane == 0 && wave < 16) { dbg[10 + 2 * wave] = ts[0]; dbg[11 + 2 * wave] = ts[5]; }
+      if (lane == 0 && wave < 16) {
+        dbg[16 + 4 * wave] = ts[0];
+        dbg[17 + 4 * wave] = ts[2];
+        dbg[18 + 4 * wave] = ts[4];
+        dbg[19 + 4 * wave] = ts[5];
+      }
     }
   }
 }
@@ -390,16 +434,6 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (MB <= 4 && TPW <= 4) {
     if (waves == 16) {
       hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
-      return PARO_OK;
-    }
-  }
-  if constexpr (MB <= 4 && !PREROT) {  // odd group counts (K = 2560 -> 20 groups, K = 9728 -> 76): 5 / 10 waves divide them evenly
-    if (waves == 10 && TPW <= 4) {
-      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 10, PREROT, PD>), grid, dim3(640), 0, st, a);
-      return PARO_OK;
-    }
-    if (waves == 5) {
-      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 5, PREROT, PD>), grid, dim3(320), 0, st, a);
       return PARO_OK;
     }
   }
@@ -416,12 +450,17 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  // only PD 1 ships; PARO_GEMV_PD = 11 / 21 / 31 select the diagnostic builds of the M = 1 kernel
+#ifdef PARO_GEMV_DIAG   // make DIAG=1: diagnostic builds of the M = 1 kernel, selected with PARO_GEMV_PD = 11 / 21 / 31 / 41
   if constexpr (MB == 1 && !PREROT) {
     if (a.pd == 11) return launch_waves_pd<AT, TPW, MB, PREROT, 11>(a, waves, grid, st);
     if (a.pd == 21) return launch_waves_pd<AT, TPW, MB, PREROT, 21>(a, waves, grid, st);
     if (a.pd == 31) return launch_waves_pd<AT, TPW, MB, PREROT, 31>(a, waves, grid, st);
+    if (a.pd == 41) return launch_waves_pd<AT, TPW, MB, PREROT, 41>(a, waves, grid, st);
+    if (a.pd == 51) return launch_waves_pd<AT, TPW, MB, PREROT, 51>(a, waves, grid, st);
+    if (a.pd == 61) return launch_waves_pd<AT, TPW, MB, PREROT, 61>(a, waves, grid, st);
   }
+#endif
+  if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

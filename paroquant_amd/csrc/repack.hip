@@ -57,156 +57,159 @@ __global__ __launch_bounds__(256) void pack_sz_kernel(const unsigned* __restrict
   out[(((int64_t)g * (pt.tsz / 4) + (ts >> 2)) * 16 + n) * 4 + (ts & 3)] = s | (zf << 16);
 }
 
-// One rotation coefficient word: the fp32 value NEAREST to `v` whose low 9 bits equal `4 * channel`
-// (the LDS byte offset of the channel's fp32 state).  The GEMV uses the word as the float directly
-// (relative error <= 2^-15, below the single final rounding to fp16 / bf16) and masks 0x1fc for the address.
-__device__ __forceinline__ unsigned coef_word(float v, unsigned channel) {
-  const unsigned lo = (channel & 127u) * 4u;
-  const unsigned b = (__builtin_bit_cast(unsigned, v) & ~0x1ffu) | lo;
-  unsigned best = b;
-  float err = fabsf(__builtin_bit_cast(float, b) - v);
-  if ((b & 0x7fffffffu) >= 0x200u) {
-    const float e = fabsf(__builtin_bit_cast(float, b - 0x200u) - v);
-    if (e < err) { err = e; best = b - 0x200u; }
-  }
-  {
-    const float e = fabsf(__builtin_bit_cast(float, b + 0x200u) - v);
-    if (e < err) { err = e; best = b + 0x200u; }
-  }
-  return best;
+// Rotation parameters of one (partition, group) -> the EXCHANGE SCHEDULE the fused GEMV executes with the
+// rotation state in registers (one thread per (partition, group); stages depend on each other).
+//
+// In the kernel lane l always holds BOTH members (A, B) of one pair of the current stage, so a stage is
+// four FMA-class ops on registers.  Between two stages every lane keeps one of its two channels and
+// fetches ONE value from another lane (a single ds_bpermute_b32): the union of two perfect matchings is a
+// set of alternating cycles, and walking each cycle in one direction gives every next-stage pair a lane
+// that already holds one of its members.  Which member is kept and the (i, j) orientation are absorbed
+// into the coefficients:
+//     keep' = P A + Q B      give' = P B - Q A      B <- give' of lane src, A <- keep'
+// with per-channel signs tracked here (the stored value of a channel may be the negated true value; the
+// last stage restores them).  (P, Q) is always (cos a, sin a) of an angle a in {+-theta + k pi/2}; both are
+// stored as signed 16-bit fixed point in units of 2^-14 (absolute error <= 3.1e-5, +-1 exact, so the
+// identity and the zero-angle dummy pairs of optim/rotation.py:53 are exact): one word per lane and
+// stage, decoded by two converts and used as integers (the kernel tracks the power-of-two scale) -- no
+// v_sin / v_cos in the launch (they cost 32 of the stage's 68 issue cycles when tried) and half the bytes
+// of ready-made fp32 pairs.  Every workgroup re-reads this stream
+// for every group it covers, so its size is L2 -> L1 traffic on every CU: 3 KiB per group, the size of
+// the checkpoint's own int16 pairs + fp16 theta.
+// Stage t = 0 is the identity on the natural layout (channels 2l, 2l+1 from one coalesced load); stage
+// t >= 1 is checkpoint stage t - 1; the last checkpoint stage produces both outputs in place,
+//     out[a] = P A + Q B      out[b] = sigma (P B - Q A).
+// Output, uint32 [p][g][3][64 lanes][4]:
+//   chunk 0 / 1: stage words t = 0..3 / 4..7:  Q << 16 | P
+//   chunk 2:     {4 * src of stages 0..3 (one byte each), 4 * src of stages 4..7, final Q << 16 | P,
+//                 2a | 2b << 8 | (sigma < 0) << 31}
+// Update of a pair follows rotation.cuh:53-56: xi' = c xi + s xj, xj' = c xj - s xi.
+// A stage that is not a perfect matching of the 128 channels (the reference's converter raises
+// "illegal pair", optim/rotation.py:36-37) sets *bad.
+__device__ __forceinline__ unsigned coef_word(double P, double Q) {
+  const int pi = (int)llrint(P * 16384.0), qi = (int)llrint(Q * 16384.0);
+  return ((unsigned)qi << 16) | ((unsigned)pi & 0xffffu);
 }
 
-// One thread per (partition, group, stage): pack that stage's 64 Givens pairs into lane words
-//   i | j << 8 | theta_fp16 << 16
-// and, because WHICH lane applies a pair and the pair's orientation are free
-// ((i, j, theta) == (j, i, -theta): xi' = c xi + s xj, xj' = c xj - s xi), choose both so that the
-// stage's LDS traffic is bank-conflict free: ds_read/write_b32 is serviced per 32-lane half over 32
-// banks (bank = channel mod 32), so within each half all `i` channels must differ mod 32 and all `j`
-// channels must differ mod 32.  Construction: the 64 pairs are the edges of a 4-regular multigraph
-// on the 32 bank classes; an Euler orientation gives every class out-degree 2 (as `i`) and in-degree
-// 2 (as `j`); the resulting 2-regular bipartite graph (i-classes x j-classes) splits into two perfect
-// matchings by alternating along its cycles -- one matching per half-wave.  Always succeeds when the
-// stage is a perfect matching of the 128 channels (every valid checkpoint: optim/rotation.py:37-54);
-// otherwise the input order is kept (still correct, just not conflict free).
 __global__ __launch_bounds__(64) void pack_rot_kernel(const int16_t* __restrict__ pairs,
                                                      const unsigned short* __restrict__ theta,
-                                                     unsigned* __restrict__ out, int K, int nparts, int krot) {
+                                                     unsigned* __restrict__ out, int K, int nparts, int krot,
+                                                     int* __restrict__ bad) {
   const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int G = K / 128;
-  if (gid >= (int64_t)nparts * G * 8) return;
-  const int r = (int)(gid & 7);
-  const int g = (int)((gid >> 3) % G);
-  const int p = (int)((gid >> 3) / G);
-  // [p][g][stage pair q = r >> 1][lane][4 words]: words 2 * (r & 1) + {0, 1} of the lane's 16-byte chunk
-  unsigned* o = out + (((int64_t)p * G + g) * 4 + (r >> 1)) * 256 + 2 * (r & 1);  // + lane * 4
-  if (r >= krot) {
-    for (int l = 0; l < 64; ++l) {  // identity stage (never executed: the kernels stop at krot)
-      o[l * 4] = coef_word(1.0f, 2 * l);
-      o[l * 4 + 1] = coef_word(0.0f, 2 * l + 1);
-    }
-    return;
-  }
-  const int64_t pb = (int64_t)p * krot + r;
-  const int16_t* pr = pairs + pb * K + g * 128;
-  const unsigned short* th = theta + pb * (K / 2) + g * 64;
+  if (gid >= (int64_t)nparts * G) return;
+  const int g = (int)(gid % G), p = (int)(gid / G);
+  unsigned* o = out + gid * 768;
+  for (int l = 0; l < 64; ++l) o[(128 + l) * 4] = o[(128 + l) * 4 + 1] = 0u;
 
-  unsigned char ei[64], ej[64], flip[64], half[64];
-  signed char adj[32][4];
-  unsigned char deg[32], seen[128];
-  bool valid = true;
-  for (int c = 0; c < 32; ++c) deg[c] = 0;
-  for (int c = 0; c < 128; ++c) seen[c] = 0;
-  for (int e = 0; e < 64; ++e) {
-    const int i = pr[2 * e], j = pr[2 * e + 1];
-    if (i < 0 || i > 127 || j < 0 || j > 127 || i == j || seen[i & 127] || seen[j & 127]) {
-      valid = false;
-      break;
-    }
-    seen[i] = seen[j] = 1;
-    ei[e] = (unsigned char)i;
-    ej[e] = (unsigned char)j;
-    flip[e] = 0;
-    half[e] = (unsigned char)(e >> 5);
-    adj[i & 31][deg[i & 31]++] = (signed char)e;
-    adj[j & 31][deg[j & 31]++] = (signed char)e;  // a loop (i == j mod 32) appears twice in its class
+  unsigned char chA[64], chB[64], lane_of[128], partner[128], pe_cur[128], pe_next[128], isi_cur[128], isi_next[128];
+  unsigned char keepA[64], src[64], seen[128], done[64];
+  signed char tau[128];
+  for (int l = 0; l < 64; ++l) {
+    chA[l] = (unsigned char)(2 * l);
+    chB[l] = (unsigned char)(2 * l + 1);
   }
-  if (valid) {
-    // --- Euler orientation: walk closed trails, orienting every edge away from the vertex it is left by
-    unsigned char used[64], tail[64], head[64];
-    for (int e = 0; e < 64; ++e) used[e] = 0;
-    for (int start = 0; start < 32; ++start) {
-      int v = start;
-      for (;;) {
-        int e = -1;
-        for (int s = 0; s < 4; ++s)
-          if (!used[adj[v][s]]) {
-            e = adj[v][s];
-            break;
-          }
-        if (e < 0) break;
-        used[e] = 1;
-        const int ci = ei[e] & 31, cj = ej[e] & 31;
-        int w;
-        if (ci == v) {
-          flip[e] = 0;
-          w = cj;
-        } else {
-          flip[e] = 1;
-          w = ci;
-        }
-        tail[e] = (unsigned char)v;
-        head[e] = (unsigned char)w;
-        v = w;
-      }
-    }
-    // --- 2-colour the 2-regular bipartite graph (tails x heads) by alternating along its cycles
-    signed char outE[32][2], inE[32][2];
-    unsigned char no[32], ni[32];
-    for (int c = 0; c < 32; ++c) no[c] = ni[c] = 0;
+  for (int c = 0; c < 128; ++c) {
+    tau[c] = 1;
+    pe_cur[c] = 0;
+    isi_cur[c] = 1;
+  }
+
+  // checkpoint stage r of this (p, g): matching + roles
+  auto load_stage = [&](int r) -> bool {
+    const int16_t* pr = pairs + ((int64_t)p * krot + r) * K + g * 128;
+    for (int c = 0; c < 128; ++c) seen[c] = 0;
     for (int e = 0; e < 64; ++e) {
-      if (no[tail[e]] >= 2 || ni[head[e]] >= 2) {
-        valid = false;
-        break;
-      }
-      outE[tail[e]][no[tail[e]]++] = (signed char)e;
-      inE[head[e]][ni[head[e]]++] = (signed char)e;
+      const int i = pr[2 * e], j = pr[2 * e + 1];
+      if (i < 0 || i > 127 || j < 0 || j > 127 || i == j || seen[i & 127] || seen[j & 127]) return false;
+      seen[i] = seen[j] = 1;
+      partner[i] = (unsigned char)j;
+      partner[j] = (unsigned char)i;
+      pe_next[i] = pe_next[j] = (unsigned char)e;
+      isi_next[i] = 1;
+      isi_next[j] = 0;
     }
-    if (valid) {
-      unsigned char col[64];
-      for (int e = 0; e < 64; ++e) col[e] = 2;
-      for (int e0 = 0; e0 < 64; ++e0) {
-        if (col[e0] != 2) continue;
-        int e = e0;
-        for (;;) {
-          col[e] = 0;
-          const int hv = head[e];
-          const int f = (inE[hv][0] == e) ? inE[hv][1] : inE[hv][0];  // the other edge into this head class
-          if (col[f] != 2) break;
-          col[f] = 1;
-          const int tv = tail[f];
-          const int gnext = (outE[tv][0] == f) ? outE[tv][1] : outE[tv][0];  // the other edge out of that tail class
-          if (col[gnext] != 2) break;
-          e = gnext;
-        }
-      }
-      for (int e = 0; e < 64; ++e) half[e] = col[e];
+    return true;
+  };
+  // rotation matrix entries of the CURRENT stage for the lane holding (a, b):  x_a' = c x_a + m x_b,  x_b' = c x_b - m x_a
+  auto coeffs = [&](int t, int a, double& c, double& m) {
+    if (t == 0) {
+      c = 1.0;
+      m = 0.0;
+      return;
+    }
+    const unsigned short th = theta[((int64_t)p * krot + (t - 1)) * (K / 2) + g * 64 + pe_cur[a]];
+    double sn, cs;
+    sincos((double)f16_bits_to_f32(th), &sn, &cs);
+    c = cs;
+    m = isi_cur[a] ? sn : -sn;
+  };
+
+  for (int t = 0; t < krot; ++t) {     // 2-word stages: identity (t = 0) and checkpoint stages 0 .. krot-2
+    if (!load_stage(t)) {              // the matching the lanes must hold AFTER this stage
+      atomicOr(bad, 1);
+      return;
+    }
+    for (int l = 0; l < 64; ++l) {
+      lane_of[chA[l]] = lane_of[chB[l]] = (unsigned char)l;
+      done[l] = 0;
+    }
+    // walk the alternating cycles: lane l keeps channel k and receives partner[k] from the lane holding it,
+    // which therefore gives that channel away and keeps its other one
+    for (int l0 = 0; l0 < 64; ++l0) {
+      if (done[l0]) continue;
+      int l = l0, k = chA[l0];
+      do {
+        done[l] = 1;
+        keepA[l] = (unsigned char)(k == chA[l]);
+        const int want = partner[k];
+        const int l2 = lane_of[want];
+        src[l] = (unsigned char)l2;
+        k = (want == chA[l2]) ? chB[l2] : chA[l2];
+        l = l2;
+      } while (l != l0);
+    }
+    for (int l = 0; l < 64; ++l) {
+      const int a = chA[l], b = chB[l];
+      double c, m;
+      coeffs(t, a, c, m);
+      // keep = a:  x_a' =  c x_a + m x_b ;  keep = b:  x_b' = -m x_a + c x_b
+      const double alpha = keepA[l] ? c : -m, beta = keepA[l] ? m : c;
+      o[((t >> 2) * 64 + l) * 4 + (t & 3)] = coef_word(alpha * tau[a], beta * tau[b]);
+      o[(128 + l) * 4 + (t >> 2)] |= (4u * src[l]) << (8 * (t & 3));
+    }
+    // new signs (all lanes read the old ones above), then the new layout
+    signed char ntau[64];
+    for (int l = 0; l < 64; ++l) ntau[l] = (signed char)((keepA[l] ? 1 : -1) * tau[chA[l]] * tau[chB[l]]);
+    for (int l = 0; l < 64; ++l) {
+      const int k = keepA[l] ? chA[l] : chB[l], gv = keepA[l] ? chB[l] : chA[l];
+      tau[k] = 1;
+      tau[gv] = ntau[l];
+    }
+    for (int l = 0; l < 64; ++l) {
+      const int k = keepA[l] ? chA[l] : chB[l];
+      chA[l] = (unsigned char)k;
+      chB[l] = partner[k];
+    }
+    for (int c = 0; c < 128; ++c) {
+      pe_cur[c] = pe_next[c];
+      isi_cur[c] = isi_next[c];
     }
   }
-  int next[2] = {0, 32};
-  if (!valid) {
-    for (int e = 0; e < 64; ++e) {
-      flip[e] = 0;
-      half[e] = (unsigned char)(e >> 5);
+  // unused stage slots (krot < 8): identity, never executed
+  for (int t = krot; t < 8; ++t)
+    for (int l = 0; l < 64; ++l) {
+      o[((t >> 2) * 64 + l) * 4 + (t & 3)] = coef_word(1.0, 0.0);
+      o[(128 + l) * 4 + (t >> 2)] |= (4u * l) << (8 * (t & 3));
     }
-  }
-  for (int e = 0; e < 64; ++e) {
-    const unsigned i = (unsigned short)pr[2 * e] & 0xffu, j = (unsigned short)pr[2 * e + 1] & 0xffu;
-    const int lane = next[half[e]]++;
-    float sn, cs;
-    sincosf(f16_bits_to_f32(th[e]), &sn, &cs);   // accurate libm sincos, once, at load time
-    // (i, j, theta) == (j, i, -theta): the orientation chosen above only swaps the roles and the sign of sin
-    o[lane * 4] = coef_word(cs, flip[e] ? j : i);
-    o[lane * 4 + 1] = coef_word(flip[e] ? -sn : sn, flip[e] ? i : j);
+  // last checkpoint stage: out[a] = c ta A + m tb B,  out[b] = -m ta A + c tb B = sigma (P B - Q A), sigma = ta tb
+  for (int l = 0; l < 64; ++l) {
+    const int a = chA[l], b = chB[l];
+    double c, m;
+    coeffs(krot, a, c, m);
+    unsigned* w = o + (128 + l) * 4 + 2;
+    w[0] = coef_word(c * tau[a], m * tau[b]);
+    w[1] = (2u * a) | ((2u * b) << 8) | ((tau[a] * tau[b] < 0) ? 0x80000000u : 0u);
   }
 }
 
@@ -249,7 +252,7 @@ extern "C" int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* p
 
 extern "C" int64_t paro_packed_rot_bytes(int64_t K, int n_parts) {
   if (K <= 0 || K % 128 != 0 || n_parts < 1 || n_parts > PARO_MAX_PARTS) return -1;
-  return (int64_t)n_parts * (K / 128) * 64 * 8 * 8;
+  return (int64_t)n_parts * (K / 128) * 3072;
 }
 
 extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
@@ -283,9 +286,23 @@ extern "C" int paro_pack_rotation(const int16_t* pairs, const void* theta, int64
   if (n_parts < 1 || n_parts > PARO_MAX_PARTS) return fail(PARO_ERR_INVALID, "n_parts must be in 1..%d", PARO_MAX_PARTS);
   if (krot < 1 || krot > 8) return fail(PARO_ERR_UNSUPPORTED, "packed rotation supports krot 1..8 (got %d)", krot);
   if (!pairs || !theta || !out_rot) return fail(PARO_ERR_INVALID, "null pointer");
-  const int64_t n = (int64_t)n_parts * (K / 128) * 8;
-  hipLaunchKernelGGL(pack_rot_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pairs,
-                     (const unsigned short*)theta, (unsigned*)out_rot, (int)K, n_parts, krot);
+  // One-time load step: a device flag reports stages that are not perfect matchings; reading it back
+  // synchronises the stream (the hot calls never do).
+  hipStream_t st = (hipStream_t)stream;
+  int* bad = nullptr;
+  if (hipMalloc((void**)&bad, sizeof(int)) != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipMalloc failed in paro_pack_rotation");
+  (void)hipMemsetAsync(bad, 0, sizeof(int), st);
+  const int64_t n = (int64_t)n_parts * (K / 128);
+  hipLaunchKernelGGL(pack_rot_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pairs,
+                     (const unsigned short*)theta, (unsigned*)out_rot, (int)K, n_parts, krot, bad);
+  int host_bad = 0;
+  const hipError_t e1 = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(bad);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(PARO_ERR_LAUNCH, "paro_pack_rotation: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  if (host_bad)
+    return fail(PARO_ERR_INVALID, "illegal pair: a rotation stage is not a perfect matching of its 128-channel group "
+                                  "(indices out of range, repeated or i == j)");
   return check_launch("paro_pack_rotation");
 }
 

@@ -131,7 +131,7 @@ def _pack_rotation_impl(pairs: torch.Tensor, theta: torch.Tensor) -> torch.Tenso
 
 def _pack_rotation_fake(pairs, theta):
     P, krot, K = pairs.shape
-    return pairs.new_empty(0 if krot > 8 else P * (K // 128) * 1024, dtype=torch.int32)
+    return pairs.new_empty(0 if krot > 8 else P * (K // 128) * 768, dtype=torch.int32)
 
 
 # --------------------------------------------------------------------------------------

@@ -153,32 +153,78 @@ def test_repack_dequant_bit_exact(dev, K, sizes):
             assert np.array([wv >> 16], dtype=np.uint16).view(np.float16)[0] == int(z[g, col])
         col0 += s_
         ts0 += (s_ // 16 + 7) // 8 * 8
-    # rotation coefficient words: [p][g][stage pair][lane]{cos | 4i, sin | 4j, cos | 4i, sin | 4j}
-    rot = torch.ops.paro.pack_rotation(_t(L["pairs"], dev), _t(L["theta"], dev)).cpu().numpy().view(np.uint32)
-    rot = rot.reshape(len(sizes), K // 128, 4, 64, 4)
-    # Each stage holds the same 64 (i, j, theta) rotations as the checkpoint -- possibly re-ordered over
-    # the lanes and re-oriented ((i, j, theta) == (j, i, -theta)) -- arranged so that within each 32-lane
-    # half all i are distinct mod 32 and all j are distinct mod 32 (bank-conflict-free LDS schedule).
-    # cos / sin are fp32 words whose low 9 bits carry 4 * channel: within 2^-15 relative of the true value.
-    for pp in range(len(sizes)):
-        for r in range(8):
-            wc, ws = rot[pp, g, r >> 1, :, 2 * (r & 1)], rot[pp, g, r >> 1, :, 2 * (r & 1) + 1]
-            i, j = (wc & 0x1ff) >> 2, (ws & 0x1ff) >> 2
-            assert not np.any(wc & 3) and not np.any(ws & 3)
-            c, sn = wc.view(np.float32).astype(np.float64), ws.view(np.float32).astype(np.float64)
-            got = {}
-            for a, b, cc, ss in zip(i.tolist(), j.tolist(), c.tolist(), sn.tolist()):
-                got[(a, b)] = (cc, ss)
-                got[(b, a)] = (cc, -ss)
-            pr = L["pairs"][pp, r, g * 128:(g + 1) * 128].astype(np.int64)
-            th = L["theta"][pp, r, g * 64:(g + 1) * 64].astype(np.float64)
-            for e in range(64):
-                cc, ss = got[(int(pr[2 * e]), int(pr[2 * e + 1]))]
-                assert abs(cc - np.cos(th[e])) <= 2.0 ** -15 * abs(np.cos(th[e])) + 1e-30
-                assert abs(ss - np.sin(th[e])) <= 2.0 ** -15 * abs(np.sin(th[e])) + 1e-30
-            assert sorted(np.concatenate([i, j]).tolist()) == list(range(128))
-            for h in (slice(0, 32), slice(32, 64)):
-                assert len(set((i[h] % 32).tolist())) == 32 and len(set((j[h] % 32).tolist())) == 32
+
+
+def _run_exchange_schedule(words, x, krot):
+    """Host model of the register exchange network the GEMV executes (gemv_impl.hpp `stage` / `finish`) on
+    one 128-channel group: words uint32 [768] from paro_pack_rotation, x float64 [128]."""
+    def coef(w):                                              # Q << 16 | P, signed 16-bit units of 2^-14
+        P = (w & 0xffff).astype(np.uint16).view(np.int16).astype(np.float64) / 16384.0
+        Q = (w >> 16).astype(np.uint16).view(np.int16).astype(np.float64) / 16384.0
+        return P, Q
+    ch = words.reshape(3, 64, 4)
+    A, B = x[0::2].copy(), x[1::2].copy()                     # lane l starts with channels 2l, 2l+1
+    for t in range(krot):
+        P, Q = coef(ch[t >> 2, :, t & 3])
+        assert np.all(np.abs(P * P + Q * Q - 1) < 2e-4)
+        src4 = (ch[2, :, t >> 2] >> (8 * (t & 3))) & 0xff
+        assert not np.any(src4 & 3) and sorted((src4 >> 2).tolist()) == list(range(64))   # a permutation of the lanes
+        keep, give = P * A + Q * B, P * B - Q * A
+        A, B = keep, give[src4 >> 2]                          # ds_bpermute: pull give' of lane src
+    P, Q = coef(ch[2, :, 2])
+    f = ch[2, :, 3]
+    sigma = np.where(f >> 31, -1.0, 1.0)
+    out = np.full(128, np.nan)
+    out[(f & 0xfe) >> 1] = P * A + Q * B
+    out[((f >> 8) & 0xfe) >> 1] = sigma * (P * B - Q * A)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("krot", [1, 2, 5, 8])
+def test_pack_rotation_schedule(dev, krot):
+    """The packed exchange schedule, run on the host, IS the rotation of the checkpoint (float64 oracle):
+    every lane fetches from a permutation of the lanes, every channel is written exactly once."""
+    K, P = 512, 2
+    rng = np.random.default_rng(100 + krot)
+    pairs = np.stack([po.random_pairs(rng, krot, K) for _ in range(P)])
+    theta = (rng.standard_normal((P, krot, K // 2)) * 0.7).astype(np.float16)
+    theta[0, 0, :8] = 0                                          # dummy pairs (angle 0, optim/rotation.py:53)
+    rot = torch.ops.paro.pack_rotation(_t(pairs, dev), _t(theta, dev)).cpu().numpy().view(np.uint32)
+    rot = rot.reshape(P, K // 128, 768)
+    x = rng.standard_normal(K)
+    for pp in range(P):
+        want = po.rotate(x[None], pairs[pp], theta[pp].astype(np.float64), None, 128, "ideal")[0]
+        for g in range(K // 128):
+            got = _run_exchange_schedule(rot[pp, g], x[g * 128:(g + 1) * 128], krot)
+            assert not np.isnan(got).any()                        # every channel written exactly once
+            np.testing.assert_allclose(got, want[g * 128:(g + 1) * 128], rtol=0, atol=4e-4)   # 16-bit coefficients: 1.5e-5 each
+    # repeated pairs in consecutive stages (lane keeps both members: fetches from itself) and the identity
+    pairs2 = np.repeat(pairs[:1, :1], krot, axis=1)
+    rot2 = torch.ops.paro.pack_rotation(_t(pairs2, dev), _t(theta[:1], dev)).cpu().numpy().view(np.uint32)
+    rot2 = rot2.reshape(1, K // 128, 768)
+    want = po.rotate(x[None], pairs2[0], theta[0].astype(np.float64), None, 128, "ideal")[0]
+    got = np.concatenate([_run_exchange_schedule(rot2[0, g], x[g * 128:(g + 1) * 128], krot) for g in range(K // 128)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-4)
+
+
+@pytest.mark.gpu
+def test_pack_rotation_rejects_illegal_pairs(dev):
+    """A stage that is not a perfect matching raises, like the reference's converter ("illegal pair",
+    optim/rotation.py:36-37)."""
+    rng = np.random.default_rng(5)
+    pairs = po.random_pairs(rng, 8, 256)[None]
+    theta = torch.zeros(1, 8, 128, dtype=torch.float16, device=dev)
+    for bad in ("dup", "self", "range"):
+        q = pairs.copy()
+        if bad == "dup":
+            q[0, 3, 130] = q[0, 3, 140]
+        elif bad == "self":
+            q[0, 7, 1] = q[0, 7, 0]
+        else:
+            q[0, 0, 5] = 128
+        with pytest.raises((RuntimeError, ValueError), match="illegal pair"):
+            torch.ops.paro.pack_rotation(_t(q, dev), theta)
 
 
 def test_repack_rejects_bad_shapes(dev):

@@ -45,7 +45,7 @@ def test_abi_validation_without_gpu(lib):
     assert lib.paro_packed_sz_bytes(4096, 3, sizes) == 32 * (256 + 64 + 64) * 16 * 4
     sizes2 = (ctypes.c_int32 * 2)(48, 16)      # 3 + 1 tiles -> padded to 8 + 8
     assert lib.paro_packed_sz_bytes(256, 2, sizes2) == 2 * 16 * 16 * 4
-    assert lib.paro_packed_rot_bytes(4096, 3) == 3 * 32 * 64 * 8 * 8
+    assert lib.paro_packed_rot_bytes(4096, 3) == 3 * 32 * 3072
 
 
 def test_ops_registered_with_reference_schema():

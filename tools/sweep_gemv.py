@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--mode", default="0")
     ap.add_argument("--order", type=int, default=-1, help="wq tile order: 0 [tile][group], 1 [group][tile], -1 auto")
     ap.add_argument("--only", default="", help="comma-separated linear names to run")
+    ap.add_argument("--share_rot", type=int, default=0, help="1: every weight copy uses copy 0's rotation schedule and "
+                    "channel scales (they stay cache resident): measures what the cold first touch of those small streams costs")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev)
@@ -48,6 +50,11 @@ def main():
         if args.only and name not in args.only.split(","):
             continue
         packs = [synth_packed(K, sizes, dev, gen, None if args.order < 0 else args.order) for _ in range(copies)]
+        if args.share_rot:
+            for pk in packs[1:]:
+                pk.rot, pk.channel_scales = packs[0].rot, packs[0].channel_scales
+                if args.share_rot >= 2:
+                    pk.sz = packs[0].sz
         x = torch.randn(args.rows, K, device=dev, dtype=torch.float16, generator=gen)
         graphs = {}
         G = K // 128

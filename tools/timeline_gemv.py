@@ -27,26 +27,25 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); ops.w4a16_gemv_tuned(x, packs[9], a.tpw, 1, a.waves, 0); e1.record(); torch.cuda.synchronize()
 ncb = sum((s // 16 + a.tpw - 1) // a.tpw for s in sizes)
 ws = packs[9].workspace
-W = 48   # 64-bit words per workgroup (gemv_impl.hpp, DIAG == 3)
+W = 80   # 64-bit words per workgroup (gemv_impl.hpp, DIAG == 3)
 raw = ws[nat.PARO_WS_COUNTER_BYTES:nat.PARO_WS_COUNTER_BYTES + ncb * W * 8].view(torch.int64).cpu().numpy().reshape(ncb, W)
 ws[nat.PARO_WS_COUNTER_BYTES:nat.PARO_WS_COUNTER_BYTES + ncb * W * 8].zero_()
-t = raw[:, :9].astype(np.float64)
+t = np.concatenate([raw[:, :9], raw[:, 10:11]], axis=1).astype(np.float64)
 # s_memtime counters are per XCD and not synchronised across XCDs: report each phase RELATIVE TO THE
 # WORKGROUP'S OWN START, in shader cycles (divide by the shader clock, ~2.1-2.4 GHz, for time).
 d = t - t[:, :1]
 names = ["wg_start", "loads_issued", "coeffs_arrived", "rotation_done", "tiles_consumed", "units_done(w0)",
-         "output_written", "all_waves_done", "partials_staged"]
-order = [0, 1, 2, 3, 4, 5, 7, 8, 6]
+         "output_written", "all_waves_done", "partials_staged", "stages_done"]
+order = [0, 1, 2, 9, 3, 4, 5, 7, 8, 6]
 print(f"{a.model} {name} tpw={a.tpw} waves={a.waves} workgroups={ncb}  kernel {e0.elapsed_time(e1)*1e3:.1f} us incl. launch"
       f" (wave 0 of each workgroup; shader cycles since its own start)")
 for k in order:
     col = d[:, k]
     print(f"  {names[k]:16s} mean {col.mean():8.0f}  p5 {np.percentile(col,5):8.0f}  p95 {np.percentile(col,95):8.0f}  max {col.max():8.0f}")
-wv = raw[:, 10:10 + 2 * a.waves].astype(np.float64).reshape(ncb, a.waves, 2) - t[:, :1, None]
-st, dn = wv[:, :, 0], wv[:, :, 1]
-print(f"  per-wave start  (rel. wave 0): mean of last-started wave {st.max(1).mean():6.0f}  max {st.max():6.0f}")
-print(f"  per-wave units_done: first {dn.min(1).mean():6.0f}  mean {dn.mean():6.0f}  last {dn.max(1).mean():6.0f}  (cycles since wg start)")
-print("  by wave index (mean start / mean done): " + " ".join(f"{st[:, w].mean():.0f}/{dn[:, w].mean():.0f}" for w in range(a.waves)))
+wv = raw[:, 16:16 + 4 * a.waves].astype(np.float64).reshape(ncb, a.waves, 4) - t[:, :1, None]
+print("  by wave index, mean cycles since workgroup start:  start / first coefficients arrived / first unit done / all units done")
+for w in range(a.waves):
+    print(f"    wave {w:2d}: " + " / ".join(f"{wv[:, w, k].mean():7.0f}" for k in range(4)))
 xcc = (raw[:, 9] >> 32) & 0xF
 hw = raw[:, 9] & 0xFFFFFFFF
 for xc in sorted(set(xcc.tolist()))[:2]:
