@@ -157,10 +157,15 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
     a.x = xrot;
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit);
-  if (L->act_dtype == PARO_DTYPE_F16)
-    rc = mode == 1 ? launch_gemv_f16_pre(a, tpw, wv, grid, st) : launch_gemv_f16(a, tpw, wv, grid, st);
-  else
-    rc = mode == 1 ? launch_gemv_bf16_pre(a, tpw, wv, grid, st) : launch_gemv_bf16(a, tpw, wv, grid, st);
+  typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
+  static const launch_fn table[2][2][4] = {
+      {{launch_gemv_f16_0_t1, launch_gemv_f16_0_t2, launch_gemv_f16_0_t4, launch_gemv_f16_0_t8},
+       {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, launch_gemv_f16_1_t4, launch_gemv_f16_1_t8}},
+      {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, launch_gemv_bf16_0_t4, launch_gemv_bf16_0_t8},
+       {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, launch_gemv_bf16_1_t4, launch_gemv_bf16_1_t8}}};
+  const int ti = tpw == 1 ? 0 : (tpw == 2 ? 1 : (tpw == 4 ? 2 : (tpw == 8 ? 3 : -1)));
+  if (ti < 0) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 1, 2, 4 or 8 (got %d)", tpw);
+  rc = table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode == 1 ? 1 : 0][ti](a, wv, grid, st);
   if (rc != PARO_OK) return rc;
   return check_launch("paro_w4a16_gemv");
 }

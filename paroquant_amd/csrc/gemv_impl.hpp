@@ -473,21 +473,16 @@ int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = 8 is not built for more than 8 batch rows");
 }
 
-template <typename AT, bool PREROT>
-int launch_gemv_variant(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st) {
-  switch (tpw) {
-    case 1: return launch_rows<AT, 1, PREROT>(a, waves, grid, st);
-    case 2: return launch_rows<AT, 2, PREROT>(a, waves, grid, st);
-    case 4: return launch_rows<AT, 4, PREROT>(a, waves, grid, st);
-    case 8: return launch_rows<AT, 8, PREROT>(a, waves, grid, st);
-  }
-  return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 1, 2, 4 or 8 (got %d)", tpw);
-}
-
-// defined in gemv_f16.hip / gemv_f16_pre.hip / gemv_bf16.hip / gemv_bf16_pre.hip
-int launch_gemv_f16(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
-int launch_gemv_f16_pre(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
-int launch_gemv_bf16(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
-int launch_gemv_bf16_pre(const GemvArgs& a, int tpw, int waves, dim3 grid, hipStream_t st);
+// defined in gemv_inst.hip, one object per (type, pre-rotated, tiles per wave)
+#define PARO_DECL_GEMV(T, P) \
+  int launch_gemv_##T##_##P##_t1(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_##P##_t2(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_##P##_t4(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_##P##_t8(const GemvArgs&, int, dim3, hipStream_t);
+PARO_DECL_GEMV(f16, 0)
+PARO_DECL_GEMV(f16, 1)
+PARO_DECL_GEMV(bf16, 0)
+PARO_DECL_GEMV(bf16, 1)
+#undef PARO_DECL_GEMV
 
 }  // namespace paro

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void pack_sz_kernel(const unsigned* __restrict
 }
 
 // Rotation parameters of one (partition, group) -> the EXCHANGE SCHEDULE the fused GEMV executes with the
-// rotation state in registers (one thread per (partition, group); stages depend on each other).
+// rotation state in registers (one workgroup per (partition, group); stages depend on each other).
 //
 // In the kernel lane l always holds BOTH members (A, B) of one pair of the current stage, so a stage is
 // four FMA-class ops on registers.  Between two stages every lane keeps one of its two channels and
@@ -91,46 +91,32 @@ __device__ __forceinline__ unsigned coef_word(double P, double Q) {
   return ((unsigned)qi << 16) | ((unsigned)pi & 0xffffu);
 }
 
+// One 64-lane workgroup per (partition, group): thread l plays lane l of the GEMV (its pair, its
+// coefficients); only the walk along the alternating cycles is serial (thread 0, 64 steps per stage).
 __global__ __launch_bounds__(64) void pack_rot_kernel(const int16_t* __restrict__ pairs,
                                                      const unsigned short* __restrict__ theta,
                                                      unsigned* __restrict__ out, int K, int nparts, int krot,
                                                      int* __restrict__ bad) {
-  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int G = K / 128;
-  if (gid >= (int64_t)nparts * G) return;
-  const int g = (int)(gid % G), p = (int)(gid / G);
-  unsigned* o = out + gid * 768;
-  for (int l = 0; l < 64; ++l) o[(128 + l) * 4] = o[(128 + l) * 4 + 1] = 0u;
+  const int g = (int)(blockIdx.x % G), p = (int)(blockIdx.x / G);
+  const int l = threadIdx.x;
+  unsigned* o = out + (int64_t)blockIdx.x * 768;
 
-  unsigned char chA[64], chB[64], lane_of[128], partner[128], pe_cur[128], pe_next[128], isi_cur[128], isi_next[128];
-  unsigned char keepA[64], src[64], seen[128], done[64];
-  signed char tau[128];
-  for (int l = 0; l < 64; ++l) {
-    chA[l] = (unsigned char)(2 * l);
-    chB[l] = (unsigned char)(2 * l + 1);
-  }
-  for (int c = 0; c < 128; ++c) {
-    tau[c] = 1;
-    pe_cur[c] = 0;
-    isi_cur[c] = 1;
-  }
+  __shared__ unsigned char chA[64], chB[64], lane_of[128], partner[128], pe_cur[128], pe_next[128], isi_cur[128],
+      isi_next[128], keepA[64], src[64], done[64];
+  __shared__ signed char tau[128];
+  __shared__ int seen[128];
+  __shared__ int invalid;
 
-  // checkpoint stage r of this (p, g): matching + roles
-  auto load_stage = [&](int r) -> bool {
-    const int16_t* pr = pairs + ((int64_t)p * krot + r) * K + g * 128;
-    for (int c = 0; c < 128; ++c) seen[c] = 0;
-    for (int e = 0; e < 64; ++e) {
-      const int i = pr[2 * e], j = pr[2 * e + 1];
-      if (i < 0 || i > 127 || j < 0 || j > 127 || i == j || seen[i & 127] || seen[j & 127]) return false;
-      seen[i] = seen[j] = 1;
-      partner[i] = (unsigned char)j;
-      partner[j] = (unsigned char)i;
-      pe_next[i] = pe_next[j] = (unsigned char)e;
-      isi_next[i] = 1;
-      isi_next[j] = 0;
-    }
-    return true;
-  };
+  chA[l] = (unsigned char)(2 * l);
+  chB[l] = (unsigned char)(2 * l + 1);
+  tau[2 * l] = tau[2 * l + 1] = 1;
+  pe_cur[2 * l] = pe_cur[2 * l + 1] = 0;
+  isi_cur[2 * l] = isi_cur[2 * l + 1] = 1;
+  if (l == 0) invalid = 0;
+  unsigned srcw[2] = {0u, 0u};
+  __syncthreads();
+
   // rotation matrix entries of the CURRENT stage for the lane holding (a, b):  x_a' = c x_a + m x_b,  x_b' = c x_b - m x_a
   auto coeffs = [&](int t, int a, double& c, double& m) {
     if (t == 0) {
@@ -146,70 +132,92 @@ __global__ __launch_bounds__(64) void pack_rot_kernel(const int16_t* __restrict_
   };
 
   for (int t = 0; t < krot; ++t) {     // 2-word stages: identity (t = 0) and checkpoint stages 0 .. krot-2
-    if (!load_stage(t)) {              // the matching the lanes must hold AFTER this stage
-      atomicOr(bad, 1);
-      return;
-    }
-    for (int l = 0; l < 64; ++l) {
+    // checkpoint stage t = the matching the lanes must hold AFTER this stage: thread l validates pair l
+    {
+      const int16_t* pr = pairs + ((int64_t)p * krot + t) * K + g * 128;
+      seen[2 * l] = seen[2 * l + 1] = 0;
+      __syncthreads();
+      const int i = pr[2 * l], j = pr[2 * l + 1];
+      const bool ok = i >= 0 && i <= 127 && j >= 0 && j <= 127 && i != j;
+      if (ok) {
+        atomicAdd(&seen[i], 1);
+        atomicAdd(&seen[j], 1);
+        partner[i] = (unsigned char)j;
+        partner[j] = (unsigned char)i;
+        pe_next[i] = pe_next[j] = (unsigned char)l;
+        isi_next[i] = 1;
+        isi_next[j] = 0;
+      } else {
+        invalid = 1;
+      }
+      __syncthreads();
+      if (seen[2 * l] != 1 || seen[2 * l + 1] != 1) invalid = 1;
       lane_of[chA[l]] = lane_of[chB[l]] = (unsigned char)l;
       done[l] = 0;
+      __syncthreads();
+      if (invalid) {
+        if (l == 0) atomicOr(bad, 1);
+        return;
+      }
     }
-    // walk the alternating cycles: lane l keeps channel k and receives partner[k] from the lane holding it,
+    // walk the alternating cycles: lane x keeps channel k and receives partner[k] from the lane holding it,
     // which therefore gives that channel away and keeps its other one
-    for (int l0 = 0; l0 < 64; ++l0) {
-      if (done[l0]) continue;
-      int l = l0, k = chA[l0];
-      do {
-        done[l] = 1;
-        keepA[l] = (unsigned char)(k == chA[l]);
-        const int want = partner[k];
-        const int l2 = lane_of[want];
-        src[l] = (unsigned char)l2;
-        k = (want == chA[l2]) ? chB[l2] : chA[l2];
-        l = l2;
-      } while (l != l0);
+    if (l == 0) {
+#pragma clang loop unroll(disable)
+      for (int l0 = 0; l0 < 64; ++l0) {
+        if (done[l0]) continue;
+        int x = l0, k = chA[l0];
+#pragma clang loop unroll(disable)
+        do {
+          done[x] = 1;
+          keepA[x] = (unsigned char)(k == chA[x]);
+          const int want = partner[k];
+          const int x2 = lane_of[want];
+          src[x] = (unsigned char)x2;
+          k = (want == chA[x2]) ? chB[x2] : chA[x2];
+          x = x2;
+        } while (x != l0);
+      }
     }
-    for (int l = 0; l < 64; ++l) {
-      const int a = chA[l], b = chB[l];
+    __syncthreads();
+    const int a = chA[l], b = chB[l];
+    {
       double c, m;
       coeffs(t, a, c, m);
       // keep = a:  x_a' =  c x_a + m x_b ;  keep = b:  x_b' = -m x_a + c x_b
       const double alpha = keepA[l] ? c : -m, beta = keepA[l] ? m : c;
       o[((t >> 2) * 64 + l) * 4 + (t & 3)] = coef_word(alpha * tau[a], beta * tau[b]);
-      o[(128 + l) * 4 + (t >> 2)] |= (4u * src[l]) << (8 * (t & 3));
+      srcw[t >> 2] |= (4u * src[l]) << (8 * (t & 3));
     }
-    // new signs (all lanes read the old ones above), then the new layout
-    signed char ntau[64];
-    for (int l = 0; l < 64; ++l) ntau[l] = (signed char)((keepA[l] ? 1 : -1) * tau[chA[l]] * tau[chB[l]]);
-    for (int l = 0; l < 64; ++l) {
-      const int k = keepA[l] ? chA[l] : chB[l], gv = keepA[l] ? chB[l] : chA[l];
-      tau[k] = 1;
-      tau[gv] = ntau[l];
-    }
-    for (int l = 0; l < 64; ++l) {
-      const int k = keepA[l] ? chA[l] : chB[l];
-      chA[l] = (unsigned char)k;
-      chB[l] = partner[k];
-    }
-    for (int c = 0; c < 128; ++c) {
-      pe_cur[c] = pe_next[c];
-      isi_cur[c] = isi_next[c];
-    }
+    // new signs and the new layout (every thread has read the old ones above)
+    const int k = keepA[l] ? a : b, gv = keepA[l] ? b : a;
+    const signed char ntau = (signed char)((keepA[l] ? 1 : -1) * tau[a] * tau[b]);
+    __syncthreads();
+    tau[k] = 1;
+    tau[gv] = ntau;
+    chA[l] = (unsigned char)k;
+    chB[l] = partner[k];
+    pe_cur[2 * l] = pe_next[2 * l];
+    pe_cur[2 * l + 1] = pe_next[2 * l + 1];
+    isi_cur[2 * l] = isi_next[2 * l];
+    isi_cur[2 * l + 1] = isi_next[2 * l + 1];
+    __syncthreads();
   }
   // unused stage slots (krot < 8): identity, never executed
-  for (int t = krot; t < 8; ++t)
-    for (int l = 0; l < 64; ++l) {
-      o[((t >> 2) * 64 + l) * 4 + (t & 3)] = coef_word(1.0, 0.0);
-      o[(128 + l) * 4 + (t >> 2)] |= (4u * l) << (8 * (t & 3));
-    }
+  for (int t = krot; t < 8; ++t) {
+    o[((t >> 2) * 64 + l) * 4 + (t & 3)] = coef_word(1.0, 0.0);
+    srcw[t >> 2] |= (4u * l) << (8 * (t & 3));
+  }
   // last checkpoint stage: out[a] = c ta A + m tb B,  out[b] = -m ta A + c tb B = sigma (P B - Q A), sigma = ta tb
-  for (int l = 0; l < 64; ++l) {
+  {
     const int a = chA[l], b = chB[l];
     double c, m;
     coeffs(krot, a, c, m);
-    unsigned* w = o + (128 + l) * 4 + 2;
-    w[0] = coef_word(c * tau[a], m * tau[b]);
-    w[1] = (2u * a) | ((2u * b) << 8) | ((tau[a] * tau[b] < 0) ? 0x80000000u : 0u);
+    unsigned* w = o + (128 + l) * 4;
+    w[0] = srcw[0];
+    w[1] = srcw[1];
+    w[2] = coef_word(c * tau[a], m * tau[b]);
+    w[3] = (2u * a) | ((2u * b) << 8) | ((tau[a] * tau[b] < 0) ? 0x80000000u : 0u);
   }
 }
 
@@ -293,7 +301,7 @@ extern "C" int paro_pack_rotation(const int16_t* pairs, const void* theta, int64
   if (hipMalloc((void**)&bad, sizeof(int)) != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipMalloc failed in paro_pack_rotation");
   (void)hipMemsetAsync(bad, 0, sizeof(int), st);
   const int64_t n = (int64_t)n_parts * (K / 128);
-  hipLaunchKernelGGL(pack_rot_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pairs,
+  hipLaunchKernelGGL(pack_rot_kernel, dim3((unsigned)n), dim3(64), 0, st, pairs,
                      (const unsigned short*)theta, (unsigned*)out_rot, (int)K, n_parts, krot, bad);
   int host_bad = 0;
   const hipError_t e1 = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
