@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase timeline of the fused GEMV (diagnostic build PARO_GEMV_PD=31): wave 0 of every
-workgroup records s_memtime at entry / loads issued / coefficients arrived / first rotation done /
-first unit's tiles consumed / all units done / output written.  Prints mean, p5 and p95 of every phase
-in microseconds relative to the earliest workgroup start.
+"""Per-workgroup / per-wave phase timeline of the fused GEMV.  Needs the diagnostic build
+(`make -C paroquant_amd/csrc clean all DIAG=1`) and PARO_GEMV_PD=31: wave 0 of every workgroup records
+s_memtime (shader clock) at entry / first loads issued / first coefficients arrived / stages done / fragments +
+sums done / first unit's tiles consumed / all units done / every wave done / partials staged / output
+written; every wave records its own start, first-coefficient arrival, first unit done, all units done.
+The stamps are data-dependent (asm with a VGPR input), so they cannot be scheduled above the waits they
+follow.  s_memtime is per XCD: only differences inside a workgroup are meaningful.
     PARO_GEMV_PD=31 python tools/timeline_gemv.py --model llama3-8b --linear o_proj --tpw 1 --waves 16"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
