@@ -95,8 +95,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (rows < 0 || rows > 16) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..16 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
-  if (tpw != 0 && tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8)
-    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto), 1, 2, 4 or 8 (got %d)", tpw);
+  if (tpw < 0 || tpw > 8)
+    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto) or 1..8 (got %d)", tpw);
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
@@ -107,7 +107,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (mode_auto && rows > 8) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && tpw > 4) tpw = 4;
-  if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
+  if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
+  if (tpw == 8 && wv == 16 && (rows > 1 || mode == 1)) wv = 8;   // 16 waves x 8 tiles: built for the fused batch-1 mode only (128 VGPRs)
   const int G = (int)(L->K / 128);
   hipStream_t st = (hipStream_t)stream;
 
@@ -158,14 +159,17 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit);
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
-  static const launch_fn table[2][2][4] = {
-      {{launch_gemv_f16_0_t1, launch_gemv_f16_0_t2, launch_gemv_f16_0_t4, launch_gemv_f16_0_t8},
-       {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, launch_gemv_f16_1_t4, launch_gemv_f16_1_t8}},
-      {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, launch_gemv_bf16_0_t4, launch_gemv_bf16_0_t8},
-       {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, launch_gemv_bf16_1_t4, launch_gemv_bf16_1_t8}}};
-  const int ti = tpw == 1 ? 0 : (tpw == 2 ? 1 : (tpw == 4 ? 2 : (tpw == 8 ? 3 : -1)));
-  if (ti < 0) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 1, 2, 4 or 8 (got %d)", tpw);
-  rc = table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode == 1 ? 1 : 0][ti](a, wv, grid, st);
+  // [type][pre-rotated][tiles per wave - 1]; 3, 5, 6, 7 tiles exist for the fused mode only
+  static const launch_fn table[2][2][8] = {
+      {{launch_gemv_f16_0_t1, launch_gemv_f16_0_t2, launch_gemv_f16_0_t3, launch_gemv_f16_0_t4, launch_gemv_f16_0_t5,
+        launch_gemv_f16_0_t6, launch_gemv_f16_0_t7, launch_gemv_f16_0_t8},
+       {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, nullptr, launch_gemv_f16_1_t4, nullptr, nullptr, nullptr, launch_gemv_f16_1_t8}},
+      {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, launch_gemv_bf16_0_t3, launch_gemv_bf16_0_t4, launch_gemv_bf16_0_t5,
+        launch_gemv_bf16_0_t6, launch_gemv_bf16_0_t7, launch_gemv_bf16_0_t8},
+       {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, nullptr, launch_gemv_bf16_1_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_1_t8}}};
+  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode == 1 ? 1 : 0][tpw - 1] : nullptr;
+  if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
+  rc = fn(a, wv, grid, st);
   if (rc != PARO_OK) return rc;
   return check_launch("paro_w4a16_gemv");
 }

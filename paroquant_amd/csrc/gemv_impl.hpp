@@ -72,7 +72,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int WORK_BYTES = WAVES * XH_BYTES;
   constexpr int EX_BYTES = (PD / 10 == 6) ? WAVES * 256 : 0;   // diagnostic exchange slots
   constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16;
-  constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;  // 16-byte scale/zero vectors per unit
+  // scale/zero words of a unit: one aligned vector load per 4 tiles when TPW is a power of two, else one
+  // dword load per tile (TPW = 3, 5, 6, 7 exist so that wide outputs can be cut into ~256 column blocks)
+  constexpr bool SZ_VEC = TPW == 1 || TPW == 2 || TPW == 4 || TPW == 8;
+  constexpr int NSZ = TPW <= 4 ? 1 : TPW / 4;
   constexpr int SZW = TPW < 4 ? TPW : 4;
   typedef unsigned SZV __attribute__((ext_vector_type(SZW)));
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   };
   struct TBuf {
     u32x4 q[TPW];
-    SZV sz[NSZ];
+    unsigned szw[TPW];
   };
 
   const unsigned short* xrot_p = a.x + (PREROT ? (int64_t)p * a.rows * a.K : 0);
@@ -177,9 +180,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       const int jj = j < nt ? j : nt - 1;
       b.q[j] = __builtin_nontemporal_load(a.wq + ((int64_t)(tile0 + jj) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
     }
-    const unsigned* sp = a.sz + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
+    if constexpr (SZ_VEC) {
+      const unsigned* sp = a.sz + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
 #pragma unroll
-    for (int v = 0; v < NSZ; ++v) b.sz[v] = *(const SZV*)(sp + v * 64);
+      for (int v = 0; v < NSZ; ++v) {
+        const SZV q = *(const SZV*)(sp + v * 64);
+#pragma unroll
+        for (int e = 0; e < SZW; ++e) b.szw[v * 4 + e] = q[e];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int ts = ts0 + (j < nt ? j : nt - 1);
+        b.szw[j] = a.sz[(int64_t)g * szrow + ((int64_t)(ts >> 2) * 16 + n) * 4 + (ts & 3)];
+      }
+    }
   };
 
   // ---- rotation pieces (state in REGISTERS: lane l holds both members (A, B) of one pair of the stage)
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
         }
       }
-      const unsigned szw = t.sz[j / 4][j % 4];
+      const unsigned szw = t.szw[j];
       const float s = f16_bits_to_f32(szw & 0xffffu);
       const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
@@ -331,11 +346,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         __builtin_amdgcn_wave_barrier();
         frags_from_lds(xh, af);
       }
-      if constexpr (PFT) load_t(tn, gt);
+      // 8 tiles x 16 waves: no second tile buffer (128-VGPR budget); the next unit's tiles are requested
+      // into the same registers right after this unit's are consumed and land during its rotation, with
+      // four waves per SIMD covering for each other
+      constexpr bool SINGLE_T = TPW == 8 && WAVES == 16;
+      if constexpr (PFT && !SINGLE_T) load_t(tn, gt);
       consume(af, tc);
       if constexpr (DIAG == 3) { if (ts[4] == 0) ts[4] = stamp_after(acc[0][0]); }
       if constexpr (PFP) pc = pn;
-      if constexpr (PFT) tc = tn;
+      if constexpr (PFT && !SINGLE_T) tc = tn;
+      if constexpr (PFT && SINGLE_T) load_t(tc, gt);
     };
     const std::true_type yes{};
     const std::false_type no{};
@@ -429,9 +449,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 }
 
 // ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
+constexpr bool tpw_is_pow2(int t) { return t == 1 || t == 2 || t == 4 || t == 8; }
+
 template <typename AT, int TPW, int MB, bool PREROT, int PD>
 int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if constexpr (MB <= 4 && TPW <= 4) {
+  if constexpr (tpw_is_pow2(TPW) && (TPW < 8 ? MB <= 4 : (MB == 1 && !PREROT))) {
     if (waves == 16) {
       hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
       return PARO_OK;
@@ -441,11 +463,13 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 8, PREROT, PD>), grid, dim3(512), 0, st, a);
     return PARO_OK;
   }
-  if (waves == 4) {
-    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT, PD>), grid, dim3(256), 0, st, a);
-    return PARO_OK;
+  if constexpr (tpw_is_pow2(TPW)) {
+    if (waves == 4) {
+      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT, PD>), grid, dim3(256), 0, st, a);
+      return PARO_OK;
+    }
   }
-  return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d batch rows", waves, MB);
+  return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d tiles per wave x %d batch rows", waves, TPW, MB);
 }
 
 template <typename AT, int TPW, int MB, bool PREROT>
@@ -468,9 +492,11 @@ template <typename AT, int TPW, bool PREROT>
 int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if (a.rows <= 1) return launch_waves<AT, TPW, 1, PREROT>(a, waves, grid, st);
   if (a.rows <= 4) return launch_waves<AT, TPW, 4, PREROT>(a, waves, grid, st);
-  if (a.rows <= 8) return launch_waves<AT, TPW, 8, PREROT>(a, waves, grid, st);
-  if constexpr (TPW <= 4) return launch_waves<AT, TPW, 16, PREROT>(a, waves, grid, st);
-  return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = 8 is not built for more than 8 batch rows");
+  if constexpr (tpw_is_pow2(TPW)) {
+    if (a.rows <= 8) return launch_waves<AT, TPW, 8, PREROT>(a, waves, grid, st);
+    if constexpr (TPW <= 4) return launch_waves<AT, TPW, 16, PREROT>(a, waves, grid, st);
+  }
+  return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for %d batch rows", TPW, a.rows);
 }
 
 // defined in gemv_inst.hip, one object per (type, pre-rotated, tiles per wave)
@@ -479,10 +505,18 @@ int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   int launch_gemv_##T##_##P##_t2(const GemvArgs&, int, dim3, hipStream_t); \
   int launch_gemv_##T##_##P##_t4(const GemvArgs&, int, dim3, hipStream_t); \
   int launch_gemv_##T##_##P##_t8(const GemvArgs&, int, dim3, hipStream_t);
+#define PARO_DECL_GEMV_ODD(T) \
+  int launch_gemv_##T##_0_t3(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_0_t5(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_0_t6(const GemvArgs&, int, dim3, hipStream_t); \
+  int launch_gemv_##T##_0_t7(const GemvArgs&, int, dim3, hipStream_t);
 PARO_DECL_GEMV(f16, 0)
 PARO_DECL_GEMV(f16, 1)
 PARO_DECL_GEMV(bf16, 0)
 PARO_DECL_GEMV(bf16, 1)
+PARO_DECL_GEMV_ODD(f16)
+PARO_DECL_GEMV_ODD(bf16)
 #undef PARO_DECL_GEMV
+#undef PARO_DECL_GEMV_ODD
 
 }  // namespace paro
