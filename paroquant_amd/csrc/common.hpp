@@ -121,14 +121,25 @@ struct Act<f16> {
   }
   // Cheaper unpack for the VALU-bound GEMV: no shift for the nibbles that already sit on mantissa
   // bits 0..3 (| 1024.0h -> 1024 + q) and 4..7 (| 64.0h -> 64 + q); one shift brings the other two
-  // pairs there.  5 VALU per word instead of 8; the per-element offsets (1024, 64, 1024, 64 per
+  // pairs there.  5 VALU per word (1 shift + 4 v_and_or_b32); the per-element offsets (1024, 64, 1024, 64 per
   // register) are removed with one extra MFMA against kOffFrag:  sum_k x_k off_k.
-  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4]) {
+  // The masks / magic numbers as OPAQUE register values (laundered once per kernel through an empty asm):
+  // gfx9 VOP3 takes no literals, so with compile-time constants the compiler emits v_and + v_or; with
+  // register operands it selects v_and_or_b32 -- 5 VALU per word instead of 9.
+  struct Unpack {
+    unsigned m0, m1, k0, k1;
+  };
+  __device__ static __forceinline__ Unpack unpack_consts() {
+    Unpack u = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
+    asm volatile("" : "+s"(u.m0), "+s"(u.m1), "+v"(u.k0), "+v"(u.k1));
+    return u;
+  }
+  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4], const Unpack& u) {
     const unsigned t = w >> 8;
-    o[0] = (w & 0x000F000Fu) | 0x64006400u;
-    o[1] = (w & 0x00F000F0u) | 0x54005400u;
-    o[2] = (t & 0x000F000Fu) | 0x64006400u;
-    o[3] = (t & 0x00F000F0u) | 0x54005400u;
+    o[0] = (w & u.m0) | u.k0;
+    o[1] = (w & u.m1) | u.k1;
+    o[2] = (t & u.m0) | u.k0;
+    o[3] = (t & u.m1) | u.k1;
   }
   static constexpr unsigned kOffFrag0 = 0x64006400u, kOffFrag1 = 0x54005400u;  // registers 0/2 and 1/3
   __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
@@ -152,12 +163,20 @@ struct Act<bf16> {
     o[3] = ((w >> 9) & kMask) | kMagic;
   }
   // bf16 has 7 mantissa bits: only bits 0..3 can hold a nibble without touching the exponent
-  // (| 128.0 -> 128 + q, exact in 8 significant bits); uniform offset 128, 7 VALU per word.
-  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4]) {
-    o[0] = (w & 0x000F000Fu) | 0x43004300u;
-    o[1] = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
-    o[2] = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
-    o[3] = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+  // (| 128.0 -> 128 + q, exact in 8 significant bits); uniform offset 128, 7 VALU per word (v_and_or_b32).
+  struct Unpack {
+    unsigned m0, k0;
+  };
+  __device__ static __forceinline__ Unpack unpack_consts() {
+    Unpack u = {0x000F000Fu, 0x43004300u};
+    asm volatile("" : "+s"(u.m0), "+v"(u.k0));
+    return u;
+  }
+  __device__ static __forceinline__ void unpack_fast(unsigned w, unsigned (&o)[4], const Unpack& u) {
+    o[0] = (w & u.m0) | u.k0;
+    o[1] = ((w >> 4) & u.m0) | u.k0;
+    o[2] = ((w >> 8) & u.m0) | u.k0;
+    o[3] = ((w >> 12) & u.m0) | u.k0;
   }
   static constexpr unsigned kOffFrag0 = 0x43004300u, kOffFrag1 = 0x43004300u;
   __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {

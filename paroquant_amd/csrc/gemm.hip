@@ -238,6 +238,7 @@ __global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a
     szn = *(const u32x4*)(szp + (int64_t)g * szrow);
   };
 
+  const A::Unpack upk = A::unpack_consts();
   f32x4 acc[8][4];
 #pragma unroll
   for (int rt = 0; rt < 8; ++rt)
@@ -276,24 +277,63 @@ __global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a
         c_hi[j] = (f16x2){ch, ch};
         c_lo[j] = (f16x2){cl, cl};
       }
+      // The group's body in explicit issue order.  Left to the compiler it comes out as [13 dequant VALU]
+      // [8 MFMA] clusters, and the PMC profile of that version showed VALU-active (37 %) and MFMA-busy
+      // (40 %) time simply adding up: an in-order wave only overlaps the two pipes if independent VALU sit
+      // BETWEEN its MFMAs.  So each of the 8 MFMAs of tile (i, j) is followed by a slice of the dequant of
+      // the NEXT tile's word (13 VALU over 7 slots) and, in the last tile of a k-step, by the ds_read of
+      // the fragment that MFMA just used, for the next k-step; sched_barrier(0) pins every slot.
+      struct DQ {
+        unsigned t, o0, o1, o2, o3;
+        f16x2 a0, a1, a2, a3;
+        u32x4 out;
+      };
+      auto dq_part = [&](int r, DQ& d, unsigned w, int j) {
+        if (r == 0) {
+          d.t = w >> 8;
+          d.o0 = (w & upk.m0) | upk.k0;
+        } else if (r == 1) {
+          d.o1 = (w & upk.m1) | upk.k1;
+          d.o2 = (d.t & upk.m0) | upk.k0;
+        } else if (r == 2) {
+          d.o3 = (d.t & upk.m1) | upk.k1;
+          d.a0 = __builtin_bit_cast(f16x2, d.o0) + c_hi[j];
+        } else if (r == 3) {
+          d.out[0] = __builtin_bit_cast(unsigned, d.a0 * s2[j]);
+          d.a1 = __builtin_bit_cast(f16x2, d.o1) + c_lo[j];
+        } else if (r == 4) {
+          d.out[1] = __builtin_bit_cast(unsigned, d.a1 * s2[j]);
+          d.a2 = __builtin_bit_cast(f16x2, d.o2) + c_hi[j];
+        } else if (r == 5) {
+          d.out[2] = __builtin_bit_cast(unsigned, d.a2 * s2[j]);
+          d.a3 = __builtin_bit_cast(f16x2, d.o3) + c_lo[j];
+        } else if (r == 6) {
+          d.out[3] = __builtin_bit_cast(unsigned, d.a3 * s2[j]);
+        }
+      };
+      vec8 af[8];
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) af[rt] = *(const vec8*)(abuf + aoff[0] + rt * 4096);
+      DQ d;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) dq_part(r, d, qc[0][0], 0);
+      u32x4 bcur = d.out;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        vec8 af[8];
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) af[rt] = *(const vec8*)(abuf + aoff[i] + rt * 4096);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          unsigned w4[4];
-          A::unpack_fast(qc[j][i], w4);
-          f16x2 h0 = (__builtin_bit_cast(f16x2, w4[0]) + c_hi[j]) * s2[j];
-          f16x2 h1 = (__builtin_bit_cast(f16x2, w4[1]) + c_lo[j]) * s2[j];
-          f16x2 h2 = (__builtin_bit_cast(f16x2, w4[2]) + c_hi[j]) * s2[j];
-          f16x2 h3 = (__builtin_bit_cast(f16x2, w4[3]) + c_lo[j]) * s2[j];
-          const u32x4 wv = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1),
-                            __builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
-          const vec8 bf = __builtin_bit_cast(vec8, wv);
+          const bool has_next = !(i == 3 && j == 3);
+          const int jn = (j + 1) & 3, in = j == 3 ? i + 1 : i;
+          const vec8 bf = __builtin_bit_cast(vec8, bcur);
 #pragma unroll
-          for (int rt = 0; rt < 8; ++rt) acc[rt][j] = A::mfma(af[rt], bf, acc[rt][j]);
+          for (int rt = 0; rt < 8; ++rt) {
+            acc[rt][j] = A::mfma(af[rt], bf, acc[rt][j]);
+            if (has_next) dq_part(rt, d, qc[jn][in & 3], jn);
+            if (j == 3 && i < 3) af[rt] = *(const vec8*)(abuf + aoff[i + 1] + rt * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (has_next) bcur = d.out;
         }
       }
     }

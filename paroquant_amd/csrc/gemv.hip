@@ -102,9 +102,12 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (mode_auto) mode = 0;
   if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
   if (L->krot > 8) mode = 1;  // the packed-coefficient fast path holds 8 stages
-  // > 8 batch rows: rotating 16 rows inside every workgroup costs more LDS time than the weights take to
-  // stream (measured: gate_up M=16 fused 61 us vs 31 us with the pre-pass), so rotate once up front
-  if (mode_auto && rows > 8) mode = 1;
+  // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
+  // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
+  // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:
+  // M=4 o 8.1/12.4 qkv 10.0/13.1; M=6 o 10.5/12.5 down 17.3/17.5 but qkv 15.2/13.5 gate_up 22.0/20.9;
+  // M=16 gate_up 53/24).
+  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1))) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && tpw > 4) tpw = 4;
   if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only

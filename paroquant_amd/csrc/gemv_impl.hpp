@@ -268,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   };
 
   // ---- consume one unit's tiles: fragments from LDS (or registers), sums, unpack -> MFMA -> scale / zero
+  const typename A::Unpack upk = A::unpack_consts();
   auto consume = [&](const vec8 (&af)[4], const TBuf& t) {
     // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in)
     f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           unsigned w4[4];
-          A::unpack_fast(t.q[j][i], w4);
+          A::unpack_fast(t.q[j][i], w4, upk);
           const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
           d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
         }

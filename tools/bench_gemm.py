@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Prefill-path microbench: fused linear at large M (rotate pre-pass + W4A16 MFMA GEMM), reporting
-TFLOP/s (2*M*K*N) and the split between the rotate pre-pass and the GEMM kernel.
+TFLOP/s (2*M*K*N).  `ms_rotate_prepass` times the STAGE kernel (torch.ops.rotation.rotate per partition)
+as a stand-alone reference; the fused linear itself uses the dense MFMA pre-pass, which is faster, so
+`TFLOPs_gemm_only` is an upper estimate -- use rocprofv3 --kernel-trace for the real split.
     python tools/bench_gemm.py [--model llama3-8b] [--rows 8192] [--reps 5]"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
