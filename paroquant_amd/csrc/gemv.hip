@@ -38,21 +38,17 @@ constexpr int kMaxKsplit = 16;
 void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, int& waves) {
   // Measured on MI355X (tools/sweep_gemv.py; Llama-3-8B, Qwen3-4B, Qwen3-0.6B shapes, M = 1):
   //   * every workgroup rotates all the groups it covers, so the total rotation work is
-  //     (#column blocks) x K/128 group rotations (~100 LDS cycles each): wide outputs want few, fat
-  //     column blocks (tpw 8), narrow outputs are launch/latency bound and want one or two tiles;
-  //   * the in-launch K-split (data-tagged granules) costs one round trip to the coherence point
-  //     (~1.5-2 us): it pays for deep-K / narrow-N layers (down_proj: tpw 4 x ksplit 4), where it
-  //     also cuts the per-workgroup rotation chain, and marginally for K >= 4096 with <= 320 tiles.
+  //     (#column blocks) x K/128 group rotations (VALU issue + 3 KiB of schedule through the CU's L1 each):
+  //     wide outputs want few, fat column blocks (tpw 8), narrow outputs want the rotation cut by a K-split;
+  //   * the in-launch K-split (data-tagged granules) costs one round trip to the coherence point: it pays
+  //     for narrow-N layers with K >= 4096 (o_proj, down_proj: tpw 4 x ksplit 4 -- o_proj 6.3 -> 6.0 us,
+  //     Qwen3-4B o_proj 6.2 -> 5.6 over tpw 2 x ksplit 2).
   const int G = (int)(L->K / 128);
   const int64_t tiles = L->N / 16;
   const bool auto_tpw = tpw <= 0, auto_ks = ksplit <= 0, auto_wv = waves <= 0;
   const bool narrow = tiles <= 320;
-  if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {
-    if (G >= 64) {          // down_proj class
-      tpw = 4; ksplit = 4; waves = 8;
-    } else {                // o_proj class
-      tpw = 2; ksplit = 2; waves = 8;
-    }
+  if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj / down_proj class
+    tpw = 4; ksplit = 4; waves = 8;
   }
   if (tpw <= 0) {
     if (tiles >= 1024)
@@ -64,7 +60,7 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   }
   if (ksplit <= 0) ksplit = 1;
   if (waves <= 0) {
-    if (rows > 4 || tpw > 2 || G < 24)
+    if (rows > 4 || tpw > 2 || G < 16)
       waves = G >= 8 ? 8 : 4;
     else
       waves = 16;
@@ -135,8 +131,6 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (!fill_part_table(a.pt, L->n_parts, L->part_cols, tpw)) return fail(PARO_ERR_INVALID, "bad partition table");
   a.slabs = nullptr;
   a.counters = nullptr;
-  static const int env_flags = getenv("PARO_GEMV_FLAGS") ? atoi(getenv("PARO_GEMV_FLAGS")) : 0;
-  a.flags = env_flags;
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
 

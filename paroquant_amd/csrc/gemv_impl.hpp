@@ -47,7 +47,6 @@ struct GemvArgs {
   unsigned* counters;
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
-  int flags;                             // debug (PARO_GEMV_FLAGS): 16 = return at kernel entry (launch floor)
   int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
   PartTable pt;
 };
@@ -317,7 +316,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // all of a wave's 2..4 units rotated together with interleaved stage chains and every load issued up
     // front -- the rotation then is VALU-issue bound (7 issue slots per unit and stage, replicated in every
     // workgroup), not latency bound, so overlapping the chains buys nothing; a workgroup barrier between
-    // the coefficient and the tile requests.  See DESIGN.md "what did not work".)
+    // the coefficient and the tile requests; the first tiles requested only once the first coefficients
+    // have arrived.  See DESIGN.md, "where the time goes".)
     PBuf pc, pn;
     TBuf tc, tn;
     // PFP: request the NEXT unit's coefficients before this unit's rotation; PFT: request the next
