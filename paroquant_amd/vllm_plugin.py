@@ -69,54 +69,56 @@ except Exception:  # ImportError or a broken install
 
     GroupQuantScaleParameter = PackedvLLMParameter = None
 
-_SHARD_INDEX = {"q": 0, "k": 1, "v": 2}          # plugin.py:28
-_SUPPORTED_BITS = (4,)                           # plugin.py:29
+_QKV_SLOT = {"q": 0, "k": 1, "v": 2}              # slot of a fused-QKV shard id (reference plugin.py:28)
+_SUPPORTED_BITS = (4,)
 
 
 def _tp_rank() -> int:
     if HAVE_VLLM:  # pragma: no cover
         from vllm.distributed import get_tensor_model_parallel_rank
         return get_tensor_model_parallel_rank()
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return torch.distributed.get_rank()
-    return 0
+    dist = torch.distributed
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def _maybe_shard_input(target: torch.Tensor, loaded_weight: torch.Tensor, tp_rank: Optional[int] = None) -> torch.Tensor:
-    """Slice ``loaded_weight`` along its last (input) dim if the param is sharded for TP.
+    """The slice of a checkpoint rotation tensor that belongs in ``target``.
 
-    Rotation params live along the linear layer's input dim: row-parallel layers allocate them with
-    ``input_size_per_partition`` while the checkpoint holds the full width (plugin.py:33-50)."""
-    if target.shape[-1] == loaded_weight.shape[-1]:
+    Rotation parameters run along the linear's INPUT dimension.  A row-parallel layer allocates them
+    ``input_size_per_partition`` wide while the checkpoint stores the full width, so rank r takes columns
+    ``[r * w, (r + 1) * w)`` (the rotation is block diagonal per 128-channel group, which makes the slice
+    self-contained).  Same contract as the reference loader, plugin.py:33-50."""
+    have, want = loaded_weight.shape[-1], target.shape[-1]
+    if have == want:
         return loaded_weight
-    if loaded_weight.shape[-1] % target.shape[-1] != 0:
-        raise ValueError(
-            f"ParoQuant rotation loader: incompatible shapes "
-            f"target={tuple(target.shape)} loaded={tuple(loaded_weight.shape)}"
-        )
-    rank = _tp_rank() if tp_rank is None else tp_rank
-    shard = target.shape[-1]
-    return loaded_weight.narrow(-1, rank * shard, shard)
+    n_shards, rest = divmod(have, want)
+    if rest:
+        raise ValueError(f"ParoQuant rotation loader: incompatible shapes target={tuple(target.shape)} "
+                         f"loaded={tuple(loaded_weight.shape)}")
+    rank = _tp_rank() if tp_rank is None else int(tp_rank)
+    if not 0 <= rank < n_shards:
+        raise ValueError(f"ParoQuant rotation loader: tp rank {rank} outside the {n_shards} input shards")
+    return loaded_weight.narrow(-1, rank * want, want)
+
+
+def _partition_slots(shard_id) -> tuple:
+    """Partition indices addressed by a vLLM shard id: ``"q"/"k"/"v"`` (fused QKV), an int (gate/up and
+    other merged projections) or a tuple of those (one checkpoint tensor feeding several partitions)."""
+    ids = shard_id if isinstance(shard_id, tuple) else (shard_id,)
+    return tuple(_QKV_SLOT.get(i, i) if isinstance(i, str) else i for i in ids)
 
 
 def _rotation_weight_loader(param: Parameter, loaded_weight: torch.Tensor,
                             loaded_shard_id: int | str | tuple | None = None) -> None:
-    """Load per-projection rotation params into the partitioned param tensor (plugin.py:53-76).
-
-      None         -> single projection, copy directly
-      "q"/"k"/"v"  -> QKV merge, partition index 0/1/2
-      int          -> gate/up merge, partition index
-      tuple        -> fused projections, copy to each index
-    """
-    if loaded_shard_id is None:
-        target = param.data[0] if param.data.dim() > loaded_weight.dim() else param.data
-        target.copy_(_maybe_shard_input(target, loaded_weight))
-        return
-    indices = (loaded_shard_id if isinstance(loaded_shard_id, tuple)
-               else (_SHARD_INDEX.get(loaded_shard_id, loaded_shard_id),))
-    for idx in indices:
-        target = param.data[idx]
-        target.copy_(_maybe_shard_input(target, loaded_weight))
+    """``weight_loader`` of the ``theta`` / ``pairs`` / ``channel_scales`` parameters, which carry one
+    leading slot per merged partition (reference dispatch: plugin.py:53-76)."""
+    store = param.data
+    if loaded_shard_id is None:   # un-merged projection: the only slot (or a slot-less tensor)
+        slots = [store[0] if store.dim() > loaded_weight.dim() else store]
+    else:
+        slots = [store[i] for i in _partition_slots(loaded_shard_id)]
+    for slot in slots:
+        slot.copy_(_maybe_shard_input(slot, loaded_weight))
 
 
 @register_quantization_config("paroquant")
@@ -127,13 +129,9 @@ class ParoQuantConfig(QuantizationConfig):
         super().__init__()
         if bits not in _SUPPORTED_BITS:
             raise ValueError(f"Unsupported bits={bits}. Supported: {list(_SUPPORTED_BITS)}")
-        self.bits = bits
-        self.group_size = group_size
-        self.krot = krot
-        self.pack_factor = 32 // bits
-        # We rely on the existence of `qweight` etc. to determine the skipped layers.
-        self.modules_to_not_convert = None
-        self.zero_point = zero_point
+        self.bits, self.group_size, self.krot, self.zero_point = bits, group_size, krot, zero_point
+        self.pack_factor = 32 // bits            # INT4 columns per int32 word of qweight / qzeros
+        self.modules_to_not_convert = None       # filled from the checkpoint header (maybe_update_config)
 
     def __repr__(self) -> str:
         return (f"ParoQuantConfig(bits={self.bits}, group_size={self.group_size}, krot={self.krot}, "
@@ -166,19 +164,21 @@ class ParoQuantConfig(QuantizationConfig):
 
     @staticmethod
     def unquantized_modules_from_metadata(metadata: dict) -> list[str]:
-        """Pure part of ``maybe_update_config`` (plugin.py:123-151): leaf modules whose tensors are
-        all fp16/bf16/fp32 in the safetensors metadata are left unquantised."""
-        unquant = {"F16", "BF16", "F32"}
-        leaf_modules = {k.rsplit(".", 1)[0] for k in metadata if k.endswith(".weight")}
-        quant_modules = {k.rsplit(".", 1)[0] for k, info in metadata.items()
-                         if (dt := info.get("dtype")) and dt not in unquant}
+        """Which modules vLLM must NOT quantise, judged from the safetensors header alone (the pure part
+        of the reference's ``maybe_update_config``, plugin.py:123-151): a module owning a ``.weight`` whose
+        tensors are all plain floating point.  Names are reported the way vLLM prefixes layers -- without
+        the leading ``model.`` and, inside the decoder stack, from ``layers.`` on."""
+        float_dtypes = ("F16", "BF16", "F32")
+        owner = lambda key: key.rpartition(".")[0]
+        with_weight = {owner(k) for k in metadata if k.endswith(".weight")}
+        non_float = {owner(k) for k, info in metadata.items() if info.get("dtype") and info["dtype"] not in float_dtypes}
 
-        def _strip(name: str) -> str:
-            name = name.removeprefix("model.")
-            i = name.find("layers.")
-            return name[i:] if i >= 0 else name
+        def vllm_name(module: str) -> str:
+            module = module[len("model."):] if module.startswith("model.") else module
+            at = module.find("layers.")
+            return module if at < 0 else module[at:]
 
-        return sorted(_strip(k) for k in leaf_modules - quant_modules)
+        return sorted(vllm_name(m) for m in with_weight - non_float)
 
     def maybe_update_config(self, model_name: str, revision: str | None = None):
         """Auto-detect unquantized layers from safetensors metadata."""
