@@ -163,7 +163,7 @@ int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
 /* Decode / small-batch path (rows <= 16): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in 1..8 (3, 5, 6, 7: fused mode, <= 4 rows, 8 waves);
- * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows; with 8 tiles: batch 1 only).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
+ * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
  * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above). */
 int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);

@@ -108,7 +108,7 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && tpw > 4) tpw = 4;
   if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
-  if (tpw == 8 && wv == 16 && (rows > 1 || mode == 1)) wv = 8;   // 16 waves x 8 tiles: built for the fused batch-1 mode only (128 VGPRs)
+  if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
   const int G = (int)(L->K / 128);
   hipStream_t st = (hipStream_t)stream;
 

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int g0 = g_begin + wave;
   {
     // One unit at a time, distance-1 software pipeline.
-    // (Tried and measured equal or slower, MI355X, every Llama-3-8B / Qwen3-4B shape: deeper prefetch;
+    // (Tried and measured equal or slower, MI355X, every Llama-3-8B / Qwen3-4B shape: deeper prefetch
+    // (tiles two units ahead: gate_up 14.5 -> 16.1 us; coefficients two ahead; both);
     // all of a wave's 2..4 units rotated together with interleaved stage chains and every load issued up
     // front -- the rotation then is VALU-issue bound (7 issue slots per unit and stage, replicated in every
     // workgroup), not latency bound, so overlapping the chains buys nothing; a workgroup barrier between
@@ -347,16 +348,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         __builtin_amdgcn_wave_barrier();
         frags_from_lds(xh, af);
       }
-      // 8 tiles x 16 waves: no second tile buffer (128-VGPR budget); the next unit's tiles are requested
-      // into the same registers right after this unit's are consumed and land during its rotation, with
-      // four waves per SIMD covering for each other
-      constexpr bool SINGLE_T = TPW == 8 && WAVES == 16;
-      if constexpr (PFT && !SINGLE_T) load_t(tn, gt);
+      if constexpr (PFT) load_t(tn, gt);
       consume(af, tc);
       if constexpr (DIAG == 3) { if (ts[4] == 0) ts[4] = stamp_after(acc[0][0]); }
       if constexpr (PFP) pc = pn;
-      if constexpr (PFT && !SINGLE_T) tc = tn;
-      if constexpr (PFT && SINGLE_T) load_t(tc, gt);
+      if constexpr (PFT) tc = tn;
     };
     const std::true_type yes{};
     const std::false_type no{};
@@ -369,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     load_t(tc, gf);
     if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
     for (int g = gf; g + WAVES < g_end; g += WAVES) step(yes, yes, g + WAVES, g + WAVES);
-    step(no, no, 0, 0);
+    step(no, no, 0, 0);   // the last unit: nothing left to request
     if (!has_work) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
@@ -454,7 +450,7 @@ constexpr bool tpw_is_pow2(int t) { return t == 1 || t == 2 || t == 4 || t == 8;
 
 template <typename AT, int TPW, int MB, bool PREROT, int PD>
 int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if constexpr (tpw_is_pow2(TPW) && (TPW < 8 ? MB <= 4 : (MB == 1 && !PREROT))) {
+  if constexpr (tpw_is_pow2(TPW) && TPW < 8 && MB <= 4) {   // 8 tiles x 16 waves does not fit 128 VGPRs
     if (waves == 16) {
       hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
       return PARO_OK;

@@ -283,7 +283,7 @@ def test_gemv_launch_shapes_agree(dev, tpw, ksplit, waves, mode):
     pk = _packed(L, dev, L["bias"])
     for rows in (1, 4, 6, 13):
         odd = tpw in (3, 5, 6, 7)
-        if (rows > 4 and waves == 16) or (rows > 8 and tpw == 8) or (tpw == 8 and waves == 16 and (rows > 1 or mode == 1)) \
+        if (rows > 4 and waves == 16) or (rows > 8 and tpw == 8) or (tpw == 8 and waves == 16) \
                 or (odd and (waves not in (0, 8) or rows > 4 or mode == 1)):
             continue   # combinations that are not built (see launch tables in gemv_impl.hpp)
         x = rng.standard_normal((rows, K)).astype(np.float16)

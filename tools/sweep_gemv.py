@@ -60,7 +60,7 @@ def main():
         G = K // 128
         import itertools
         for tpw, ksp, wv, mode in itertools.product(tpws, ksps, wvs, modes):
-            if ksp > max(1, G // 2) or (tpw == 8 and wv == 16 and args.rows > 1) or (args.rows > 4 and wv == 16) \
+            if ksp > max(1, G // 2) or (tpw == 8 and wv == 16) or (args.rows > 4 and wv == 16) \
                     or (tpw in (3, 5, 6, 7) and (wv != 8 or args.rows > 4)):
                 continue
 
