@@ -31,6 +31,8 @@ struct GemmArgs {
   unsigned short* y;
   int K, N, G, rows;
   int tstride, gstride;        // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
+  int ksplit, gps;             // K-split (grid.z) of the v2 kernel: groups per split; 1 = none
+  float* partial;              // [ksplit][rows][N] fp32 partial sums when ksplit > 1
   PartTable pt;                // column blocks of BN_TILES tiles
 };
 
@@ -252,20 +254,23 @@ __global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a
 #pragma unroll
   for (int i = 0; i < 4; ++i) aoff[i] = abase + (((4 * i + mq) ^ mrow) << 4);
 
+  // K-split (small M: too few output tiles to fill the chip): this workgroup covers groups [g0, g1)
+  const int ks = blockIdx.z;
+  const int g0 = ks * a.gps, g1 = min(a.G, g0 + a.gps);
   {
-    issue_a(0, 0);
-    load_b(0);
-    for (int g = 0; g < a.G; ++g) {
+    issue_a(g0, 0);
+    load_b(g0);
+    for (int g = g0; g < g1; ++g) {
       u32x4 qc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) qc[j] = qn[j];
       const u32x4 szc = szn;
-      __syncthreads();  // A(g) has landed (the barrier drains the LDS-DMA), everyone left buffer (g+1)&1
-      if (g + 1 < a.G) {
-        issue_a(g + 1, (g + 1) & 1);
+      __syncthreads();  // A(g) has landed (the barrier drains the LDS-DMA), everyone left the other buffer
+      if (g + 1 < g1) {
+        issue_a(g + 1, (g + 1 - g0) & 1);
         load_b(g + 1);
       }
-      const unsigned char* abuf = lds + (g & 1) * (BM2 * 256);
+      const unsigned char* abuf = lds + ((g - g0) & 1) * (BM2 * 256);
       // per-(tile, group) dequant constants as packed halves
       f16x2 s2[4], c_hi[4], c_lo[4];
 #pragma unroll
@@ -344,18 +349,59 @@ __global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a
   for (int j = 0; j < 4; ++j) {
     if (j < nt) {
       const int col = (tile0 + j) * 16 + n;
-      const float bv = a.bias ? A::to_f32(a.bias[col]) : 0.f;
+      const float bv = (a.bias && a.ksplit == 1) ? A::to_f32(a.bias[col]) : 0.f;
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = row0 + wr * 128 + rt * 16 + 4 * mq + r;
-          if (row < a.rows) a.y[(int64_t)row * a.N + col] = A::from_f32(acc[rt][j][r] + bv);
+          if (row < a.rows) {
+            if (a.ksplit == 1)
+              a.y[(int64_t)row * a.N + col] = A::from_f32(acc[rt][j][r] + bv);
+            else
+              a.partial[((int64_t)ks * a.rows + row) * a.N + col] = acc[rt][j][r];   // summed by gemm_reduce_kernel
+          }
         }
     }
   }
 }
 
+// y = fp16(sum over K-splits of the fp32 partial tiles + bias); 4 columns per thread
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ partial,
+                                                         const unsigned short* __restrict__ bias,
+                                                         unsigned short* __restrict__ y, int64_t rows, int N, int ksplit) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index of a group of 4 columns
+  const int64_t total4 = rows * N / 4;
+  if (i4 >= total4) return;
+  f32x4 v = *(const f32x4*)(partial + i4 * 4);
+  for (int s = 1; s < ksplit; ++s) v += *(const f32x4*)(partial + (int64_t)s * rows * N + i4 * 4);
+  const int col = (int)((i4 * 4) % N);
+  u32x2 o;
+  unsigned short h[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = Act<f16>::from_f32(v[e] + (bias ? Act<f16>::to_f32(bias[col + e]) : 0.f));
+  o[0] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+  o[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+  *(u32x2*)(y + i4 * 4) = o;
+}
+
+}  // namespace paro
+
+namespace paro {
+// K-split of the v2 GEMM for small M: with one 256-row block the grid is only N / 128 workgroups (32 for
+// N = 4096), each looping over all of K (o_proj, M = 32..128: 70 us); splitting K over grid.z and summing
+// fp32 partial tiles in a second small kernel fills the chip.  Used for 17 <= rows < 512 when the grid is
+// below half of the CUs; at most 8 splits of at least 2 groups.
+int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
+  if (L->act_dtype != PARO_DTYPE_F16 || rows <= 16 || rows >= 512) return 1;
+  const int64_t wgs = ((L->N + 127) / 128) * ((rows + 255) / 256);
+  if (wgs >= 128) return 1;
+  const int G = (int)(L->K / 128);
+  int ks = (int)(256 / wgs);
+  if (ks > 8) ks = 8;
+  if (ks > G / 2) ks = G / 2;
+  return ks < 1 ? 1 : ks;
+}
 }  // namespace paro
 
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
@@ -366,7 +412,9 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 0x7fffffff) return fail(PARO_ERR_INVALID, "rows out of range");
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
-  const int64_t need = PARO_WS_COUNTER_BYTES + (int64_t)L->n_parts * rows * L->K * 2;
+  const int ksplit_req = gemm_ksplit(L, rows);
+  const int64_t xrot_bytes = (int64_t)L->n_parts * rows * L->K * 2;
+  const int64_t need = PARO_WS_COUNTER_BYTES + xrot_bytes + (ksplit_req > 1 ? 256 + (int64_t)ksplit_req * rows * L->N * 4 : 0);
   if (!workspace || workspace_bytes < need)
     return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -393,7 +441,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   // vs 560-810 for the 4-wave 256 x 128 tile); 128..255 rows -> 256 x 128; fewer (and bf16) -> v1 kernel.
   // PARO_GEMM_VERSION = 1 | 2 | 3 forces one of them (A/B runs).
   static const int env_v = getenv("PARO_GEMM_VERSION") ? atoi(getenv("PARO_GEMM_VERSION")) : 0;
-  const bool v2 = L->act_dtype == PARO_DTYPE_F16 && env_v != 1 && rows >= 128;
+  const bool v2 = L->act_dtype == PARO_DTYPE_F16 && env_v != 1 && rows > 16;
   // the wide tile needs enough workgroups to cover the 256 CUs (narrow N x moderate M does not)
   const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
   const bool v2wide = v2 && (env_v == 3 || (env_v == 0 && rows >= 256 && wide_wgs >= 192));
@@ -401,11 +449,25 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   const int bm = v2 ? BM2 : BM;
   const int64_t rb = (rows + bm - 1) / bm;
   if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * bm);
-  dim3 grid((unsigned)a.pt.cbs, (unsigned)rb);
+  a.ksplit = 1;
+  a.gps = a.G;
+  a.partial = nullptr;
+  if (v2 && !v2wide && ksplit_req > 1) {
+    a.gps = (a.G + ksplit_req - 1) / ksplit_req;
+    a.ksplit = (a.G + a.gps - 1) / a.gps;   // drop empty splits
+    a.partial = (float*)((char*)workspace + PARO_WS_COUNTER_BYTES + ((xrot_bytes + 255) / 256) * 256);
+  }
+  dim3 grid((unsigned)a.pt.cbs, (unsigned)rb, (unsigned)a.ksplit);
   if (v2wide)
     hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);
-  else if (v2)
+  else if (v2) {
     hipLaunchKernelGGL(gemm2_f16_kernel<2>, grid, dim3(256), 0, st, a);
+    if (a.ksplit > 1) {
+      const int64_t total4 = rows * L->N / 4;
+      hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a.partial,
+                         (const unsigned short*)L->bias, (unsigned short*)y, rows, (int)L->N, a.ksplit);
+    }
+  }
   else if (L->act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
   else

@@ -5,6 +5,7 @@
 
 namespace paro {
 
+int gemm_ksplit(const paro_linear_t* L, int64_t rows);   // gemm.hip
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
                   int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 
@@ -79,7 +80,9 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   const int64_t r = rows < 1 ? 1 : rows;
   const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
   const int64_t slabs = r <= 16 ? (int64_t)kMaxKsplit * r * L->N * 8 : 0;  // 8-byte {tag, partial} granules
-  return PARO_WS_COUNTER_BYTES + slabs + xrot;
+  const int gks = gemm_ksplit(L, r);                                      // fp32 partial tiles of the small-M GEMM
+  const int64_t partial = gks > 1 ? 256 + (int64_t)gks * r * L->N * 4 : 0;
+  return PARO_WS_COUNTER_BYTES + slabs + xrot + partial;
 }
 
 extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,

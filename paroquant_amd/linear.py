@@ -107,10 +107,10 @@ class PackedParoWeights:
         if b is not None and b.dtype != x.dtype:
             b = b.to(x.dtype)
         rows = x.numel() // self.K
-        if rows >= 128 and x.dtype == torch.bfloat16:
-            # prefill with bf16 activations: gfx950 has no packed bf16 VALU for the in-register dequant, so run
-            # the fp16 kernels (fp16 carries 3 more mantissa bits than bf16; values beyond the fp16 range are
-            # saturated) and hand the result back in bf16 -- 2x the throughput of the native bf16 GEMM.
+        if rows > 16 and x.dtype == torch.bfloat16:
+            # more than 16 rows with bf16 activations: gfx950 has no packed bf16 VALU for the in-register
+            # dequant, so run the fp16 GEMM (fp16 carries 3 more mantissa bits than bf16; values beyond the fp16
+            # range are saturated) and hand the result back in bf16 -- 2x the throughput of the native bf16 GEMM.
             y = self.apply(x.clamp(-65504.0, 65504.0).to(torch.float16), None if b is None else b.to(torch.float16))
             return y.to(torch.bfloat16)
         rmat = self.rotation_matrices(x.dtype) if rows >= 256 else None
