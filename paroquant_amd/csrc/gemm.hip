@@ -218,9 +218,14 @@ __global__ __launch_bounds__(WCOLS * 128) void gemm2_f16_kernel(const GemmArgs a
     const int grow = min(row0 + row, a.rows - 1);  // tail rows re-read the last valid row (never stored)
     asrc[c] = xp + (int64_t)grow * a.K + ((sphys ^ (row & 15)) << 3);
   }
+  // small M: rows beyond a.rows are not staged (a 256-row tile at M = 32 would spend 7/8 of its LDS-DMA
+  // traffic -- x_rot re-read by every column block -- on copies of the last row); the MFMAs still run on
+  // whatever those LDS rows hold, their results are never stored
+  const int rows_here = min(BM2, a.rows - row0);
   auto issue_a = [&](int g, int buf) {
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
+      if ((wave * CPW + c) * 4 >= rows_here) continue;   // wave-uniform
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[c] + g * 128),
                                        (__attribute__((address_space(3))) void*)(lds + buf * (BM2 * 256) + (wave * CPW + c) * 1024),
                                        16, 0, 0);
