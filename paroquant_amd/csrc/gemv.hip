@@ -79,7 +79,8 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
   const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
-  const int64_t slabs = r <= 16 ? (int64_t)kMaxKsplit * r * L->N * 8 : 0;  // 8-byte {tag, partial} granules
+  // 8-byte {tag, partial} granules of the GEMV K-split (17..32 rows may run as two 16-row GEMV passes)
+  const int64_t slabs = r <= 32 ? (int64_t)kMaxKsplit * (r < 16 ? r : 16) * L->N * 8 : 0;
   const int gks = gemm_ksplit(L, r);                                      // fp32 partial tiles of the small-M GEMM
   const int64_t partial = gks > 1 ? 256 + (int64_t)gks * r * L->N * 4 : 0;
   return PARO_WS_COUNTER_BYTES + slabs + xrot + partial;
