@@ -160,7 +160,7 @@ typedef struct paro_linear {
 #define PARO_WS_COUNTER_BYTES 16384
 int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
 
-/* Decode / small-batch path (rows <= 16): one launch; x is rotated per
+/* Decode / small-batch path (rows <= 64; above 16 rows always with the rotate pre-pass): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in 1..8 (3, 5, 6, 7: fused mode, <= 4 rows, 8 waves);
  * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into

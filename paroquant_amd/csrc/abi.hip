@@ -18,15 +18,13 @@ extern "C" const char* paro_last_error(void) { return paro::error_buffer(); }
 extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   if (rows <= 16) return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, -1, stream);
-  // 17..32 rows on a wide output (>= 1024 column tiles): two passes of the 16-row GEMV beat the MFMA kernel,
-  // whose per-group cost does not shrink with M (measured, gate_up 4096 -> 28672: M = 32 50 vs 80 us; for
-  // the narrow shapes the K-split GEMM wins: o_proj 27 vs 34 us)
-  if (rows <= 32 && L && L->N / 16 >= 1024 && L->act_dtype == PARO_DTYPE_F16) {
-    const int64_t esz = 2;
-    int rc = paro_w4a16_gemv(L, x, y, 16, workspace, workspace_bytes, 0, 0, 0, -1, stream);
-    if (rc != PARO_OK) return rc;
-    return paro_w4a16_gemv(L, (const char*)x + 16 * L->K * esz, (char*)y + 16 * L->N * esz, rows - 16, workspace,
-                           workspace_bytes, 0, 0, 0, -1, stream);
-  }
+  // 17..64 rows: the GEMV kernel on pre-rotated activations with 2 / 4 MFMA row tiles per weight fragment
+  // (measured, Llama-3-8B shapes, us GEMV / K-split MFMA GEMM: M=32 qkv 20 / 32, o 19 / 27, gate_up 37 / 74,
+  // down 28 / 45; M=64 qkv 30 / 35, o 22 / 30, down 45 / 47, but gate_up 85 / 76: with four row tiles only
+  // two column tiles fit a wave, and every workgroup re-reads all of x_rot -- wide outputs above 32 rows stay
+  // on the GEMM).  PARO_SKINNY=0 routes everything above 16 rows to the GEMM (A/B runs).
+  static const int skinny = getenv("PARO_SKINNY") ? atoi(getenv("PARO_SKINNY")) : 1;
+  if (skinny && rows <= 64 && L && L->act_dtype == PARO_DTYPE_F16 && !(rows > 32 && L->N / 16 >= 1024))
+    return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 1, stream);
   return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, stream);
 }

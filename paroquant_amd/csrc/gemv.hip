@@ -46,6 +46,22 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   //     Qwen3-4B o_proj 6.2 -> 5.6 over tpw 2 x ksplit 2).
   const int G = (int)(L->K / 128);
   const int64_t tiles = L->N / 16;
+  if (rows > 16) {
+    // 17..64 rows (pre-rotated activations, 2 / 4 MFMA row tiles per weight fragment): every workgroup reads
+    // all of x_rot, so few, fat column blocks -- as many tiles per wave as the accumulators allow -- and a
+    // K-split only to reach ~256 workgroups on narrow outputs
+    const int cap = rows <= 32 ? 4 : 2;
+    if (tpw <= 0 || tpw > cap) tpw = cap;
+    if (waves <= 0 || waves > 8) waves = 8;
+    if (ksplit <= 0) {
+      const int64_t cbs = (tiles + tpw - 1) / tpw;
+      ksplit = (int)(256 / (cbs > 0 ? cbs : 1));
+      if (ksplit > 4) ksplit = 4;
+      if (ksplit > G / 8) ksplit = G / 8;
+      if (ksplit < 1) ksplit = 1;
+    }
+    return;
+  }
   const bool auto_tpw = tpw <= 0, auto_ks = ksplit <= 0, auto_wv = waves <= 0;
   const bool narrow = tiles <= 320;
   if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj / down_proj class
@@ -79,8 +95,17 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
   const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
-  // 8-byte {tag, partial} granules of the GEMV K-split (17..32 rows may run as two 16-row GEMV passes)
-  const int64_t slabs = r <= 32 ? (int64_t)kMaxKsplit * (r < 16 ? r : 16) * L->N * 8 : 0;
+  // 8-byte {tag, partial} granules of the GEMV K-split: any split up to kMaxKsplit for <= 16 rows (the
+  // launch-shape knobs are the caller's), the automatic one for 17..64 rows
+  int64_t slabs = 0;
+  if (r <= 16) {
+    slabs = (int64_t)kMaxKsplit * r * L->N * 8;
+  } else if (r <= 64) {
+    int tpw = 0, ks = 0, wv = 0;
+    gemv_autotune(L, r, tpw, ks, wv);
+    slabs = (int64_t)(ks > 1 ? ks : 1) * r * L->N * 8;
+    if (slabs < (int64_t)kMaxKsplit * 16 * L->N * 8) slabs = (int64_t)kMaxKsplit * 16 * L->N * 8;   // two 16-row passes
+  }
   const int gks = gemm_ksplit(L, r);                                      // fp32 partial tiles of the small-M GEMM
   const int64_t partial = gks > 1 ? 256 + (int64_t)gks * r * L->N * 4 : 0;
   return PARO_WS_COUNTER_BYTES + slabs + xrot + partial;
@@ -93,7 +118,7 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
-  if (rows < 0 || rows > 16) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..16 rows (got %lld)", (long long)rows);
+  if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
   if (tpw < 0 || tpw > 8)
@@ -102,7 +127,7 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
   if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
-  if (L->krot > 8) mode = 1;  // the packed-coefficient fast path holds 8 stages
+  if (L->krot > 8 || rows > 16) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
   // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
   // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
   // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:

@@ -62,12 +62,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
-  constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile
+  constexpr int MR = MB <= 4 ? 1 : (MB <= 8 ? 2 : 4);  // accumulator registers kept per tile and MFMA row tile
+  constexpr int RT = MB <= 16 ? 1 : MB / 16;            // MFMA row tiles: 32 / 64 batch rows, pre-rotated mode only
+  constexpr int MRT = MR * RT;
+  static_assert(RT == 1 || PREROT, "more than 16 batch rows run on pre-rotated activations");
   // LDS: per wave only the fragment-row block (MB rows + one zero row) that transposes the rotated
   // slice into MFMA A-fragment order; the rotation state itself lives in registers.
   constexpr int XH_HALVES = PREROT ? 0 : (((MB + 1) * kXhStride + 7) / 8) * 8;
   constexpr int XH_BYTES = XH_HALVES * 2;
-  constexpr int RED_FLOATS = WAVES * TPW * MR * 64;
+  constexpr int RED_FLOATS = WAVES * TPW * MRT * 64;
   constexpr int WORK_BYTES = WAVES * XH_BYTES;
   constexpr int EX_BYTES = (PD / 10 == 6) ? WAVES * 256 : 0;   // diagnostic exchange slots
   constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16;
@@ -130,17 +133,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int brow = (mrow >> 2) * MR + (mrow & 3);
   const bool avalid = ((mrow & 3) < MR) && (brow < a.rows);
 
-  float acc[TPW][MR];
+  float acc[TPW][MRT];   // [tile][row tile * MR + r]
 #pragma unroll
   for (int j = 0; j < TPW; ++j)
 #pragma unroll
-    for (int r = 0; r < MR; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < MRT; ++r) acc[j][r] = 0.f;
 
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
-    u32x4 xa[PREROT ? 4 : 1];
+    u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
   };
   struct TBuf {
     u32x4 q[TPW];
@@ -153,10 +156,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   auto load_p = [&](PBuf& b, int g) {
     if constexpr (PREROT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        b.xa[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (avalid) b.xa[i] = *(const u32x4*)(xrot_p + (int64_t)brow * a.K + g * 128 + 32 * i + 8 * mq);
-      }
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = rt * 16 + brow;
+          b.xa[rt * 4 + i] = (u32x4){0u, 0u, 0u, 0u};
+          if (((mrow & 3) < MR) && row < a.rows)
+            b.xa[rt * 4 + i] = *(const u32x4*)(xrot_p + (int64_t)row * a.K + g * 128 + 32 * i + 8 * mq);
+        }
     } else {
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
       const u32x4* rp = (const u32x4*)a.rot + ((int64_t)p * a.G + g) * 192 + lane;
@@ -268,42 +275,54 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   // ---- consume one unit's tiles: fragments from LDS (or registers), sums, unpack -> MFMA -> scale / zero
   const typename A::Unpack upk = A::unpack_consts();
-  auto consume = [&](const vec8 (&af)[4], const TBuf& t) {
-    // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in)
-    f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
+  auto consume = [&](const vec8 (&af)[4 * RT], const TBuf& t) {
+    // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in), per row tile
+    f32x4 sx[RT], so[RT];
     {
       const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
       const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
       const vec8 ob = __builtin_bit_cast(vec8, ones);
       const vec8 fb = __builtin_bit_cast(vec8, offs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        sx = A::mfma(af[i], ob, sx);
-        so = A::mfma(af[i], fb, so);
+      for (int rt = 0; rt < RT; ++rt) {
+        sx[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        so[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          sx[rt] = A::mfma(af[rt * 4 + i], ob, sx[rt]);
+          so[rt] = A::mfma(af[rt * 4 + i], fb, so[rt]);
+        }
       }
     }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      f32x4 d[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) d[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if constexpr (DIAG == 2) {
-        d[0] = __builtin_bit_cast(float, (t.q[j][0] ^ t.q[j][1] ^ t.q[j][2] ^ t.q[j][3]) & 0x3fffffffu);
+        d[0][0] = __builtin_bit_cast(float, (t.q[j][0] ^ t.q[j][1] ^ t.q[j][2] ^ t.q[j][3]) & 0x3fffffffu);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           unsigned w4[4];
-          A::unpack_fast(t.q[j][i], w4, upk);
+          A::unpack_fast(t.q[j][i], w4, upk);      // one unpack feeds every row tile
           const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
-          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+          const vec8 bfrag = __builtin_bit_cast(vec8, wv);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) d[rt] = A::mfma(af[rt * 4 + i], bfrag, d[rt]);
         }
       }
       const unsigned szw = t.szw[j];
       const float s = f16_bits_to_f32(szw & 0xffffu);
       const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
-      for (int r = 0; r < MR; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[r], d[r] - so[r]), acc[j][r]);
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+          acc[j][rt * MR + r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][r], d[rt][r] - so[rt][r]), acc[j][rt * MR + r]);
     }
   };
-  auto frags_from_lds = [&](const unsigned short* xs, vec8 (&af)[4]) {
+  auto frags_from_lds = [&](const unsigned short* xs, vec8 (&af)[4 * RT]) {
     const unsigned short* afrag = xs + (avalid ? brow : MB) * kXhStride + 8 * mq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
@@ -328,10 +347,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       constexpr bool PFP = decltype(pfp_tag)::value;
       constexpr bool PFT = decltype(pft_tag)::value;
       if constexpr (PFP) load_p(pn, gp);
-      vec8 af[4];
+      vec8 af[4 * RT];
       if constexpr (PREROT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
+        for (int i = 0; i < 4 * RT; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
       } else {
         float sa[MB], sb[MB];
         seed(pc, sa, sb);
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
 #pragma unroll
-        for (int r = 0; r < MR; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < MRT; ++r) acc[j][r] = 0.f;
     }
   }
 
@@ -382,18 +401,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
   for (int j = 0; j < TPW; ++j)
 #pragma unroll
-    for (int r = 0; r < MR; ++r) red[((wave * TPW + j) * MR + r) * 64 + lane] = acc[j][r];
+    for (int r = 0; r < MRT; ++r) red[((wave * TPW + j) * MRT + r) * 64 + lane] = acc[j][r];
   __syncthreads();
   if constexpr (DIAG == 3) ts[8] = __builtin_amdgcn_s_memtime();   // partials staged
 
   const bool direct = (a.ksplit == 1);
-  for (int e = tid; e < TPW * MR * 64; e += WAVES * 64) {
-    const int el = e & 63, r = (e >> 6) % MR, j = e / (MR * 64);
-    const int b = (el >> 4) * MR + r;
+  for (int e = tid; e < TPW * MRT * 64; e += WAVES * 64) {
+    const int el = e & 63, q = (e >> 6) % MRT, j = e / (MRT * 64);
+    const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);   // row tile * 16 + row inside the tile
     if (j >= nt || b >= a.rows) continue;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MR * 64];
+    for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MRT * 64];
     const int col = (tile0 + j) * 16 + (el & 15);
     if (direct) {
       if (a.bias) v += A::to_f32(a.bias[col]);
@@ -491,7 +510,15 @@ int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if (a.rows <= 4) return launch_waves<AT, TPW, 4, PREROT>(a, waves, grid, st);
   if constexpr (tpw_is_pow2(TPW)) {
     if (a.rows <= 8) return launch_waves<AT, TPW, 8, PREROT>(a, waves, grid, st);
-    if constexpr (TPW <= 4) return launch_waves<AT, TPW, 16, PREROT>(a, waves, grid, st);
+    if constexpr (TPW <= 4) {
+      if (a.rows <= 16) return launch_waves<AT, TPW, 16, PREROT>(a, waves, grid, st);
+      if constexpr (PREROT) {   // 17..64 rows: 2 / 4 MFMA row tiles per weight fragment, pre-rotated activations only
+        if (a.rows <= 32) return launch_waves<AT, TPW, 32, PREROT>(a, waves, grid, st);
+        if constexpr (TPW <= 2) {
+          if (a.rows <= 64) return launch_waves<AT, TPW, 64, PREROT>(a, waves, grid, st);
+        }
+      }
+    }
   }
   return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for %d batch rows", TPW, a.rows);
 }

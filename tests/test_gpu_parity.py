@@ -362,7 +362,7 @@ def test_gemv_hip_graph_capture(dev):
 @pytest.mark.parametrize("K,sizes,rows", [
     (512, [256], 17), (1024, [2048, 1024, 1024], 130), (4096, [4096], 256), (2560, [9728, 9728], 64),
     (256, [48, 16], 300), (9728, [2560], 129),
-    (256, [8192, 8192], 24), (128, [16384], 32),     # 17..32 rows on a wide output: two passes of the 16-row GEMV
+    (256, [8192, 8192], 24), (128, [16384], 32), (2048, [512, 272], 40), (4096, [1024], 64), (1024, [48], 33),   # 17..64 rows: GEMV with 2 / 4 MFMA row tiles
 ])
 def test_gemm_matches_oracle(dev, K, sizes, rows):
     L = po.make_layer(K + rows, K, sizes, bias=True)
