@@ -206,6 +206,9 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
             channel_scales=rng.uniform(0.5, 2.0, size=(P, 1, K)).astype(np.float16), sizes=sizes, K=K))
     xs = [rng.standard_normal((1, l["K"])).astype(np.float16) for l in layers]
     pc.load()
+    # one socket's worth of physical cores at most: on the 2 x 64-core / 256-thread MI355X host the default
+    # 128-thread team is 1.4-8x slower and erratic (oversubscribed SMT siblings, cross-socket traffic)
+    pc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
     times = []
     t_start = time.perf_counter()
     while True:

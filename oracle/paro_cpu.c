@@ -90,6 +90,17 @@ int paro_cpu_threads(void) {
 #endif
 }
 
+/* Cap the OpenMP team (bench.py's cpu_baseline: one socket's physical cores -- measured on the 2 x 64-core
+ * MI355X host: 64 threads 2.4 / 4.1 ms per layer (Qwen3-4B / Llama-3-8B), 128 threads 3.4 / 32 ms and
+ * erratic from run to run). */
+void paro_cpu_set_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int paro_cpu_has_f16c(void) {
 #ifdef __F16C__
   return 1;

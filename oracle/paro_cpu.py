@@ -37,6 +37,8 @@ def load():
     lib = ctypes.CDLL(path)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.paro_cpu_threads.restype = i32
+    lib.paro_cpu_set_threads.restype = None
+    lib.paro_cpu_set_threads.argtypes = [i32]
     lib.paro_cpu_has_f16c.restype = i32
     lib.paro_cpu_rotate_f16.restype = None
     lib.paro_cpu_rotate_f16.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32]
@@ -52,6 +54,11 @@ def _p(a):
 
 def threads() -> int:
     return int(load().paro_cpu_threads())
+
+
+def set_threads(n: int) -> None:
+    """Cap the OpenMP team of the C port (the CPU-baseline leg of bench.py)."""
+    load().paro_cpu_set_threads(int(n))
 
 
 def rotate_f16(x, idx_ij, theta, scales=None, group_size: int = 128) -> np.ndarray:
