@@ -150,13 +150,14 @@ namespace paro {
 template <typename AT>
 __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* __restrict__ x,
                                                          unsigned short* __restrict__ out,
-                                                         const unsigned short* __restrict__ rmat, int rows, int K) {
+                                                         const unsigned short* __restrict__ rmat, int rows, int K,
+                                                         int nparts) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * 256, g = blockIdx.y, p = blockIdx.z;
+  const int row0 = blockIdx.x * 256, g = blockIdx.y;
   const int G = K >> 7;
   const int n = lane & 15, mq = lane >> 4;
 
@@ -181,32 +182,36 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
   }
   __syncthreads();  // the tile is now free: it becomes the output staging buffer
 
-  const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;  // [n][k], k contiguous
+  // every merged partition from the SAME staged activations (qkv: x is read once, not three times)
+  for (int p = 0; p < nparts; ++p) {
+    const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;  // [n][k], k contiguous
 #pragma unroll 2
-  for (int ct = 0; ct < 8; ++ct) {
-    vec8 bf[4];
+    for (int ct = 0; ct < 8; ++ct) {
+      vec8 bf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bf[i] = *(const vec8*)(rp + (ct * 16 + n) * 128 + 32 * i + 8 * mq);
+      for (int i = 0; i < 4; ++i) bf[i] = *(const vec8*)(rp + (ct * 16 + n) * 128 + 32 * i + 8 * mq);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < 4; ++rt) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[i], d);
-      // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major 256 B)
+        for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[i], d);
+        // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major 256 B)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wave * 64 + rt * 16 + 4 * mq + r;
-        *(unsigned short*)(lds + row * 256 + (ct * 16 + n) * 2) = A::from_f32(d[r]);
+        for (int r = 0; r < 4; ++r) {
+          const int row = wave * 64 + rt * 16 + 4 * mq + r;
+          *(unsigned short*)(lds + row * 256 + (ct * 16 + n) * 2) = A::from_f32(d[r]);
+        }
       }
     }
-  }
-  __syncthreads();
-  unsigned short* op = out + (int64_t)p * rows * K;
+    __syncthreads();
+    unsigned short* op = out + (int64_t)p * rows * K;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int row = (tid >> 4) + 16 * c;
-    if (row0 + row < rows)
-      *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * 256 + (tid & 15) * 16);
+    for (int c = 0; c < 16; ++c) {
+      const int row = (tid >> 4) + 16 * c;
+      if (row0 + row < rows)
+        *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * 256 + (tid & 15) * 16);
+    }
+    __syncthreads();   // the staging tile is reused by the next partition
   }
 }
 
@@ -214,13 +219,13 @@ int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows,
                        hipStream_t st) {
   if (rows == 0) return PARO_OK;
   const int64_t rb = (rows + 255) / 256;
-  dim3 grid((unsigned)rb, (unsigned)(K / 128), (unsigned)nparts);
+  dim3 grid((unsigned)rb, (unsigned)(K / 128));
   if (dt == PARO_DTYPE_F16)
     hipLaunchKernelGGL(rotate_mfma_kernel<f16>, grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,
-                       (const unsigned short*)rmat, (int)rows, (int)K);
+                       (const unsigned short*)rmat, (int)rows, (int)K, nparts);
   else
     hipLaunchKernelGGL(rotate_mfma_kernel<bf16>, grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,
-                       (const unsigned short*)rmat, (int)rows, (int)K);
+                       (const unsigned short*)rmat, (int)rows, (int)K, nparts);
   return check_launch("paro_rotate (mfma pre-pass)");
 }
 
