@@ -64,7 +64,13 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   }
   const bool auto_tpw = tpw <= 0, auto_ks = ksplit <= 0, auto_wv = waves <= 0;
   const bool narrow = tiles <= 320;
-  if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj / down_proj class
+  if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= 64) {
+    // deep K (down_proj, every 70B-class projection but gate_up): a 4-way K-split cuts the replicated rotation
+    // and still leaves >= 256 workgroups (Llama-3-70B: qkv 20.0 -> 14.2 us, down 31.5 -> 25.3, o 12.2 -> 11.6)
+    tpw = (tiles >= 512 && G >= 128) ? 8 : 4;
+    ksplit = 4;
+    waves = 8;
+  } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj class
     tpw = 4; ksplit = 4;
     waves = G / 4 <= 8 ? 4 : 8;   // 8 groups per split: 4 waves x 2 units beat 8 x 1 (o_proj 7.0 -> 6.6 us on the same box)
   }
