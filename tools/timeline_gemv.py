@@ -39,7 +39,7 @@ t = np.concatenate([raw[:, :9], raw[:, 10:11]], axis=1).astype(np.float64)
 d = t - t[:, :1]
 names = ["wg_start", "loads_issued", "coeffs_arrived", "rotation_done", "tiles_consumed", "units_done(w0)",
          "output_written", "all_waves_done", "partials_staged", "stages_done"]
-order = [0, 1, 2, 9, 3, 4, 5, 7, 8, 6]
+order = [0, 1, 2, 9, 4, 5, 7, 8, 6]
 print(f"{a.model} {name} tpw={a.tpw} waves={a.waves} workgroups={ncb}  kernel {e0.elapsed_time(e1)*1e3:.1f} us incl. launch"
       f" (wave 0 of each workgroup; shader cycles since its own start)")
 for k in order:
@@ -49,10 +49,3 @@ wv = raw[:, 16:16 + 4 * a.waves].astype(np.float64).reshape(ncb, a.waves, 4) - t
 print("  by wave index, mean cycles since workgroup start:  start / first coefficients arrived / first unit done / all units done")
 for w in range(a.waves):
     print(f"    wave {w:2d}: " + " / ".join(f"{wv[:, w, k].mean():7.0f}" for k in range(4)))
-xcc = (raw[:, 9] >> 32) & 0xF
-hw = raw[:, 9] & 0xFFFFFFFF
-for xc in sorted(set(xcc.tolist()))[:2]:
-    m = xcc == xc
-    s0 = t[m, 0] - t[m, 0].min()
-    e6 = t[m, 6] - t[m, 0].min()
-    print(f"  XCD {xc}: {m.sum()} workgroups; start spread {s0.max():.0f} cycles (p50 {np.median(s0):.0f}); last output at {e6.max():.0f}")
