@@ -168,6 +168,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   a.slabs = nullptr;
   a.counters = nullptr;
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
+  static const int env_skew = getenv("PARO_GEMV_SKEW") ? atoi(getenv("PARO_GEMV_SKEW")) : 1;
+  a.skew = env_skew;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;

@@ -48,6 +48,7 @@ struct GemvArgs {
   int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
+  int skew;                              // 1: uneven unit split inside the workgroup (see the driver loop)
   PartTable pt;
 };
 
@@ -328,7 +329,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
   };
 
-  const int g0 = g_begin + wave;
   {
     // One unit at a time, distance-1 software pipeline.
     // (Tried and measured equal or slower, MI355X, every Llama-3-8B / Qwen3-4B shape: deeper prefetch
@@ -378,12 +378,40 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // The first unit's loads are issued unconditionally (group index clamped) BEFORE any branch, so the
     // compiler fetches the whole argument block in one scalar batch at kernel entry.  A wave without
     // work (fewer groups than waves) runs one clamped unit and discards it.
-    const bool has_work = g0 < g_end;
-    const int gf = has_work ? g0 : a.G - 1;
+    // Which units (groups) this wave takes.  Even split: unit i of wave w is group w + i * WAVES.  The
+    // waves that share a SIMD do not start together, though: the per-wave timeline shows the second / third /
+    // fourth wave of a SIMD receiving its first coefficients one step later each (3800 vs 9150 cycles with
+    // 8 tiles per wave; 2250 / 3080 / 4080 / 5530 with 16 waves) and finishing that much later.  With
+    // a.skew the first wave of every SIMD therefore takes one unit more and the last one unit less (static,
+    // so results stay bit-reproducible): rounds 0 .. c-2 as before, round c-1 without the last rank, round c
+    // for the first rank only.
+    const int n_local = g_end - g_begin;
+    constexpr int RANKS = WAVES / 4;
+    const int c_even = n_local / WAVES;
+    const bool skew = a.skew && RANKS >= 2 && n_local == c_even * WAVES && c_even >= (RANKS == 2 ? 3 : 2);
+    const int rank = wave >> 2;
+    int my_count;
+    if (skew)
+      my_count = c_even + (rank == 0 ? 1 : 0) - (rank == RANKS - 1 ? 1 : 0);
+    else
+      my_count = wave < n_local ? (n_local - wave + WAVES - 1) / WAVES : 0;
+    auto unit_group = [&](int i) {
+      int li = wave + i * WAVES;
+      if (skew && i >= c_even - 1) {
+        const int base = (c_even - 1) * WAVES;
+        li = (i == c_even - 1) ? base + wave : base + (WAVES - 4) + wave;   // round c-1: ranks 0 .. RANKS-2; round c: rank 0
+      }
+      return g_begin + li;
+    };
+    const bool has_work = my_count > 0;
+    const int gf = has_work ? unit_group(0) : a.G - 1;
     load_p(pc, gf);
     load_t(tc, gf);
     if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
-    for (int g = gf; g + WAVES < g_end; g += WAVES) step(yes, yes, g + WAVES, g + WAVES);
+    for (int i = 0; i + 1 < my_count; ++i) {
+      const int gn = unit_group(i + 1);
+      step(yes, yes, gn, gn);
+    }
     step(no, no, 0, 0);   // the last unit: nothing left to request
     if (!has_work) {
 #pragma unroll
