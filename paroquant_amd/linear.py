@@ -102,6 +102,12 @@ class PackedParoWeights:
             self._rmat[dtype] = r
         return r
 
+    def prepare_prefill(self, dtype: torch.dtype = torch.float16) -> "PackedParoWeights":
+        """Build the dense prefill rotation matrices now (P * K * 256 bytes) instead of on the first call with
+        >= 256 rows -- call it before capturing a prefill step in a HIP graph, where nothing may allocate."""
+        self.rotation_matrices(torch.float16 if dtype == torch.bfloat16 else dtype)
+        return self
+
     def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self.bias if bias is None else bias
         if b is not None and b.dtype != x.dtype:
@@ -164,11 +170,12 @@ class RotateQuantizedLinear(nn.Module):
             self.bias = None
         self._packed: Optional[PackedParoWeights] = None
 
-    def prepare(self) -> "RotateQuantizedLinear":
+    def prepare(self, prefill: bool = False) -> "RotateQuantizedLinear":
         """One-time repack of the checkpoint buffers into the CDNA4 tile layout (device side).
 
         Called lazily by ``forward``; call it explicitly after loading weights (the HF quantizer does,
-        in ``_process_model_after_weight_loading``) so nothing allocates inside a captured HIP graph."""
+        in ``_process_model_after_weight_loading``) so nothing allocates inside a captured HIP graph.
+        ``prefill=True`` also builds the dense rotation matrices of the >= 256-row path up front."""
         if not self.qweight.is_cuda:
             raise RuntimeError("ParoQuant requires a GPU: RotateQuantizedLinear has no CPU path "
                                "(reference: transformers/quantizer.py:78-80)")
@@ -178,6 +185,8 @@ class RotateQuantizedLinear(nn.Module):
             bias = torch.nn.functional.pad(bias, (0, padded[0] - self.out_features))
         self._packed = PackedParoWeights(qw, qz, sc, self.theta, self.pairs, self.channel_scales, padded, bias,
                                          self.group_size, self.w_bit)
+        if prefill:
+            self._packed.prepare_prefill()
         return self
 
     def _apply(self, fn, *args, **kwargs):   # .to()/.cuda() invalidate the packed copy
