@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 2
+#define PARO_ABI_VERSION 3
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -165,6 +165,9 @@ int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
  * Launch-shape knobs (0 = auto): tiles_per_wave in 1..8 (3, 5, 6, 7: fused mode, <= 4 rows, 8 waves);
  * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
  * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above). */
+/* The launch shape paro_w4a16_gemv resolves the knobs to (in: 0 / -1 = auto, out: final values) -- host-only,
+ * touches no device memory: for tooling, logs and tests of the heuristics. */
+int paro_gemv_launch_shape(const paro_linear_t* L, int64_t rows, int* tiles_per_wave, int* ksplit, int* waves, int* mode);
 int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);
 

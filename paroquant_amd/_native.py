@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 2
+PARO_ABI_VERSION = 3
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -31,6 +31,7 @@ EXPORTS = (
     "paro_repack_awq",
     "paro_pack_rotation",
     "paro_linear_workspace_bytes",
+    "paro_gemv_launch_shape",
     "paro_w4a16_gemv",
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
@@ -99,6 +100,9 @@ def load() -> ctypes.CDLL:
     lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.paro_linear_workspace_bytes.restype = c_int64
     lib.paro_linear_workspace_bytes.argtypes = [POINTER(ParoLinearDesc), c_int64]
+    lib.paro_gemv_launch_shape.restype = c_int
+    lib.paro_gemv_launch_shape.argtypes = [POINTER(ParoLinearDesc), c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                           POINTER(c_int)]
     lib.paro_w4a16_gemv.restype = c_int
     lib.paro_w4a16_gemv.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_int, c_int, c_int, c_void_p]

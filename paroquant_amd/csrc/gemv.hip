@@ -95,6 +95,44 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
 
 }  // namespace paro
 
+namespace paro {
+// The launch shape a GEMV call ends up with: caller's knobs (0 = auto, mode -1 = auto) -> final values.
+int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ksp, int& wv, int& mode) {
+  const int waves_in = wv;
+  if (tpw < 0 || tpw > 8)
+    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto) or 1..8 (got %d)", tpw);
+  if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
+  const bool mode_auto = mode < 0;
+  if (mode_auto) mode = 0;
+  if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
+  if (L->krot > 8 || rows > 16) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
+  // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
+  // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
+  // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:
+  // M=4 o 8.1/12.4 qkv 10.0/13.1; M=6 o 10.5/12.5 down 17.3/17.5 but qkv 15.2/13.5 gate_up 22.0/20.9;
+  // M=16 gate_up 53/24).
+  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1))) mode = 1;
+  gemv_autotune(L, rows, tpw, ksp, wv);
+  if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
+  if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves_in <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
+  if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
+  const int G = (int)(L->K / 128);
+  const int gps = (G + ksp - 1) / ksp;
+  ksp = (G + gps - 1) / gps;           // empty splits are dropped
+  return PARO_OK;
+}
+}  // namespace paro
+
+extern "C" int paro_gemv_launch_shape(const paro_linear_t* L, int64_t rows, int* tiles_per_wave, int* ksplit, int* waves,
+                                      int* mode) {
+  using namespace paro;
+  int rc = validate_linear(L);
+  if (rc != PARO_OK) return rc;
+  if (rows < 1 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
+  if (!tiles_per_wave || !ksplit || !waves || !mode) return fail(PARO_ERR_INVALID, "null pointer");
+  return resolve_launch_shape(L, rows, *tiles_per_wave, *ksplit, *waves, *mode);
+}
+
 extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows) {
   using namespace paro;
   if (validate_linear(L) != PARO_OK) return -1;
@@ -127,23 +165,8 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
-  if (tpw < 0 || tpw > 8)
-    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto) or 1..8 (got %d)", tpw);
-  if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
-  const bool mode_auto = mode < 0;
-  if (mode_auto) mode = 0;
-  if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
-  if (L->krot > 8 || rows > 16) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
-  // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
-  // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
-  // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:
-  // M=4 o 8.1/12.4 qkv 10.0/13.1; M=6 o 10.5/12.5 down 17.3/17.5 but qkv 15.2/13.5 gate_up 22.0/20.9;
-  // M=16 gate_up 53/24).
-  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1))) mode = 1;
-  gemv_autotune(L, rows, tpw, ksp, wv);
-  if (rows > 8 && tpw > 4) tpw = 4;
-  if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
-  if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
+  rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
+  if (rc != PARO_OK) return rc;
   const int G = (int)(L->K / 128);
   hipStream_t st = (hipStream_t)stream;
 

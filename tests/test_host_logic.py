@@ -174,3 +174,42 @@ def test_bench_byte_model():
     assert bench.alg_bytes(14336, 4096, 1) == 30916608
     per_tok = 32 * sum(bench.alg_bytes(K, sum(s), len(s)) for _, K, s, _ in bench.layer_shapes("llama3-8b"))
     assert per_tok == 32 * (13414400 + 8839168 + 61292544 + 30916608)
+
+
+def test_gemv_launch_shape_heuristics():
+    """The launch shapes the dispatcher picks for the Llama-3-8B / Qwen3-4B / Llama-3-70B linears (calibrated on
+    MI355X with tools/sweep_gemv.py) -- host-only query, no device memory is touched."""
+    import bench
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+
+    def shape(K, sizes, rows, tpw=0, ksplit=0, waves=0, mode=-1):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.wq_order = K, sum(sizes), len(sizes), 8, nat.DTYPE_F16, 0
+        for i, s_ in enumerate(sizes):
+            d.part_cols[i] = s_
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)          # never dereferenced on the host
+        out = [ctypes.c_int(v) for v in (tpw, ksplit, waves, mode)]
+        nat.check(lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(o) for o in out]))
+        return tuple(o.value for o in out)
+
+    by_model = {m: {n: (K, s) for n, K, s, _ in bench.layer_shapes(m)} for m in ("llama3-8b", "qwen3-4b", "llama3-70b")}
+    l8, q4, l70 = by_model["llama3-8b"], by_model["qwen3-4b"], by_model["llama3-70b"]
+    # batch 1: (tiles per wave, K-split, waves per workgroup, mode 0 = fused rotation)
+    assert shape(*l8["qkv_proj"], 1) == (2, 1, 16, 0)
+    assert shape(*l8["o_proj"], 1) == (4, 4, 4, 0)
+    assert shape(*l8["gate_up_proj"], 1) == (8, 1, 8, 0)
+    assert shape(*l8["down_proj"], 1) == (4, 4, 8, 0)
+    assert shape(*q4["qkv_proj"], 1) == (2, 1, 16, 0)
+    assert shape(*q4["gate_up_proj"], 1) == (8, 1, 8, 0)
+    assert shape(*l70["qkv_proj"], 1) == (4, 4, 8, 0)
+    assert shape(*l70["down_proj"], 1) == (8, 4, 8, 0)
+    # small batches: fused up to 8 rows (4 for merged projections), rotate pre-pass above; 17..64 rows always pre-pass
+    assert shape(*l8["o_proj"], 8)[3] == 0 and shape(*l8["o_proj"], 9)[3] == 1
+    assert shape(*l8["qkv_proj"], 4)[3] == 0 and shape(*l8["qkv_proj"], 5)[3] == 1
+    assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
+    # explicit knobs are respected, empty K-splits dropped
+    assert shape(1536, [512], 1, tpw=2, ksplit=5, waves=8, mode=0) == (2, 4, 8, 0)
+    with pytest.raises(RuntimeError):
+        shape(1536, [512], 1, tpw=9)
