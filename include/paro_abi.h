@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 3
+#define PARO_ABI_VERSION 4
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -118,11 +118,14 @@ int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* s
  * Stage t = 0 is the identity on the natural layout (channels 2l, 2l+1), stage t >= 1 is checkpoint
  * stage t - 1, the last checkpoint stage is the final one.
  * Requires krot <= 8 (larger krot uses the unfused rotate + GEMV route).
- * One-time load step: synchronises `stream` to report stages that are not perfect matchings of their
- * 128 channels (PARO_ERR_INVALID "illegal pair", as optim/rotation.py:36-37 raises at conversion). */
+ * `status` is a caller-owned int32 in device memory (the library never allocates): it is zeroed on the
+ * stream and then set non-zero by the kernel when a stage is not a perfect matching of its 128 channels
+ * (the condition optim/rotation.py:36-37 raises on at conversion).  The call itself neither allocates
+ * nor synchronises; the caller reads `status` after the stream has drained (the Python shim raises
+ * RuntimeError "illegal pair" from it). */
 int64_t paro_packed_rot_bytes(int64_t K, int n_parts);
 int paro_pack_rotation(const int16_t* pairs, const void* theta, int64_t K, int n_parts, int krot, void* out_rot,
-                       void* stream);
+                       int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused rotate + INT4 dequant + matmul.  Replaces, in one call,
@@ -158,7 +161,18 @@ typedef struct paro_linear {
  * it (the kernels leave the counters at zero on exit).  A workspace must not be
  * shared by launches that may run concurrently on different streams. */
 #define PARO_WS_COUNTER_BYTES 16384
+/* Last word of the counter area: sticky status of the in-launch K-split.  0 = healthy.  A reducer that
+ * gives up waiting for a partial (bounded spin; cannot happen while the whole grid is resident, which
+ * paro_w4a16_gemv checks before every K-split launch) stores PARO_WS_STATUS_GIVEUP here and writes NaN
+ * instead of a partial sum -- a failed hand-off is never a silently wrong number.  After a give-up the
+ * workspace must be zero-filled again before reuse. */
+#define PARO_WS_STATUS_OFFSET (PARO_WS_COUNTER_BYTES - 4)
+#define PARO_WS_STATUS_GIVEUP 0xDEADu
 int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t rows);
+/* Diagnostic (the ONLY entry point that synchronises): copies the status word back after draining
+ * `stream`.  Returns PARO_OK, or PARO_ERR_LAUNCH with a message when a K-split gave up.  Call it at
+ * graph-capture / teardown time, never on the hot path. */
+int paro_workspace_status(const void* workspace, void* stream);
 
 /* Decode / small-batch path (rows <= 64; above 16 rows always with the rotate pre-pass): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
@@ -172,9 +186,17 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);
 
 /* Prefill path (any rows): rotate pre-pass into the workspace, then an
- * LDS-staged MFMA GEMM with in-register INT4 unpack. */
+ * LDS-staged MFMA GEMM with in-register INT4 dequant.
+ * `variant` selects the kernel: 0 = auto (by rows / grid size / dtype);
+ *   1 = 128x128 tile, 4 waves, per-group scale epilogue (f16 / bf16; the small-M fallback);
+ *   2 = 256x128 tile, 4 waves, 16x16x32 MFMA, exact fp16 weights in registers (f16 only; K-split at small M);
+ *   3 = 256x256 tile, 8 waves as 2 x 4, 16x16x32 MFMA (f16 only);
+ *   4 = 256x256 tile, 8 waves as 1 x 8 (every wave owns 32 distinct columns over all 256 rows: each INT4
+ *       word is dequantised exactly once per workgroup), 32x32x16 MFMA, f16 and native bf16.
+ * Every variant computes the same function; tests force each one at small sizes through this knob. */
+#define PARO_GEMM_AUTO 0
 int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
-                    int64_t workspace_bytes, void* stream);
+                    int64_t workspace_bytes, int variant, void* stream);
 
 /* Dispatcher used by the Python operator: gemv for rows <= 16, gemm otherwise. */
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,

@@ -14,9 +14,11 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 3
+PARO_ABI_VERSION = 4
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
+PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
+PARO_WS_STATUS_GIVEUP = 0xDEAD
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libparo_mi355x.so")
@@ -31,6 +33,7 @@ EXPORTS = (
     "paro_repack_awq",
     "paro_pack_rotation",
     "paro_linear_workspace_bytes",
+    "paro_workspace_status",
     "paro_gemv_launch_shape",
     "paro_w4a16_gemv",
     "paro_w4a16_gemm",
@@ -97,7 +100,7 @@ def load() -> ctypes.CDLL:
     lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int32), c_int,
                                     c_void_p, c_void_p, c_void_p]
     lib.paro_pack_rotation.restype = c_int
-    lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
+    lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.paro_linear_workspace_bytes.restype = c_int64
     lib.paro_linear_workspace_bytes.argtypes = [POINTER(ParoLinearDesc), c_int64]
     lib.paro_gemv_launch_shape.restype = c_int
@@ -107,7 +110,10 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemv.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_int, c_int, c_int, c_void_p]
     lib.paro_w4a16_gemm.restype = c_int
-    lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                    c_void_p]
+    lib.paro_workspace_status.restype = c_int
+    lib.paro_workspace_status.argtypes = [c_void_p, c_void_p]
     lib.paro_w4a16_linear.restype = c_int
     lib.paro_w4a16_linear.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p]

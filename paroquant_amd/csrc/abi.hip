@@ -1,4 +1,6 @@
 // ABI plumbing: version, thread-local error string, and the M-based dispatcher.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace paro {
@@ -6,7 +8,33 @@ char* error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
 }
+int device_cu_count() {
+  static int cus = 0;
+  if (cus <= 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;   // MI355X
+    cus = v;
+  }
+  return cus;
+}
 }  // namespace paro
+
+extern "C" int paro_workspace_status(const void* workspace, void* stream) {
+  using namespace paro;
+  if (!workspace) return fail(PARO_ERR_INVALID, "null workspace");
+  unsigned word = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const hipError_t e1 = hipMemcpyAsync(&word, (const char*)workspace + PARO_WS_STATUS_OFFSET, 4, hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  if (e1 != hipSuccess || e2 != hipSuccess)
+    return fail(PARO_ERR_LAUNCH, "paro_workspace_status: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  if (word == PARO_WS_STATUS_GIVEUP)
+    return fail(PARO_ERR_LAUNCH, "a K-split reducer gave up waiting for a partial sum (outputs of that launch are NaN); "
+                                 "zero-fill the workspace before reusing it");
+  if (word != 0) return fail(PARO_ERR_LAUNCH, "workspace status word is 0x%x: the workspace was not zero-filled", word);
+  return PARO_OK;
+}
 
 extern "C" int paro_abi_version(void) { return PARO_ABI_VERSION; }
 
@@ -26,5 +54,5 @@ extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y,
   static const int skinny = getenv("PARO_SKINNY") ? atoi(getenv("PARO_SKINNY")) : 1;
   if (skinny && rows <= 64 && L && L->act_dtype == PARO_DTYPE_F16 && !(rows > 32 && L->N / 16 >= 1024))
     return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 1, stream);
-  return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, stream);
+  return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, PARO_GEMM_AUTO, stream);
 }

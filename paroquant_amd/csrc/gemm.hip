@@ -1,19 +1,22 @@
 // W4A16 MFMA GEMM for gfx950 (prefill / large-batch path):  y = rotate(x) @ dequant(W) (+ bias).
 //
 // Two steps behind one ABI call (paro_w4a16_gemm):
-//   1. rotate pre-pass (rotate.hip) writes the rotated activations once per merged partition
-//      into the caller's workspace  xrot[p][rows][K]  (the reference re-launches `rotate` per
-//      partition too -- vllm/plugin.py:288-290 -- but then hands fp16 x to a separate Marlin GEMM);
-//   2. this kernel: 128 x 128 output tile per 256-thread workgroup, K walked one quantisation
-//      group (128) at a time.  The A tile goes through LDS in full 256-byte rows with a 16-slot XOR
-//      swizzle (conflict-free ds_read_b128 fragments); the INT4 B tiles are NOT staged: each wave
-//      loads its four 1-KiB tiles straight to VGPRs in MFMA B-fragment order (paro_repack_awq),
-//      unpacks to (16 + q) halves and feeds v_mfma_f32_16x16x32.  Scale and zero point are applied
-//      per (group, column) on the fp32 group result, exactly as in the GEMV:
-//          acc += s * (D_g - (16 + z) * sum_k x_k)
+//   1. rotate pre-pass (rotate.hip) writes the rotated activations once per merged partition into the
+//      caller's workspace  xrot[p][rows][K]  (the reference re-launches `rotate` per partition too --
+//      vllm/plugin.py:288-290 -- and then hands fp16 x to a separate Marlin GEMM);
+//   2. one of four GEMM kernels (the `variant` knob of the ABI; 0 = auto):
+//        1  gemm_kernel<T>          128 x 128 tile, 4 waves, register-staged A, per-group scale epilogue
+//                                   (f16 / bf16; what bf16 runs below 256 rows)
+//        2  gemm2_f16_kernel<2>     256 x 128 tile, 4 waves (2 x 2), A by LDS-DMA, exact fp16 weights in
+//                                   registers, optional K-split over grid.z for small M
+//        3  gemm2_f16_kernel<4>     256 x 256 tile, 8 waves (2 x 4)            -- the round-1 prefill kernel
+//        4  gemm3_kernel<T>         256 x 256 tile, 8 waves (1 x 8), 32x32x16 MFMA (gemm3.hip), f16 / bf16
+//      In all of them the INT4 B tiles are NOT staged through LDS: a lane's 16-byte load of the packed
+//      tile (paro_repack_awq) is its MFMA operand after the in-register dequant.
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "gemm_args.hpp"
 
 namespace paro {
 
@@ -22,19 +25,6 @@ int launch_rotate(const void* x, void* out, const int16_t* idx, const void* thet
 int validate_linear(const paro_linear_t* L);
 int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows, int64_t K, int nparts, int dt,
                        hipStream_t st);
-
-struct GemmArgs {
-  const u32x4* wq;
-  const unsigned* sz;
-  const unsigned short* bias;
-  const unsigned short* xrot;  // [nparts][rows][K]
-  unsigned short* y;
-  int K, N, G, rows;
-  int tstride, gstride;        // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
-  int ksplit, gps;             // K-split (grid.z) of the v2 kernel: groups per split; 1 = none
-  float* partial;              // [ksplit][rows][N] fp32 partial sums when ksplit > 1
-  PartTable pt;                // column blocks of BN_TILES tiles
-};
 
 constexpr int BM = 128;
 constexpr int BN_TILES = 8;  // 128 columns per workgroup
@@ -409,15 +399,33 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
 }
 }  // namespace paro
 
+namespace paro {
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st);   // gemm3.hip
+}
+
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+                               int64_t workspace_bytes, int variant, void* stream) {
   using namespace paro;
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 0x7fffffff) return fail(PARO_ERR_INVALID, "rows out of range");
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
-  const int ksplit_req = gemm_ksplit(L, rows);
+  if (variant < 0 || variant > 4) return fail(PARO_ERR_INVALID, "variant must be 0 (auto) or 1..4 (got %d)", variant);
+  const bool f16in = L->act_dtype == PARO_DTYPE_F16;
+  if ((variant == 2 || variant == 3) && !f16in)
+    return fail(PARO_ERR_UNSUPPORTED, "GEMM variants 2 and 3 are fp16-only; bf16 runs variant 1 or 4");
+  // ---- kernel choice.  Auto: variant 4 (256 x 256 tile, 1 x 8 waves, 32x32x16 MFMA) when there are >= 256 rows
+  // and enough 256 x 256 tiles to cover the CUs; fp16 below that -> 256 x 128 tile with a K-split at small M;
+  // bf16 below that -> the 128 x 128 kernel.
+  const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
+  int v = variant;
+  if (v == PARO_GEMM_AUTO) {
+    if (rows >= 256 && wide_wgs >= 192) v = 4;
+    else if (f16in && rows > 16) v = 2;
+    else v = 1;
+  }
+  const int ksplit_req = v == 2 ? gemm_ksplit(L, rows) : 1;
   const int64_t xrot_bytes = (int64_t)L->n_parts * rows * L->K * 2;
   const int64_t need = PARO_WS_COUNTER_BYTES + xrot_bytes + (ksplit_req > 1 ? 256 + (int64_t)ksplit_req * rows * L->N * 4 : 0);
   if (!workspace || workspace_bytes < need)
@@ -442,40 +450,36 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.rows = (int)rows;
   a.tstride = L->wq_order ? 1 : a.G;
   a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  // fp16: >= 256 rows -> 256 x 256 tile / 8 waves (measured 730-950 TFLOP/s incl. pre-pass at M = 8192,
-  // vs 560-810 for the 4-wave 256 x 128 tile); 128..255 rows -> 256 x 128; fewer (and bf16) -> v1 kernel.
-  // PARO_GEMM_VERSION = 1 | 2 | 3 forces one of them (A/B runs).
-  static const int env_v = getenv("PARO_GEMM_VERSION") ? atoi(getenv("PARO_GEMM_VERSION")) : 0;
-  const bool v2 = L->act_dtype == PARO_DTYPE_F16 && env_v != 1 && rows > 16;
-  // the wide tile needs enough workgroups to cover the 256 CUs (narrow N x moderate M does not)
-  const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
-  const bool v2wide = v2 && (env_v == 3 || (env_v == 0 && rows >= 256 && wide_wgs >= 192));
-  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, v2wide ? 16 : BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
-  const int bm = v2 ? BM2 : BM;
+  const bool wide = v == 3 || v == 4;
+  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, wide ? 16 : BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
+  const int bm = v == 1 ? BM : BM2;
   const int64_t rb = (rows + bm - 1) / bm;
   if (rb > 65535) return fail(PARO_ERR_INVALID, "rows too large for one launch (max %d)", 65535 * bm);
   a.ksplit = 1;
   a.gps = a.G;
   a.partial = nullptr;
-  if (v2 && !v2wide && ksplit_req > 1) {
+  if (v == 2 && ksplit_req > 1) {
     a.gps = (a.G + ksplit_req - 1) / ksplit_req;
     a.ksplit = (a.G + a.gps - 1) / a.gps;   // drop empty splits
     a.partial = (float*)((char*)workspace + PARO_WS_COUNTER_BYTES + ((xrot_bytes + 255) / 256) * 256);
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)rb, (unsigned)a.ksplit);
-  if (v2wide)
+  if (v == 4) {
+    rc = launch_gemm3(a, L->act_dtype, grid, st);
+    if (rc != PARO_OK) return rc;
+  } else if (v == 3) {
     hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);
-  else if (v2) {
+  } else if (v == 2) {
     hipLaunchKernelGGL(gemm2_f16_kernel<2>, grid, dim3(256), 0, st, a);
     if (a.ksplit > 1) {
       const int64_t total4 = rows * L->N / 4;
       hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a.partial,
                          (const unsigned short*)L->bias, (unsigned short*)y, rows, (int)L->N, a.ksplit);
     }
-  }
-  else if (L->act_dtype == PARO_DTYPE_F16)
+  } else if (f16in) {
     hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
-  else
+  } else {
     hipLaunchKernelGGL(gemm_kernel<bf16>, grid, dim3(256), 0, st, a);
+  }
   return check_launch("paro_w4a16_gemm");
 }

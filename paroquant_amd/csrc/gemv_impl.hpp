@@ -461,9 +461,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           __builtin_amdgcn_s_sleep(2);
           gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if ((gv >> 32) != 1ull) a.counters[PARO_WS_COUNTER_BYTES / 4 - 1] = 0xDEADu;  // give-up code, checked by tests
-        v += __builtin_bit_cast(float, (unsigned)gv);
-        __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((gv >> 32) != 1ull) {
+          // give-up: never a silent wrong sum -- the output becomes NaN and the sticky status word of the
+          // workspace is set (paro_workspace_status / ops.check_workspace); the granule is NOT re-armed, so
+          // a producer that arrives late cannot be mistaken for the next launch's partial without the
+          // status word already saying so.  Unreachable while every workgroup of the launch is resident
+          // (checked on the host before a K-split launch).
+          a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
+          v = __builtin_nanf("");
+        } else {
+          v += __builtin_bit_cast(float, (unsigned)gv);
+          __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
@@ -495,23 +504,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 // ---- per-translation-unit launch tables (one TU per activation type x PREROT, built in parallel)
 constexpr bool tpw_is_pow2(int t) { return t == 1 || t == 2 || t == 4 || t == 8; }
 
+// The in-launch K-split has reducers spin on granules that other workgroups of the SAME launch publish:
+// forward progress is guaranteed -- whatever order the hardware dispatches workgroups in -- exactly when
+// every workgroup of the grid is resident at once.  The occupancy query runs once per instantiation.
+int device_cu_count();
+template <auto Kern, int THREADS>
+int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
+  if (a.ksplit > 1) {
+    static int per_cu = -1;
+    if (per_cu < 0) {
+      int v = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, Kern, THREADS, 0) != hipSuccess || v < 1) v = 1;
+      per_cu = v;
+    }
+    const long long cap = (long long)per_cu * device_cu_count();
+    if ((long long)grid.x * grid.y > cap)
+      return fail(PARO_ERR_UNSUPPORTED, "K-split grid of %u x %u workgroups exceeds the %lld that are resident at once; "
+                  "use a smaller ksplit or more tiles per wave", grid.x, grid.y, cap);
+  }
+  hipLaunchKernelGGL(Kern, grid, dim3(THREADS), 0, st, a);
+  return PARO_OK;
+}
+
 template <typename AT, int TPW, int MB, bool PREROT, int PD>
 int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (tpw_is_pow2(TPW) && TPW < 8 && MB <= 4) {   // 8 tiles x 16 waves does not fit 128 VGPRs
-    if (waves == 16) {
-      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 16, PREROT, PD>), grid, dim3(1024), 0, st, a);
-      return PARO_OK;
-    }
+    if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, PREROT, PD>, 1024>(a, grid, st);
   }
-  if (waves == 8) {
-    hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 8, PREROT, PD>), grid, dim3(512), 0, st, a);
-    return PARO_OK;
-  }
+  if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, PREROT, PD>, 512>(a, grid, st);
   if constexpr (tpw_is_pow2(TPW)) {
-    if (waves == 4) {
-      hipLaunchKernelGGL((gemv_kernel<AT, TPW, MB, 4, PREROT, PD>), grid, dim3(256), 0, st, a);
-      return PARO_OK;
-    }
+    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, PREROT, PD>, 256>(a, grid, st);
   }
   return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d tiles per wave x %d batch rows", waves, TPW, MB);
 }

@@ -288,29 +288,19 @@ extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, co
 }
 
 extern "C" int paro_pack_rotation(const int16_t* pairs, const void* theta, int64_t K, int n_parts, int krot,
-                                  void* out_rot, void* stream) {
+                                  void* out_rot, int32_t* status, void* stream) {
   using namespace paro;
   if (K <= 0 || K % 128 != 0) return fail(PARO_ERR_INVALID, "in_features must be a multiple of 128");
   if (n_parts < 1 || n_parts > PARO_MAX_PARTS) return fail(PARO_ERR_INVALID, "n_parts must be in 1..%d", PARO_MAX_PARTS);
   if (krot < 1 || krot > 8) return fail(PARO_ERR_UNSUPPORTED, "packed rotation supports krot 1..8 (got %d)", krot);
-  if (!pairs || !theta || !out_rot) return fail(PARO_ERR_INVALID, "null pointer");
-  // One-time load step: a device flag reports stages that are not perfect matchings; reading it back
-  // synchronises the stream (the hot calls never do).
+  if (!pairs || !theta || !out_rot || !status) return fail(PARO_ERR_INVALID, "null pointer");
+  // The caller-owned status word reports stages that are not perfect matchings; nothing is allocated and
+  // nothing synchronises here (the caller reads the word once the stream has drained).
   hipStream_t st = (hipStream_t)stream;
-  int* bad = nullptr;
-  if (hipMalloc((void**)&bad, sizeof(int)) != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipMalloc failed in paro_pack_rotation");
-  (void)hipMemsetAsync(bad, 0, sizeof(int), st);
+  (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
   const int64_t n = (int64_t)n_parts * (K / 128);
   hipLaunchKernelGGL(pack_rot_kernel, dim3((unsigned)n), dim3(64), 0, st, pairs,
-                     (const unsigned short*)theta, (unsigned*)out_rot, (int)K, n_parts, krot, bad);
-  int host_bad = 0;
-  const hipError_t e1 = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
-  const hipError_t e2 = hipStreamSynchronize(st);
-  (void)hipFree(bad);
-  if (e1 != hipSuccess || e2 != hipSuccess) return fail(PARO_ERR_LAUNCH, "paro_pack_rotation: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-  if (host_bad)
-    return fail(PARO_ERR_INVALID, "illegal pair: a rotation stage is not a perfect matching of its 128-channel group "
-                                  "(indices out of range, repeated or i == j)");
+                     (const unsigned short*)theta, (unsigned*)out_rot, (int)K, n_parts, krot, (int*)status);
   return check_launch("paro_pack_rotation");
 }
 

@@ -105,7 +105,14 @@ class PackedParoWeights:
     def prepare_prefill(self, dtype: torch.dtype = torch.float16) -> "PackedParoWeights":
         """Build the dense prefill rotation matrices now (P * K * 256 bytes) instead of on the first call with
         >= 256 rows -- call it before capturing a prefill step in a HIP graph, where nothing may allocate."""
-        self.rotation_matrices(torch.float16 if dtype == torch.bfloat16 else dtype)
+        self.rotation_matrices(dtype)
+        return self
+
+    def bind_stream(self, stream) -> "PackedParoWeights":
+        """Use a workspace private to ``stream`` (needed only when launches of different layers may overlap in time
+        on different streams: K-split granules must not be shared by concurrent launches)."""
+        self.workspace = ops.get_workspace(self.wq.device, ops.decode_workspace_bytes(self.K, self.N, len(self.partition_sizes)),
+                                           stream)
         return self
 
     def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -113,12 +120,6 @@ class PackedParoWeights:
         if b is not None and b.dtype != x.dtype:
             b = b.to(x.dtype)
         rows = x.numel() // self.K
-        if rows > 16 and x.dtype == torch.bfloat16:
-            # more than 16 rows with bf16 activations: gfx950 has no packed bf16 VALU for the in-register
-            # dequant, so run the fp16 GEMM (fp16 carries 3 more mantissa bits than bf16; values beyond the fp16
-            # range are saturated) and hand the result back in bf16 -- 2x the throughput of the native bf16 GEMM.
-            y = self.apply(x.clamp(-65504.0, 65504.0).to(torch.float16), None if b is None else b.to(torch.float16))
-            return y.to(torch.bfloat16)
         rmat = self.rotation_matrices(x.dtype) if rows >= 256 else None
         return torch.ops.paro.w4a16_linear(x, self.wq, self.sz, self.rot, self.pairs, self.theta,
                                            self.channel_scales, b, self.partition_sizes, self.workspace,

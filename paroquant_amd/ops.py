@@ -59,9 +59,10 @@ def _rotate_impl(x: torch.Tensor, idx_ij: torch.Tensor, theta: torch.Tensor,
         if group_size not in (64, 128):
             raise RuntimeError(f"Unsupported group_size: {group_size}; expected 64 or 128")
         return out
-    nat.check(lib.paro_rotate(x.data_ptr(), out.data_ptr(), idx_ij.data_ptr(), theta.data_ptr(), s_ptr, rows, h,
-                              int(theta.size(0)), int(group_size), nat.dtype_code(x.dtype), nat.dtype_code(pd),
-                              nat.current_stream_ptr(x.device)))
+    with torch.cuda.device(x.device):     # launch on x's device, not the thread's current one
+        nat.check(lib.paro_rotate(x.data_ptr(), out.data_ptr(), idx_ij.data_ptr(), theta.data_ptr(), s_ptr, rows, h,
+                                  int(theta.size(0)), int(group_size), nat.dtype_code(x.dtype), nat.dtype_code(pd),
+                                  nat.current_stream_ptr(x.device)))
     return out
 
 
@@ -101,8 +102,9 @@ def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
     qweight, qzeros, scales = qweight.contiguous(), qzeros.contiguous(), scales.contiguous()
     wq = torch.empty(lib.paro_packed_qweight_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
     sz = torch.empty(lib.paro_packed_sz_bytes(K, len(sizes), arr) // 4, dtype=torch.int32, device=qweight.device)
-    nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, len(sizes), arr,
-                                  int(wq_order), wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
+    with torch.cuda.device(qweight.device):
+        nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, len(sizes), arr,
+                                      int(wq_order), wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
     return wq, sz
 
 
@@ -124,8 +126,14 @@ def _pack_rotation_impl(pairs: torch.Tensor, theta: torch.Tensor) -> torch.Tenso
         return torch.empty(0, dtype=torch.int32, device=pairs.device)   # unfused route (rotate kernel + GEMV)
     pairs, theta = pairs.contiguous(), theta.contiguous()
     rot = torch.empty(lib.paro_packed_rot_bytes(K, P) // 4, dtype=torch.int32, device=pairs.device)
-    nat.check(lib.paro_pack_rotation(pairs.data_ptr(), theta.data_ptr(), K, P, krot, rot.data_ptr(),
-                                     nat.current_stream_ptr(pairs.device)))
+    # the library never allocates or synchronises: the "illegal pair" status word is ours, and so is the read-back
+    status = torch.empty(1, dtype=torch.int32, device=pairs.device)
+    with torch.cuda.device(pairs.device):
+        nat.check(lib.paro_pack_rotation(pairs.data_ptr(), theta.data_ptr(), K, P, krot, rot.data_ptr(),
+                                         status.data_ptr(), nat.current_stream_ptr(pairs.device)))
+    if not torch.cuda.is_current_stream_capturing() and int(status.item()) != 0:
+        raise RuntimeError("illegal pair: a rotation stage is not a perfect matching of its 128-channel group "
+                           "(indices out of range, repeated or i == j)")     # optim/rotation.py:36-37
     return rot
 
 
@@ -198,14 +206,16 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
         return y.reshape(*x.shape[:-1], N)
     d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias,
                   wq_order, rmat)
+    # Scratch: K-split granules / rotated activations / fp32 partial tiles.  NEVER uninitialised memory: the
+    # granule protocol of the split-K GEMV reads {tag, partial} words and needs the slabs to start at zero, so a
+    # workspace that is too small is replaced by the cached zero-filled one (grown with torch.zeros).
+    need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
     ws = workspace
-    if rows > 16:
-        # prefill: rotated activations live in a scratch buffer from torch's caching allocator
-        need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
-        if ws.numel() * ws.element_size() < need:
-            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    nat.check(lib.paro_w4a16_linear(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
-                                    ws.numel() * ws.element_size(), nat.current_stream_ptr(x.device)))
+    if ws.numel() * ws.element_size() < need:
+        ws = get_workspace(x.device, need)
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_w4a16_linear(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                        ws.numel() * ws.element_size(), nat.current_stream_ptr(x.device)))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -227,14 +237,19 @@ def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
                   pk.channel_scales, bias, pk.wq_order)
     ws = pk.workspace
-    nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
-                                  ws.numel() * ws.element_size(), tiles_per_wave, ksplit, waves, mode,
-                                  nat.current_stream_ptr(x.device)))
+    need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
+    if ws.numel() * ws.element_size() < need:
+        ws = get_workspace(x.device, need)
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                      ws.numel() * ws.element_size(), tiles_per_wave, ksplit, waves, mode,
+                                      nat.current_stream_ptr(x.device)))
     return y.reshape(*x.shape[:-1], N)
 
 
-def w4a16_gemm_forced(x, pk, bias=None, use_rmat: bool = True) -> torch.Tensor:
-    """Direct call of ``paro_w4a16_gemm`` regardless of the row count (tests / benchmarks)."""
+def w4a16_gemm_forced(x, pk, bias=None, use_rmat: bool = True, variant: int = 0) -> torch.Tensor:
+    """Direct call of ``paro_w4a16_gemm`` regardless of the row count (tests / benchmarks); ``variant`` forces one
+    of the GEMM kernels (include/paro_abi.h: 1 = 128x128, 2 = 256x128, 3 = 256x256 2x4 waves, 4 = 256x256 1x8 waves)."""
     lib = nat.load()
     _check_linear_args(x, pk.pairs, pk.theta, pk.channel_scales, bias, pk.partition_sizes)
     K, N = pk.K, pk.N
@@ -243,10 +258,12 @@ def w4a16_gemm_forced(x, pk, bias=None, use_rmat: bool = True) -> torch.Tensor:
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
                   pk.channel_scales, bias, pk.wq_order, pk.rotation_matrices(x.dtype) if use_rmat else None)
-    need = nat.PARO_WS_COUNTER_BYTES + len(pk.partition_sizes) * rows * K * 2
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(), need,
-                                  nat.current_stream_ptr(x.device)))
+    need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
+    ws = get_workspace(x.device, need)
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_w4a16_gemm(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                      ws.numel() * ws.element_size(),
+                                      int(variant), nat.current_stream_ptr(x.device)))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -262,27 +279,40 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
     d.act_dtype = nat.dtype_code(dtype)
     d.wq_order = int(wq_order)
     d.wq, d.sz = wq.data_ptr(), sz.data_ptr()
-    nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
+    with torch.cuda.device(wq.device):
+        nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
     return out
 
 
 _workspaces: dict = {}
 
 
-def get_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Per-device zero-initialised scratch shared by all layers (split-K slabs + arrival counters,
-    rotated activations of the unfused routes).
+def get_workspace(device: torch.device, nbytes: int, stream=None) -> torch.Tensor:
+    """Zero-initialised scratch shared by all layers that run on one (device, stream): split-K granules + arrival
+    counters + status word, rotated activations of the unfused routes, fp32 partial tiles.
 
-    The GEMV kernels leave the counters at zero on exit, so one buffer serves every layer that
-    runs on the same stream; it only ever grows (never during graph capture: it is sized when the
-    layer is prepared)."""
+    The GEMV kernels leave counters and granules at zero on exit, so one buffer serves every layer that runs on
+    the same stream; it only ever grows, and always with ``torch.zeros`` (the granule protocol must never see
+    uninitialised memory).  ``stream=None`` is the default workspace of the device: correct for any number of
+    streams that use it ONE AT A TIME (eager warm-up stream, then a graph-capture stream).  Launches that may
+    overlap in time on different streams must not share granules: give each such stream its own workspace with
+    ``get_workspace(device, nbytes, stream)`` / ``PackedParoWeights.bind_stream(stream)``."""
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx, None if stream is None else int(stream.cuda_stream))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device(device.type, idx))
         _workspaces[key] = ws
     return ws
+
+
+def check_workspace(ws: torch.Tensor) -> None:
+    """Raise if a K-split launch on this workspace ever gave up waiting for a partial sum (its outputs were NaN) or
+    the workspace was not zero-filled.  Synchronises: call it after graph capture / at teardown, not per token."""
+    lib = nat.load()
+    with torch.cuda.device(ws.device):
+        nat.check(lib.paro_workspace_status(ws.data_ptr(), nat.current_stream_ptr(ws.device)))
 
 
 def decode_workspace_bytes(K: int, N: int, n_parts: int, rows: int = 16) -> int:

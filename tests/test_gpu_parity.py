@@ -248,6 +248,11 @@ GEMV_SHAPES = [
     (2560, [9728, 9728]),           # Qwen3-4B merged gate_up (2 rotations, 20 groups)
     (9728, [2560]),                 # Qwen3-4B down_proj (76 groups)
     (256, [48, 16]),                # ragged tiny case: 3 + 1 tiles, 2 groups
+    (4096, [2560]),                 # Qwen3-4B o_proj (t4 k4 w4 K-split path; the worst roofline shape)
+    (2560, [4096, 1024, 1024]),     # Qwen3-4B merged qkv
+    (2048, [1024]),                 # Qwen3-0.6B o_proj
+    (1024, [3072, 3072]),           # Qwen3-0.6B merged gate_up
+    (3072, [1024]),                 # Qwen3-0.6B down_proj
 ]
 
 
@@ -405,7 +410,8 @@ def test_gemm_bf16(dev):
 
 # ---------------------------------------------------------------- full-size properties (BASELINE shapes)
 
-@pytest.mark.parametrize("K,sizes", [(4096, [14336, 14336]), (14336, [4096]), (8192, [8192])])
+@pytest.mark.parametrize("K,sizes", [(4096, [14336, 14336]), (14336, [4096]), (8192, [8192]),
+                                     (8192, [28672, 28672]), (28672, [8192]), (8192, [8192, 1024, 1024])])
 def test_full_size_consistency_and_linearity(dev, K, sizes):
     """At Llama-3-8B / 70B-class shapes the oracle is too slow, so use size-independent properties:
     (i) fused == rotate-op -> dense matmul on the GPU-dequantised weights (each piece is separately
@@ -438,6 +444,223 @@ def test_full_size_consistency_and_linearity(dev, K, sizes):
     x2 = torch.randn(1, K, device=dev, dtype=torch.float16)
     ya, yb, yab = pk.apply(x1).float(), pk.apply(x2).float(), pk.apply((x1.float() * 0.5 + x2.float() * 0.25).half()).float()
     assert (yab - (0.5 * ya + 0.25 * yb)).abs().max().item() <= 6e-3 * yab.abs().max().item()
+
+
+# ---------------------------------------------------------------- every GEMM variant, forced through the ABI knob
+
+def _random_gpu_layer(dev, K, sizes, seed):
+    """Random layer in checkpoint format generated ON the GPU (full-size shapes), plus its numpy view for the oracle."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    N, G, P = sum(sizes), K // 128, len(sizes)
+    L = dict(
+        qweight=torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32),
+        qzeros=torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32),
+        scales=(torch.rand(G, N, device=dev, generator=gen) * 0.018 + 0.002).half(),
+        theta=(torch.randn(P, 8, K // 2, device=dev, generator=gen) * 0.1).half(),
+        pairs=_t(np.stack([po.random_pairs(np.random.default_rng(seed + p), 8, K) for p in range(P)]), dev),
+        channel_scales=(torch.rand(P, 1, K, device=dev, generator=gen) * 1.5 + 0.5).half(), sizes=list(sizes))
+    return L
+
+
+def _pack_gpu_layer(L, bias=None):
+    from paroquant_amd.linear import PackedParoWeights
+    return PackedParoWeights(L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"],
+                             L["sizes"], bias)
+
+
+def _oracle_rows(L, x_rows, bias=None):
+    n = lambda t: t.detach().cpu().numpy()
+    return po.paro_linear_merged(_np(x_rows), n(L["qweight"]), n(L["qzeros"]), n(L["scales"]), n(L["theta"]), n(L["pairs"]),
+                                 n(L["channel_scales"]), L["sizes"], None if bias is None else _np(bias), ideal=True)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("K,sizes,rows", [
+    (512, [256], 300),                      # one column block, ragged row tail
+    (1024, [272, 48], 700),                 # ragged partitions: 17 + 3 tiles -> partial 256-column blocks
+    (384, [512, 256, 256], 256),            # merged qkv-style, exactly one row block, 3 groups
+    (256, [48, 16], 33),                    # tiny
+])
+def test_gemm_variants_forced(dev, variant, K, sizes, rows):
+    """Every prefill kernel (ABI knob `variant`) computes the same function at sizes the oracle finishes in seconds."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + rows + variant, K, sizes, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+    y = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=variant)
+    ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, L["bias"], ideal=True)
+    ref = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                L["channel_scales"], sizes, L["bias"], act="f16")
+    assert np.isfinite(_np(y)).all()
+    assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    assert po.rel_err(_np(y), ref) < REL_TOL
+
+
+@pytest.mark.parametrize("variant", [1, 4])
+@pytest.mark.parametrize("K,sizes,rows", [(1024, [512, 272], 300), (256, [4096], 512)])
+def test_gemm_bf16_native(dev, variant, K, sizes, rows):
+    """bf16 activations run bf16 MFMAs on bf16-dequantised weights (no fp16 detour): variants 1 and 4."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + rows, K, sizes, bias=True)
+    pk = _packed(L, dev)
+    x = torch.randn(rows, K, device=dev).to(torch.bfloat16)
+    bias = _t(L["bias"], dev).to(torch.bfloat16)
+    y = ops.w4a16_gemm_forced(x, pk, bias, variant=variant)
+    assert y.dtype == torch.bfloat16
+    ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, _np(bias), ideal=True)
+    assert po.rel_err(_np(y), ideal) < TIGHT_BF16
+    # values far outside the fp16 range survive (the round-1 fp16 detour saturated them at 65504)
+    xb = x.clone()
+    xb[0, :] *= 3.0e4
+    yb = ops.w4a16_gemm_forced(xb, pk, bias, variant=variant)
+    assert torch.isfinite(yb.float()).all()
+    ideal_b = po.paro_linear_merged(_np(xb[:1]), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                    L["channel_scales"], sizes, _np(bias), ideal=True)
+    assert po.rel_err(_np(yb[:1]), ideal_b) < TIGHT_BF16
+
+
+BASELINE_PREFILL = [
+    ("qwen3-4b.gate_up", 2560, [9728, 9728]), ("qwen3-4b.down", 9728, [2560]),
+    ("llama3-8b.o", 4096, [4096]), ("llama3-8b.qkv", 4096, [4096, 1024, 1024]),
+]
+
+
+@pytest.mark.parametrize("rows", [65536, 3333])
+@pytest.mark.parametrize("name,K,sizes", BASELINE_PREFILL)
+def test_prefill_gemm_at_baseline_sizes(dev, name, K, sizes, rows):
+    """BASELINE config 3 (batch 32 x seq 2048 = 65536 rows) and a ragged M, on the 256 x 256 prefill kernels
+    (variant 4 = what auto picks, variant 3 = the round-1 kernel):
+      (i)  64 sampled rows x all N columns against the float64 oracle;
+      (ii) the FULL tensor against rotation::rotate -> fp32 matmul on the GPU-dequantised weights
+           (each piece is separately oracle-checked), in row chunks."""
+    from paroquant_amd import ops
+    L = _random_gpu_layer(dev, K, sizes, seed=K + rows)
+    pk = _pack_gpu_layer(L).prepare_prefill(torch.float16)
+    N = sum(sizes)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rows)
+    x = torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen)
+    W = ops.dequant_packed(pk.wq, pk.sz, K, sizes, torch.float16, pk.wq_order).float()
+    sample = torch.randperm(rows, device=dev, generator=gen)[:64].sort().values
+    ideal = _oracle_rows(L, x[sample])
+    assert pk.apply(x[:16]).shape == (16, N)
+    for variant in (4, 3):
+        y = ops.w4a16_gemm_forced(x, pk, variant=variant)
+        assert y.shape == (rows, N)
+        assert po.rel_err(_np(y[sample]), ideal) < TIGHT_F16, (name, variant)
+        worst = 0.0
+        for r0 in range(0, rows, 8192):
+            xs = x[r0:r0 + 8192]
+            col, parts = 0, []
+            for p, n in enumerate(sizes):
+                xr = torch.ops.rotation.rotate(xs, L["pairs"][p], L["theta"][p], L["channel_scales"][p]).float()
+                parts.append(xr @ W[:, col:col + n])
+                col += n
+            ref = torch.cat(parts, dim=-1)
+            worst = max(worst, ((y[r0:r0 + 8192].float() - ref).abs().max() / ref.abs().max()).item())
+            del ref, parts
+        assert worst <= 4e-3, (name, variant, worst)
+        if variant == 4:
+            y_auto = pk.apply(x)                      # the dispatcher's own choice at this size
+            assert torch.equal(y_auto, y) or po.rel_err(_np(y_auto[sample]), ideal) < TIGHT_F16
+            del y_auto
+        del y
+    torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- tensor parallelism, emulated on one GPU (SURVEY 8c K7)
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_sharded_hip_path_single_gpu(dev, world):
+    """BASELINE config 5 (70B-class, TP = 2 / 4): every rank's shard goes through the HIP path
+    (PackedParoWeights.apply on the sharded checkpoint tensors, rotation params narrowed exactly as
+    vllm/plugin.py:33-50 does), the partial results are summed (row-parallel: what the RCCL all-reduce does) or
+    concatenated (column-parallel) on the device, and compared with the unsharded HIP result and the oracle."""
+    from paroquant_amd import tp
+    from paroquant_amd.linear import PackedParoWeights
+    cases = [("o_proj", 8192, [8192], "row"), ("qkv_proj", 8192, [8192, 1024, 1024], "col"),
+             ("down_proj", 28672, [8192], "row"), ("gate_up_proj", 8192, [28672, 28672], "col")]
+    for name, K, sizes, kind in cases:
+        L = _random_gpu_layer(dev, K, sizes, seed=world * 1000 + K)
+        full = _pack_gpu_layer(L)
+        for rows in (1, 5):
+            x = torch.randn(rows, K, device=dev, dtype=torch.float16)
+            y_full = full.apply(x)
+            if kind == "row":
+                acc = torch.zeros(rows, sizes[0], device=dev, dtype=torch.float32)
+                for r in range(world):
+                    sh = tp.shard_row_parallel(L, r, world)
+                    pk = PackedParoWeights(sh["qweight"], sh["qzeros"], sh["scales"], sh["theta"], sh["pairs"],
+                                           sh["channel_scales"], sizes)
+                    Kp = K // world
+                    acc += pk.apply(x[:, r * Kp:(r + 1) * Kp].contiguous()).float()
+                y_tp = acc
+            else:
+                outs = []
+                for r in range(world):
+                    sh = tp.shard_column_parallel(L, sizes, r, world)
+                    pk = PackedParoWeights(sh["qweight"], sh["qzeros"], sh["scales"], sh["theta"], sh["pairs"],
+                                           sh["channel_scales"], sh["sizes"])
+                    outs.append(pk.apply(x).float().split(sh["sizes"], dim=-1))
+                # rank-major per partition -> the unsharded column order
+                y_tp = torch.cat([torch.cat([outs[r][p] for r in range(world)], dim=-1) for p in range(len(sizes))], dim=-1)
+            ref = y_full.float()
+            tol = 4e-3 if kind == "row" else 1e-6      # column shards compute the very same dot products
+            assert ((y_tp - ref).abs().max() / ref.abs().max()).item() <= tol, (name, world, rows)
+            if name in ("o_proj", "qkv_proj") and rows == 1:
+                ideal = _oracle_rows(L, x)
+                assert po.rel_err(_np(y_tp), ideal) < TIGHT_F16
+                assert po.rel_err(_np(y_full), ideal) < TIGHT_F16
+        del full, L
+        torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- workspace contract (zero-filled, never uninitialised)
+
+def test_workspace_never_uninitialised(dev):
+    """17..64 rows take the K-split GEMV on {tag, partial} granules that must start at zero.  A layer whose shared
+    decode workspace is too small for that must NOT fall back to uninitialised allocator memory: poison the
+    caching allocator with 0x00000001 words (read as "tag = 1" by a reducer) and check the results."""
+    from paroquant_amd import ops
+    ops._workspaces.clear()
+    L = po.make_layer(4242, 4096, [1024])             # narrow N, deep K: auto K-split at 17..64 rows
+    pk = _packed(L, dev)
+    x = np.random.default_rng(1).standard_normal((48, 4096)).astype(np.float16)
+    ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], [1024], None, ideal=True)
+    for _ in range(3):
+        poison = torch.full((64 << 20,), 0x00000001, dtype=torch.int32, device=dev)
+        del poison                                      # back to the caching allocator, contents intact
+        y = pk.apply(_t(x, dev))
+        assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    ops.check_workspace(ops.get_workspace(dev, 1))
+    ops.check_workspace(pk.workspace)
+
+
+def test_workspace_status_reports_poison(dev):
+    """paro_workspace_status: healthy after K-split launches; a non-zero status word is reported."""
+    from paroquant_amd import ops, _native
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    ops.check_workspace(ws)
+    ws[_native.PARO_WS_STATUS_OFFSET:_native.PARO_WS_STATUS_OFFSET + 4] = torch.tensor([0xAD, 0xDE, 0, 0], dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="gave up"):
+        ops.check_workspace(ws)
+
+
+def test_ksplit_grid_must_be_resident(dev):
+    """A K-split whose grid cannot be resident at once is refused on the host (the reducers spin on partials
+    published by other workgroups of the same launch: forward progress must not depend on dispatch order)."""
+    from paroquant_amd import ops
+    L = po.make_layer(9, 2048, [16384 * 4])            # 4096 column tiles
+    pk = _packed(L, dev)
+    x = torch.randn(1, 2048, device=dev, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="resident"):
+        ops.w4a16_gemv_tuned(x, pk, 1, 16, 4, 0)       # 4096 x 16 workgroups of 4 waves
+    y = ops.w4a16_gemv_tuned(x, pk, 1, 1, 4, 0)
+    assert torch.isfinite(y.float()).all()
 
 
 # ---------------------------------------------------------------- operator API / plug-in surface

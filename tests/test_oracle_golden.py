@@ -119,6 +119,52 @@ def test_g6_quantize_layer_end_to_end(golden_dir):
     assert po.rel_err(y, y_ref) < 2e-3    # only fp16 storage of scales / channel_scales / theta separates the two
 
 
+# ---- G7: rotation orientation + pair layout pinned by the reference's analytic d/dtheta ---------------
+# (kernels/cuda/autograd.py:40-52, evaluated by importing the reference -- tests/golden/make_golden_g7.py)
+
+def _fd_theta(g, rotate_fn, eps=1e-6):
+    loss = lambda th: float((rotate_fn(g["x"], g["idx"], th, g["scale"]) * g["G"]).sum())
+    th0 = g["theta"].astype(np.float64)
+    fd = np.zeros_like(th0)
+    for t in range(th0.shape[1]):
+        d = np.zeros_like(th0)
+        d[0, t] = eps
+        fd[0, t] = (loss(th0 + d) - loss(th0 - d)) / (2 * eps)
+    return fd
+
+
+def test_g7_orientation_pinned_by_reference_backward(golden_dir):
+    """The reference's d/dtheta expression (pair layout idx[0::2] / idx[1::2], orientation xi' = c xi + s xj,
+    xj' = c xj - s xi) reproduces central finite differences of the oracle's forward -- and would not for the
+    opposite orientation or a swapped pair layout (negative controls)."""
+    g = _load(golden_dir, "rotate_backward.npz")
+    ideal = lambda x, idx, th, sc: po.rotate(x, idx, th, sc, 128, mode="ideal")
+    fd = _fd_theta(g, ideal)
+    assert np.abs(fd - g["grad_theta"]).max() < 1e-6
+    assert np.abs(g["grad_theta"]).max() > 0.5           # the comparison is not between zeros
+    # negative controls: a forward with the opposite orientation, or with (i, j) taken from the wrong halves
+    flipped = lambda x, idx, th, sc: po.rotate(x, idx, -th, sc, 128, mode="ideal")
+    assert np.abs(_fd_theta(g, flipped) - g["grad_theta"]).max() > 0.5
+    swapped_idx = g["idx"].reshape(1, -1, 2)[:, :, ::-1].reshape(1, -1)
+    swapped = lambda x, idx, th, sc: po.rotate(x, swapped_idx, th, sc, 128, mode="ideal")
+    assert np.abs(_fd_theta(g, swapped) - g["grad_theta"]).max() > 0.5
+    # the forward stored by the generator is the oracle's own (stubbed in): consistency of the fixture
+    assert np.abs(ideal(g["x"], g["idx"], g["theta"], g["scale"]) - g["y"]).max() < 1e-12
+
+
+def test_g7_grad_x_and_scale(golden_dir):
+    """grad_x = scale * R^T grad_out and grad_scale = sum_b x * R^T grad_out (autograd.py:54-58): the inverse of
+    the rotation is its transpose and the channel scales enter before the first stage."""
+    g = _load(golden_dir, "rotate_backward.npz")
+    inv_idx, inv_th = po.inverse_rotation_params(g["idx"], g["theta"])
+    rt_g = po.rotate(g["grad_out_rotated"], inv_idx, inv_th, None, 128, mode="ideal")
+    assert np.abs(rt_g - g["G"]).max() < 1e-12            # R^T R G = G
+    assert np.abs(rt_g * g["scale"][None, :] - g["grad_x"]).max() < 1e-12
+    assert np.abs((g["x"] * rt_g).sum(0) - g["grad_scale"]).max() < 1e-12
+    # the generator recorded that backward() as shipped (v0.1.16) is NOT the derivative of its own forward
+    assert float(g["fd_err_as_shipped"]) > 0.5
+
+
 # ---- K1..K4: rotation KATs / algebra (rotation.cuh:55-56; optim/qlinear.py:110-120) ----
 
 def _single_pair_idx(K=128):
