@@ -202,6 +202,14 @@ int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                       int64_t workspace_bytes, void* stream);
 
+/* Weight prefetch for decode harnesses that know the NEXT layer (no reference counterpart -- the
+ * reference leaves scheduling to vLLM / HF generate).  Touches one dword per 128-byte line of up to
+ * PARO_MAX_PREFETCH buffers (128-byte aligned) with `workgroups` x 256 threads and discards the data, pulling the
+ * lines into the memory-side Infinity Cache.  Meant for a side branch of a captured decode step; purely a
+ * performance hint: nothing is written (checksum, if non-NULL, receives the XOR of the touched dwords -- tests). */
+#define PARO_MAX_PREFETCH 16
+int paro_prefetch(const void* const* ptrs, const int64_t* bytes, int n, int workgroups, void* checksum, void* stream);
+
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */
 int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);

@@ -16,6 +16,7 @@ import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolv
 
 PARO_ABI_VERSION = 4
 PARO_MAX_PARTS = 8
+PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
 PARO_WS_STATUS_GIVEUP = 0xDEAD
@@ -39,6 +40,7 @@ EXPORTS = (
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
     "paro_dequant_packed",
+    "paro_prefetch",
 )
 
 
@@ -117,6 +119,8 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_linear.restype = c_int
     lib.paro_w4a16_linear.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p]
+    lib.paro_prefetch.restype = c_int
+    lib.paro_prefetch.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]
     lib.paro_dequant_packed.restype = c_int
     lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:

@@ -400,7 +400,7 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
 }  // namespace paro
 
 namespace paro {
-int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st);   // gemm3.hip
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag);   // gemm3.hip
 }
 
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
@@ -411,6 +411,11 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 0x7fffffff) return fail(PARO_ERR_INVALID, "rows out of range");
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
+  int diag = 0;
+  if (variant >= 41 && variant <= 43) {   // ablation builds of variant 4 (wrong results; tools/bench_gemm.py)
+    diag = variant - 40;
+    variant = 4;
+  }
   if (variant < 0 || variant > 4) return fail(PARO_ERR_INVALID, "variant must be 0 (auto) or 1..4 (got %d)", variant);
   const bool f16in = L->act_dtype == PARO_DTYPE_F16;
   if ((variant == 2 || variant == 3) && !f16in)
@@ -465,7 +470,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)rb, (unsigned)a.ksplit);
   if (v == 4) {
-    rc = launch_gemm3(a, L->act_dtype, grid, st);
+    rc = launch_gemm3(a, L->act_dtype, grid, st, diag);
     if (rc != PARO_OK) return rc;
   } else if (v == 3) {
     hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);

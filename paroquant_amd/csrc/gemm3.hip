@@ -141,7 +141,10 @@ struct Dequant<bf16> {
 
 constexpr int BM3 = 256;
 
-template <typename AT>
+// DIAG (energy / issue ablation on the power-limited chip, tools/bench_gemm.py --variants 41,42,43; wrong results):
+// 1 = no dequant (raw INT4 words as the weight operand), 2 = no fragment re-reads inside a group (the first
+// k-step's fragments are reused), 3 = both.  0 = the shipping kernel.
+template <typename AT, int DIAG = 0>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -231,8 +234,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     d.set_group(szn);
     auto word = [&](int s) -> unsigned { return (s & 1) ? qc1[(s >> 1) & 3] : qc0[(s >> 1) & 3]; };
     // the first k-step's weights are dequantised before the barrier (they need nothing from LDS)
+    if constexpr (DIAG == 1 || DIAG == 3) {
+      d.out = (u32x4){qc0[0], qc0[1], qc1[0], qc1[1]};
+    } else {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) d.part(r, word(0));
+      for (int r = 0; r < 7; ++r) d.part(r, word(0));
+    }
     u32x4 bcur = d.out;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab g have landed ...
     __syncthreads();                                   // ... and so have everyone else's; all have left the other buffer
@@ -250,8 +257,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       for (int rt = 0; rt < 8; ++rt) {
         acc[rt] = Mma32<AT>::run(wf, af[rt], acc[rt]);
         if (s < 7) {
-          d.part(rt, word(s + 1));
-          af[rt] = *(const vec8*)(abuf + (a0 ^ (unsigned)((s + 1) << 5)) + rt * 8192);
+          if constexpr (DIAG == 1 || DIAG == 3) {
+            if (rt == 0) d.out = (u32x4){word(s + 1), qc0[s & 3], qc1[s & 3], qc0[(s + 1) & 3]};
+          } else {
+            d.part(rt, word(s + 1));
+          }
+          if constexpr (DIAG != 2 && DIAG != 3)
+            af[rt] = *(const vec8*)(abuf + (a0 ^ (unsigned)((s + 1) << 5)) + rt * 8192);
         }
         // the next slab's eight DMA pieces go out during the first four k-steps (two per step), so that the
         // vmcnt drain in front of the next group's first weight use finds them long landed
@@ -290,11 +302,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   }
 }
 
-int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st) {
-  if (act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL(gemm3_kernel<f16>, grid, dim3(512), 0, st, a);
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag) {
+  if (diag == 1 && act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL((gemm3_kernel<f16, 1>), grid, dim3(512), 0, st, a);
+  else if (diag == 2 && act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL((gemm3_kernel<f16, 2>), grid, dim3(512), 0, st, a);
+  else if (diag == 3 && act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL((gemm3_kernel<f16, 3>), grid, dim3(512), 0, st, a);
+  else if (act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL((gemm3_kernel<f16, 0>), grid, dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL(gemm3_kernel<bf16>, grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL((gemm3_kernel<bf16, 0>), grid, dim3(512), 0, st, a);
   return PARO_OK;
 }
 

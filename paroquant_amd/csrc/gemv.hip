@@ -59,6 +59,7 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
       if (ksplit > 4) ksplit = 4;
       if (ksplit > G / 8) ksplit = G / 8;
       if (ksplit < 1) ksplit = 1;
+      while (ksplit > 1 && cbs * ksplit > 256) --ksplit;   // whole grid resident (one 8-wave workgroup per CU at worst)
     }
     return;
   }
@@ -91,6 +92,14 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   }
   if (ksplit > G) ksplit = G;
   if (ksplit > kMaxKsplit) ksplit = kMaxKsplit;
+  // An in-launch K-split needs its whole grid resident at once (reducers spin on partials of the same launch):
+  // shrink an AUTOMATIC split until column blocks x splits fits 256 CUs x the workgroups a CU holds at <= 128
+  // VGPRs (16 waves); the launcher re-checks against the real occupancy of the instantiation.
+  if (auto_ks && ksplit > 1) {
+    const int64_t cbs = (tiles + tpw - 1) / tpw;
+    const int64_t cap = 256 * (16 / (waves > 0 ? waves : 8));
+    while (ksplit > 1 && cbs * ksplit > cap) --ksplit;
+  }
 }
 
 }  // namespace paro
@@ -228,6 +237,13 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode == 1 ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
   rc = fn(a, wv, grid, st);
+  if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1) {
+    // the automatic K-split does not fit this instantiation's real occupancy: run unsplit (always legal)
+    a.ksplit = 1;
+    a.gps = G;
+    rc = fn(a, wv, dim3((unsigned)a.pt.cbs, 1), st);
+  }
+  if (rc == PARO_ERR_NOT_RESIDENT) rc = PARO_ERR_UNSUPPORTED;
   if (rc != PARO_OK) return rc;
   return check_launch("paro_w4a16_gemv");
 }

@@ -507,6 +507,7 @@ constexpr bool tpw_is_pow2(int t) { return t == 1 || t == 2 || t == 4 || t == 8;
 // The in-launch K-split has reducers spin on granules that other workgroups of the SAME launch publish:
 // forward progress is guaranteed -- whatever order the hardware dispatches workgroups in -- exactly when
 // every workgroup of the grid is resident at once.  The occupancy query runs once per instantiation.
+constexpr int PARO_ERR_NOT_RESIDENT = -100;   // internal: mapped to PARO_ERR_UNSUPPORTED at the ABI boundary
 int device_cu_count();
 template <auto Kern, int THREADS>
 int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
@@ -519,7 +520,7 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
     }
     const long long cap = (long long)per_cu * device_cu_count();
     if ((long long)grid.x * grid.y > cap)
-      return fail(PARO_ERR_UNSUPPORTED, "K-split grid of %u x %u workgroups exceeds the %lld that are resident at once; "
+      return fail(PARO_ERR_NOT_RESIDENT, "K-split grid of %u x %u workgroups exceeds the %lld that are resident at once; "
                   "use a smaller ksplit or more tiles per wave", grid.x, grid.y, cap);
   }
   hipLaunchKernelGGL(Kern, grid, dim3(THREADS), 0, st, a);

@@ -125,6 +125,10 @@ class PackedParoWeights:
                                            self.channel_scales, b, self.partition_sizes, self.workspace,
                                            self.wq_order, rmat)
 
+    def stream_buffers(self):
+        """The buffers a decode launch streams from HBM (what ``ops.prefetch`` should touch for this layer)."""
+        return [self.wq, self.sz, self.rot]
+
     def nbytes(self) -> int:
         ts = [self.wq, self.sz, self.rot, self.channel_scales]
         return sum(t.numel() * t.element_size() for t in ts)

@@ -284,6 +284,24 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
     return out
 
 
+def prefetch(tensors, workgroups: int = 64, checksum: Optional[torch.Tensor] = None) -> None:
+    """Pull the given device buffers into the Infinity Cache on the CURRENT stream (``paro_prefetch``): one dword per
+    128-byte line is touched and discarded.  Call it on a side stream of a captured decode step for the packed
+    weights of a LATER layer; it changes no results."""
+    lib = nat.load()
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    dev = ts[0].device
+    with torch.cuda.device(dev):
+        for i in range(0, len(ts), nat.PARO_MAX_PREFETCH):
+            chunk = ts[i:i + nat.PARO_MAX_PREFETCH]
+            ptrs = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+            sizes = (ctypes.c_int64 * len(chunk))(*[t.numel() * t.element_size() for t in chunk])
+            nat.check(lib.paro_prefetch(ptrs, sizes, len(chunk), int(workgroups),
+                                        None if checksum is None else checksum.data_ptr(), nat.current_stream_ptr(dev)))
+
+
 _workspaces: dict = {}
 
 

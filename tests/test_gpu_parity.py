@@ -608,7 +608,9 @@ def test_tp_sharded_hip_path_single_gpu(dev, world):
                 # rank-major per partition -> the unsharded column order
                 y_tp = torch.cat([torch.cat([outs[r][p] for r in range(world)], dim=-1) for p in range(len(sizes))], dim=-1)
             ref = y_full.float()
-            tol = 4e-3 if kind == "row" else 1e-6      # column shards compute the very same dot products
+            # row shards sum fp16-rounded partials; column shards compute the same dot products, but the narrower
+            # shard resolves to a different launch shape (K-split / wave count), i.e. another fp32 summation order
+            tol = 4e-3 if kind == "row" else 1e-3
             assert ((y_tp - ref).abs().max() / ref.abs().max()).item() <= tol, (name, world, rows)
             if name in ("o_proj", "qkv_proj") and rows == 1:
                 ideal = _oracle_rows(L, x)

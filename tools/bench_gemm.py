@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--variants", default="0", help="comma list of GEMM variants (0 = the dispatcher's choice)")
     ap.add_argument("--only", default="")
+    ap.add_argument("--fill", default="randn", choices=["randn", "zero"], help="activation fill (DVFS check: zeros clock higher)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev); gen.manual_seed(1)
@@ -51,6 +52,8 @@ def main():
         pk.prepare_prefill(dt)
         for rows in [int(r) for r in args.rows.split(",")]:
             x = torch.randn(rows, K, device=dev, dtype=torch.float32, generator=gen).to(dt)
+            if args.fill == "zero":
+                x.zero_()
             fns = {}
             for v in variants:
                 if v in (2, 3) and dt != torch.float16:
@@ -66,7 +69,7 @@ def main():
             flops = 2.0 * rows * K * sum(sizes)
             for v, ts in times.items():
                 med, best = float(np.median(ts)), float(np.min(ts))
-                print(json.dumps({"model": args.model, "linear": name, "dtype": args.dtype, "variant": v, "M": rows, "K": K,
+                print(json.dumps({"model": args.model, "linear": name, "dtype": args.dtype, "fill": args.fill, "variant": v, "M": rows, "K": K,
                                   "N": sum(sizes), "P": len(sizes), "ms_total": round(med, 4), "ms_best": round(best, 4),
                                   "TFLOPs_total": round(flops / med / 1e9, 1), "TFLOPs_best": round(flops / best / 1e9, 1),
                                   "mfma_util_total": round(flops / med / 1e9 / MFMA_PEAK_TFLOPS, 4)}), flush=True)
