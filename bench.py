@@ -12,10 +12,13 @@ the product path), distinct per layer, so a step streams the whole model from HB
 1.9 GB -- far past the 256 MB Infinity Cache).  The step is captured once in a HIP graph and
 replayed (vLLM captures decode the same way).
 
-At N > 1 the default workload runs N independent replicas (data-parallel decode: one process per
-GPU, no data-path collective; `scaling: weak`).  `--workload llama3-70b-tp` instead shards every
-linear Megatron-style across the N ranks (column-parallel qkv / gate_up, row-parallel o / down with
-an RCCL all-reduce after each row-parallel linear) -- `scaling: strong`.
+At N > 1 the DEFAULT workload is the north-star multi-GPU case: the 70B-class model with every linear sharded
+Megatron-style across the N ranks (`llama3-70b-tp`: column-parallel qkv / gate_up, row-parallel o / down with an
+RCCL all-reduce(SUM) of the [1, hidden] activations after each row-parallel linear) -- `scaling: strong`; the same
+workload runs at N = 1 (`--gpus 1 --workload llama3-70b-tp`) for a like-for-like scaling curve.  Any single-GPU
+workload named explicitly at N > 1 runs N independent replicas (data-parallel decode, no data-path collective,
+`scaling: weak`).  `python bench.py --gpus N` spawns its N ranks itself (one process per GPU, backend nccl = RCCL)
+unless it already runs under torchrun (WORLD_SIZE set).
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
   roofline      -- the fused GEMV kernel family `paro::gemv_kernel`: algorithmic bytes per launch
@@ -48,7 +51,22 @@ MODELS = {
     "qwen3-4b": (2560, 9728, 4096, 1024, 36),
     "llama3-8b": (4096, 14336, 4096, 1024, 32),
     "llama3-70b": (8192, 28672, 8192, 1024, 80),
+    "qwen3-32b": (5120, 25600, 8192, 1024, 64),      # 27B..32B-class dense stand-in for BASELINE config 5
 }
+
+
+def register_model_from_config(path: str) -> str:
+    """Add a model read from an HF `config.json` (hidden_size, intermediate_size, num_attention_heads,
+    num_key_value_heads, head_dim, num_hidden_layers) -- e.g. a Qwen3.5-27B checkpoint whose dimensions are
+    not knowable offline.  Returns the registered name."""
+    with open(path) as f:
+        c = json.load(f)
+    c = c.get("text_config", c)
+    hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
+    name = os.path.basename(os.path.dirname(os.path.abspath(path))) or "custom"
+    MODELS[name] = (c["hidden_size"], c["intermediate_size"], c["num_attention_heads"] * hd,
+                    c.get("num_key_value_heads", c["num_attention_heads"]) * hd, c["num_hidden_layers"])
+    return name
 
 
 def alg_bytes(K: int, N: int, P: int) -> int:
@@ -224,22 +242,102 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
                       f"tokens/s = 1 / (ms_per_layer * {L})"}
 
 
-def main():
+def newest_pmc_file(model: str, explicit: str = ""):
+    """profiles/rNN_pmc_bench_<model>.json of the latest round (or the file named on the command line)."""
+    import glob
+    if explicit:
+        return explicit if os.path.exists(explicit) else None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_bench_{model}.json")))
+    return files[-1] if files else None
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="qwen3-4b", choices=list(MODELS) + ["llama3-70b-tp"])
+    ap.add_argument("--workload", default=None,
+                    help="model name (single GPU / replicas) or <model>-tp (tensor parallel over --gpus ranks); "
+                         "default: qwen3-4b at --gpus 1, llama3-70b-tp above")
+    ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--pmc-file", default="", help="PMC summary json for roofline.traffic (default: newest profiles/rNN_pmc_bench_<model>.json)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise only the multi-process plumbing (spawn, rendezvous, barrier, max-over-ranks timing, JSON) "
+                         "with backend gloo and a trivial CPU step -- used by the CPU test-suite; prints data: 'dry-run'")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" in os.environ:        # launched by torchrun / the driver: one rank per process already
+        run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"]))
+        return
+    if args.gpus <= 1:
+        run(args, 0, 0, 1)
+        return
+    # plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU, rendezvous on 127.0.0.1)
+    import socket
+    import torch.multiprocessing as mp
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_spawned, args=(args,), nprocs=args.gpus, join=True)
+
+
+def _spawned(local_rank: int, args):
+    os.environ["RANK"] = os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ["WORLD_SIZE"] = str(args.gpus)
+    run(args, local_rank, local_rank, args.gpus)
+
+
+def run(args, rank: int, local_rank: int, world: int):
+    if args.model_config:
+        registered = register_model_from_config(args.model_config)
+        if args.workload is None:
+            args.workload = registered + ("-tp" if world > 1 else "")
+    workload = args.workload or ("qwen3-4b" if world == 1 else "llama3-70b-tp")
+    tp_mode = workload.endswith("-tp")
+    model = workload[:-3] if tp_mode else workload
+    if model not in MODELS:
+        raise SystemExit(f"unknown workload {workload!r}; known models: {sorted(MODELS)} (each also as <model>-tp)")
+    tp = world if tp_mode else 1
+
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        w = torch.randn(256, 256)
+        buf = torch.randn(1, 256)
+
+        def fn():
+            h = buf @ w
+            if world > 1 and tp_mode:
+                dist.all_reduce(h)
+            return h
+        wall, ev_ms = time_steps_cpu(fn, args.steps, args.warmup, world)
+        result = {"metric": "dry-run (multi-process plumbing only)", "value": round((1 if tp_mode else world) * args.steps / wall, 2),
+                  "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
+                  "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run",
+                  "config": {"workload": workload, "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world)}}
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the ParoQuant hot path)")
     dev = torch.device("cuda", local_rank)
@@ -252,9 +350,10 @@ def main():
     from paroquant_amd import _native
     _native.load()
 
-    tp_mode = args.workload.endswith("-tp")
-    model = args.workload[:-3] if tp_mode else args.workload
-    tp = world if tp_mode else 1
+    if tp_mode:
+        h, inter, q, kv, _ = MODELS[model]
+        if q % (tp * 128) or inter % (tp * 128) or kv % (tp * 16):
+            raise SystemExit(f"{model} does not shard {tp}-way: K slices must be multiples of 128, column slices of 16")
     stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank)
 
     out = stack.step(stack.x)           # eager warm-up (also sizes the shared workspace)
@@ -262,18 +361,27 @@ def main():
     assert torch.isfinite(out.float()).all(), "non-finite activations in the synthetic decode chain"
 
     use_graph = not args.no_graph
+    fn = lambda: stack.step(stack.x)
     if use_graph:
-        s = torch.cuda.Stream(dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            stack.step(stack.x)
-        torch.cuda.current_stream(dev).wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            stack.step(stack.x)
-        fn = graph.replay
-    else:
-        fn = lambda: stack.step(stack.x)
+        try:
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                stack.step(stack.x)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                stack.step(stack.x)
+            graph.replay()
+            torch.cuda.synchronize(dev)
+            fn = graph.replay
+        except Exception as e:           # e.g. an RCCL build that cannot be captured: measure eagerly, say so
+            if tp <= 1:
+                raise
+            print(f"[bench] HIP-graph capture of the TP step failed ({type(e).__name__}: {e}); timing eager launches",
+                  file=sys.stderr, flush=True)
+            use_graph = False
+            torch.cuda.synchronize(dev)
 
     wall, ev_ms = time_steps(fn, args.steps, args.warmup, world, dev)
     ms_per_step = wall * 1e3 / args.steps
@@ -283,18 +391,20 @@ def main():
     launches = stack.launches_per_step
     us_per_launch = ev_ms * 1e3 / (args.steps * launches)
     bytes_per_launch = stack.bytes_per_step / launches
-    achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s
-    traffic = None   # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/)
-    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_bench_{model}.json")
-    if os.path.exists(pmc_file) and not tp_mode and stack.n_layers == MODELS[model][4]:
+    achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s, per rank
+    traffic = None   # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, summaries under profiles/)
+    pmc_file = newest_pmc_file(model, args.pmc_file)
+    if pmc_file and not tp_mode and stack.n_layers == MODELS[model][4]:
         with open(pmc_file) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "paro::gemv_kernel (fused rotate+INT4 GEMV, all launches of the step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": os.path.relpath(pmc_file, ROOT) if (pmc_file and traffic is not None) else None,
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
                 "launches_per_step": launches,
-                "note": "launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps)"}
+                "note": "per rank; launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps"
+                        + (" and the all-reduces" if tp > 1 else "") + ")"}
 
     result = {
         "metric": "decode tokens/s through the ParoQuant quantised-linear hot path (fused rotation + INT4 GEMV), batch 1",
@@ -303,9 +413,10 @@ def main():
         "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f16 activations x int4 weights (fp32 accumulate)",
         "data": "synthetic (random INT4 AWQ-format weights, random fp16 activations, random perfect-matching pairs)",
         "config": {"workload": f"{model}-PARO batch-1 decode: {stack.n_layers} layers x (qkv[P=3], o, gate_up[P=2], down) "
-                               f"W4A16 g128 krot8, {'TP=%d' % tp if tp_mode else 'replica per GPU'}",
+                               f"W4A16 g128 krot8, {'TP=%d (RCCL all-reduce after o / down)' % tp if tp_mode else 'replica per GPU'}",
                    "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
-                   "bytes_per_token": stack.bytes_per_step, "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world)},
+                   "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
+                   "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world)},
         "roofline": roofline,
     }
 
@@ -321,6 +432,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def time_steps_cpu(fn, steps: int, warmup: int, world: int):
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = t[0].item()
+    return wall, wall * 1e3
 
 
 if __name__ == "__main__":

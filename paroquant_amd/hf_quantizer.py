@@ -74,9 +74,12 @@ class ParoQuantConfig(QuantizationConfigMixin):
     """``quantization_config`` block of a ``*-PARO`` checkpoint (W4A16, group 128, ``krot`` Givens stages)."""
 
     def __init__(self, bits: int = 4, group_size: int = 128, krot: int = 8,
-                 modules_to_not_convert: Optional[Sequence[str]] = None, **_ignored):
+                 modules_to_not_convert: Optional[Sequence[str]] = None, free_checkpoint_buffers: bool = False, **_ignored):
         self.quant_method = "paroquant"
         self.bits, self.group_size, self.krot = int(bits), int(group_size), int(krot)
+        # this build only: drop the AWQ-format buffers after the one-time repack (halves the INT4 footprint;
+        # the model can then not be saved or moved) -- RotateQuantizedLinear.release_checkpoint_buffers
+        self.free_checkpoint_buffers = bool(free_checkpoint_buffers)
         self.modules_to_not_convert = None if modules_to_not_convert is None else list(modules_to_not_convert)
         post_init = getattr(self, "post_init", None)   # newer transformers validate here
         if callable(post_init):
@@ -139,6 +142,8 @@ class ParoQuantHfQuantizer(HfQuantizer):
         for layer in model.modules():
             if isinstance(layer, RotateQuantizedLinear) and layer.qweight.is_cuda:
                 layer.prepare()
+                if getattr(self.quantization_config, "free_checkpoint_buffers", False):
+                    layer.release_checkpoint_buffers()
         return model
 
     # -- capabilities

@@ -81,6 +81,23 @@ class PackedParoWeights:
         self._rmat = {}
         self.workspace = ops.get_workspace(qweight.device, ops.decode_workspace_bytes(K, N, P))
 
+    @classmethod
+    def from_packed(cls, wq, sz, rot, theta, pairs, channel_scales, partition_sizes: Sequence[int], K: int,
+                    wq_order: int = 0, bias: Optional[torch.Tensor] = None) -> "PackedParoWeights":
+        """Adopt buffers that are ALREADY in the kernel layout (``pack.load_prepacked``): no repack launches."""
+        self = cls.__new__(cls)
+        self.partition_sizes = [int(s) for s in partition_sizes]
+        self.K, self.N = int(K), int(sum(self.partition_sizes))
+        P = len(self.partition_sizes)
+        self.theta, self.pairs = theta.to(torch.float16).contiguous(), pairs.to(torch.int16).contiguous()
+        self.channel_scales = channel_scales.reshape(P, self.K).to(torch.float16).contiguous()
+        self.wq_order = int(wq_order)
+        self.wq, self.sz, self.rot = wq.contiguous(), sz.contiguous(), rot.contiguous()
+        self.bias = bias
+        self._rmat = {}
+        self.workspace = ops.get_workspace(wq.device, ops.decode_workspace_bytes(self.K, self.N, P))
+        return self
+
     def rotation_matrices(self, dtype: torch.dtype) -> torch.Tensor:
         """Dense per-group rotation matrices for the prefill pre-pass on the matrix cores:
         ``rmat[p, g, n, k] = (diag(cs) G_1 .. G_krot)[k, n]`` of group g -- obtained by pushing the scaled
@@ -135,39 +152,31 @@ class PackedParoWeights:
 
 
 class RotateQuantizedLinear(nn.Module):
-    """Pairwise Givens rotation + INT4 quantized matmul (fused CDNA4 kernels).
+    """HF-side operator: ``y = rotate(x * channel_scales) @ dequant(qweight, qzeros, scales) (+ bias)`` on the fused
+    CDNA4 kernels.
 
-    All parameters are stored flat (no submodules), so state dict keys like ``gate_proj.theta`` and
-    ``gate_proj.qweight`` match checkpoint naming directly (reference modules.py:16-55).
+    Drop-in for the reference module of the same name (transformers/modules.py:16-71): same constructor, and the
+    checkpoint tensors of a linear are plain buffers of THIS module under the reference's names, dtypes and shapes
+    (modules.py:43-55) so that ``*-PARO`` safetensors keys such as ``...gate_proj.theta`` load without remapping:
+
+        theta          f16   [krot, in/2]        pairs   int16 [krot, in]       channel_scales f16 [1, in]
+        qweight        int32 [in, out/8]         qzeros  int32 [in/gs, out/8]   scales         f16 [in/gs, out]
+        bias           f16   [out]  (optional)
     """
 
-    def __init__(
-        self,
-        in_features: int,
-        out_features: int,
-        bias: bool = False,
-        group_size: int = 128,
-        bits: int = 4,
-        krot: int = 8,
-    ):
+    def __init__(self, in_features: int, out_features: int, bias: bool = False, group_size: int = 128, bits: int = 4,
+                 krot: int = 8):
         super().__init__()
-        self.in_features = in_features
-        self.out_features = out_features
-        self.w_bit = bits
-        self.group_size = group_size
-
-        pack = 32 // bits
-        n_groups = in_features // group_size
-
-        # Rotation buffers (modules.py:43-46)
-        self.register_buffer("theta", torch.zeros(krot, in_features // 2, dtype=torch.float16))
-        self.register_buffer("pairs", torch.zeros(krot, in_features, dtype=torch.int16))
-        self.register_buffer("channel_scales", torch.ones(1, in_features, dtype=torch.float16))
-
-        # AWQ quantized weight buffers (modules.py:48-50)
-        self.register_buffer("qweight", torch.zeros(in_features, out_features // pack, dtype=torch.int32))
-        self.register_buffer("qzeros", torch.zeros(n_groups, out_features // pack, dtype=torch.int32))
-        self.register_buffer("scales", torch.zeros(n_groups, out_features, dtype=torch.float16))
+        self.in_features, self.out_features = in_features, out_features
+        self.w_bit, self.group_size = bits, group_size
+        per_word, groups = 32 // bits, in_features // group_size
+        i16, i32, f16 = torch.int16, torch.int32, torch.float16
+        for name, shape, dtype, fill in (
+                ("theta", (krot, in_features // 2), f16, 0), ("pairs", (krot, in_features), i16, 0),
+                ("channel_scales", (1, in_features), f16, 1),
+                ("qweight", (in_features, out_features // per_word), i32, 0),
+                ("qzeros", (groups, out_features // per_word), i32, 0), ("scales", (groups, out_features), f16, 0)):
+            self.register_buffer(name, torch.full(shape, fill, dtype=dtype))
 
         if bias:
             self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float16))
@@ -194,7 +203,21 @@ class RotateQuantizedLinear(nn.Module):
             self._packed.prepare_prefill()
         return self
 
+    def release_checkpoint_buffers(self) -> "RotateQuantizedLinear":
+        """Drop the AWQ-format ``qweight`` / ``qzeros`` / ``scales`` once the kernel-layout copy exists (they double
+        the INT4 footprint otherwise: +35 GB on a 70B model).  Opt-in: afterwards the module can no longer be
+        re-packed (``.to()`` another device) or saved -- the reference keeps the buffers because AutoAWQ computes
+        on them directly (modules.py:61-70), the vLLM path frees them like this (plugin.py:276-279)."""
+        if self._packed is None:
+            self.prepare()
+        for name in ("qweight", "qzeros", "scales"):
+            setattr(self, name, torch.empty(0, dtype=getattr(self, name).dtype, device=getattr(self, name).device))
+        self._released = True
+        return self
+
     def _apply(self, fn, *args, **kwargs):   # .to()/.cuda() invalidate the packed copy
+        if getattr(self, "_released", False):
+            raise RuntimeError("RotateQuantizedLinear: checkpoint buffers were released; the module cannot be moved")
         self._packed = None
         return super()._apply(fn, *args, **kwargs)
 

@@ -739,3 +739,89 @@ def test_prefill_prepass_variants_agree(dev, dtype):
     gram = torch.einsum("pgnk,pgnl->pgkl", R, R)
     eye = torch.diag_embed(cs * cs)
     assert (gram - eye).abs().max().item() < 5e-3
+
+
+# ---------------------------------------------------------------- f1: the packer library in the product
+
+def test_pack_library_gpu_matches_goldens(dev, golden_dir):
+    """paroquant_amd.pack on GPU tensors (rotation through rotation::rotate in fp32): bit-exact against the
+    reference-generated goldens G5 (_quantize_rotated_weight) and G6 (_quantize_layer)."""
+    from paroquant_amd import pack
+    g = np.load(os.path.join(golden_dir, "quantize_rotated.npz"))
+    q, s2d, z2d = pack.quantize_rotated_weight(_t(g["weight"], dev), _t(g["pairs"], dev), _t(g["theta"], dev),
+                                               _t(g["channel_scales"], dev), _t(g["scales_flat"], dev), _t(g["zp_flat"], dev))
+    # the fp32 rotation on the GPU (v_sin / v_cos) and the oracle's libm rotation may round a weight that sits on
+    # a quantisation boundary to the neighbouring level: allow |dq| <= 1 on < 0.1 % of the weights, exact elsewhere
+    dq = (q.cpu().numpy().astype(np.int64) - g["quantized"].astype(np.int64))
+    assert np.abs(dq).max() <= 1 and (dq != 0).mean() < 1e-3
+    assert np.array_equal(z2d.cpu().numpy(), g["zeros_2d"].astype(np.int32))
+    assert np.allclose(s2d.cpu().numpy(), g["scales_2d"], rtol=0, atol=0)
+    g6 = np.load(os.path.join(golden_dir, "quantize_layer.npz"))
+    sd = {"weight": torch.from_numpy(g6["weight"]), "n_bits": torch.tensor(int(g6["bits"])), "group_size": torch.tensor(int(g6["group_size"])),
+          "pairs_grouped": torch.from_numpy(g6["pairs_in"]), "angles_grouped": torch.from_numpy(g6["theta_in"]),
+          "channel_scales": torch.from_numpy(g6["channel_scales_opt"]), "quantizer.scale": torch.from_numpy(g6["scale"]),
+          "quantizer.zero_point_float": torch.from_numpy(g6["zero_point_float"]), "bias": torch.from_numpy(g6["bias_in"])}
+    out = pack.quantize_layer(sd, dev)
+    for k in ("qzeros", "scales", "theta", "pairs", "channel_scales", "bias"):
+        a, b = out[k].cpu().numpy(), g6["out_" + k]
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+    dq = pack.unpack_awq(out["qweight"]).cpu().numpy().astype(np.int64) - po.unpack_awq(g6["out_qweight"]).astype(np.int64)
+    assert np.abs(dq).max() <= 1 and (dq != 0).mean() < 1e-3
+
+
+def test_prepacked_roundtrip(dev, tmp_path):
+    """save_prepacked / load_prepacked: a linear stored in the CDNA4 kernel layout comes back bit-identical and
+    computes the same outputs without any repack launch."""
+    from paroquant_amd import pack
+    L = po.make_layer(606, 1024, [512, 256, 256], bias=True)
+    pk = _packed(L, dev, L["bias"])
+    f = str(tmp_path / "qkv.prepacked.safetensors")
+    pack.save_prepacked(pk, f)
+    pk2 = pack.load_prepacked(f, dev)
+    for name in ("wq", "sz", "rot"):
+        assert torch.equal(getattr(pk, name), getattr(pk2, name))
+    assert pk2.partition_sizes == [512, 256, 256] and pk2.K == 1024 and pk2.wq_order == pk.wq_order
+    for rows in (1, 40, 300):
+        x = torch.randn(rows, 1024, device=dev, dtype=torch.float16)
+        assert torch.equal(pk.apply(x), pk2.apply(x))
+
+
+# ---------------------------------------------------------------- a8: HF from_pretrained end to end
+
+def test_hf_from_pretrained_end_to_end(dev, tmp_path):
+    """A synthetic 2-layer Llama-style PARO checkpoint (safetensors + config.json with quantization_config, tensors
+    from the oracle's packer) loads through AutoModelForCausalLM.from_pretrained -> ParoQuantHfQuantizer
+    (transformers/quantizer.py:88-115): every quantised nn.Linear is swapped for RotateQuantizedLinear, repacked,
+    and one forward of each swapped linear matches the oracle on the activations it actually received."""
+    import paroquant_amd.hf_quantizer  # noqa: F401  (registers the "paroquant" config + quantizer)
+    from paroquant_amd import RotateQuantizedLinear
+    from tests.hf_ckpt import write_tiny_paro_llama
+    from transformers import AutoModelForCausalLM
+    layers = write_tiny_paro_llama(str(tmp_path))
+    try:
+        model = AutoModelForCausalLM.from_pretrained(str(tmp_path), dtype=torch.float16, device_map={"": "cuda:0"})
+    except TypeError:
+        model = AutoModelForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.float16, device_map={"": "cuda:0"})
+    swapped = {k: m for k, m in model.named_modules() if isinstance(m, RotateQuantizedLinear)}
+    assert set(swapped) == set(layers)
+    assert all(m._packed is not None for m in swapped.values())          # repacked by the after-loading hook
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: seen.__setitem__(k, (inp[0].detach(), out.detach())))
+             for k, m in swapped.items()]
+    ids = torch.randint(0, 128, (1, 9), device=dev)
+    with torch.no_grad():
+        logits = model(input_ids=ids).logits
+    for h in hooks:
+        h.remove()
+    assert logits.shape == (1, 9, 128) and torch.isfinite(logits.float()).all()
+    assert set(seen) == set(layers)
+    for k, (x, y) in seen.items():
+        L = layers[k]
+        K = x.shape[-1]
+        ref = po.paro_linear(_np(x.reshape(-1, K)), L["qweight"], L["qzeros"], L["scales"], L["theta"][0], L["pairs"][0],
+                             L["channel_scales"][0], None, ideal=True)
+        assert po.rel_err(_np(y.reshape(-1, y.shape[-1])), ref) < TIGHT_F16, k
+    # greedy decode runs (prefill rows > 1, then single-token steps through the GEMV)
+    with torch.no_grad():
+        gen = model.generate(ids, max_new_tokens=4, do_sample=False)
+    assert gen.shape == (1, 13)

@@ -215,3 +215,54 @@ def test_gemv_launch_shape_heuristics():
     assert shape(1536, [512], 1, tpw=2, ksplit=5, waves=8, mode=0) == (2, 4, 8, 0)
     with pytest.raises(RuntimeError):
         shape(1536, [512], 1, tpw=9)
+
+
+def test_packaging_entry_point():
+    """pyproject.toml declares the vLLM plug-in entry point of the reference (pyproject.toml:22-23 there) and it
+    resolves to a callable (vLLM itself is not installed here: register() must still import cleanly)."""
+    import importlib
+    import tomli
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as f:
+        meta = tomli.load(f)
+    ep = meta["project"]["entry-points"]["vllm.general_plugins"]["paroquant"]
+    mod, _, attr = ep.partition(":")
+    fn = getattr(importlib.import_module(mod), attr)
+    assert callable(fn)
+    fn()
+    assert "paroquant_amd" in meta["tool"]["setuptools"]["packages"]
+
+
+def test_pack_library_matches_reference_goldens_cpu(golden_dir):
+    """paroquant_amd.pack (the product's packer, torch): bit-exact against the reference-generated goldens G1 / G2
+    (the pure integer part runs on any device; the rotation-dependent part is a -m gpu test)."""
+    from paroquant_amd import pack
+    g = np.load(os.path.join(golden_dir, "pack_awq.npz"))
+    packed = pack.pack_awq(torch.from_numpy(g["values"]))
+    assert np.array_equal(packed.numpy(), g["packed"])
+    assert np.array_equal(pack.unpack_awq(torch.from_numpy(g["packed"])).numpy(), g["values"].astype(np.uint8))
+    assert int(pack.pack_awq(torch.from_numpy(g["kat_values"])).numpy().view(np.uint32)[0, 0]) == 0x7B0F335C
+    g2 = np.load(os.path.join(golden_dir, "to_awq_buffers.npz"))
+    b = pack.to_awq_buffers(torch.from_numpy(g2["quantized"]), torch.from_numpy(g2["scales_2d"]), torch.from_numpy(g2["zeros_2d"]))
+    assert np.array_equal(b["qweight"].numpy(), g2["qweight"]) and np.array_equal(b["qzeros"].numpy(), g2["qzeros"])
+    assert np.array_equal(b["scales"].numpy().view(np.uint16), g2["scales"].view(np.uint16))
+
+
+def test_hf_checkpoint_discovery_and_surgery(tmp_path):
+    """HF quantizer host logic on a synthetic 2-layer Llama-style PARO checkpoint: the quantised modules are found
+    from the safetensors header (transformers/quantizer.py:30-44) and exactly those nn.Linear are swapped."""
+    from tests.hf_ckpt import LINEARS, write_tiny_paro_llama
+    from paroquant_amd import RotateQuantizedLinear
+    from paroquant_amd.hf_quantizer import ParoQuantConfig, _find_quantized_modules, replace_linears
+    write_tiny_paro_llama(str(tmp_path))
+    found = _find_quantized_modules(str(tmp_path))
+    assert found == {f"model.layers.{l}.{n}" for l in range(2) for n, _, _ in LINEARS}
+    from transformers import AutoConfig, AutoModelForCausalLM
+    cfg = AutoConfig.from_pretrained(str(tmp_path))
+    with torch.device("meta"):
+        model = AutoModelForCausalLM.from_config(cfg)
+    n = replace_linears(model, found, ParoQuantConfig())
+    assert n == 14
+    swapped = {k for k, m in model.named_modules() if isinstance(m, RotateQuantizedLinear)}
+    assert swapped == found and isinstance(model.lm_head, torch.nn.Linear)
+    q = model.model.layers[1].self_attn.k_proj
+    assert (q.in_features, q.out_features) == (256, 128) and q.qweight.shape == (256, 16)

@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) test of the tensor-parallel sharding logic
+"""Multi-process (gloo, world_size 2 and 4, CPU) test of the tensor-parallel sharding logic
 (paroquant_amd/tp.py; reference vllm/plugin.py:33-50,196-198).  The per-rank linear is evaluated by
 the CPU oracle here (the HIP path needs a GPU); what is under test is the sharding of the
 checkpoint tensors, the narrowing of the rotation parameters and the all-reduce placement."""
@@ -72,15 +72,55 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_tp_sharding_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_sharding(world):
+    """World 2 and world 4 (BASELINE config 5 is TP = 4): K = 512 shards into 128-channel slices, every merged
+    partition of [128, 64, 64] columns into 16-column multiples."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True, True, True), (1, True, True, True)]
+    assert res == [(r, True, True, True) for r in range(world)]
+
+
+def _bench_line(cmd, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable] + cmd, cwd=root, env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout      # rank 0 prints exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_ranks():
+    """`python bench.py --gpus N` (the driver's command shape without torchrun) must start N ranks itself and
+    report n_gpus = N; the default workload at N > 1 is the tensor-parallel one (strong scaling), a single-GPU
+    workload named explicitly runs N replicas (weak scaling).  --dry-run swaps the GPU step for a CPU matmul and
+    nccl for gloo; everything else (spawn, rendezvous, barrier, max-over-ranks clock, JSON) is the real path."""
+    r = _bench_line(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["parallelism"] == "tp2"
+    assert r["config"]["workload"] == "llama3-70b-tp" and r["steps"] == 3 and r["warmup"] == 1
+    r = _bench_line(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--workload", "qwen3-4b"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "dp2"
+    r = _bench_line(["bench.py", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert r["n_gpus"] == 1 and r["config"]["workload"] == "qwen3-4b"
+
+
+def test_bench_under_torchrun():
+    """The driver's launch line for N > 1: torch.distributed.run, one rank per process, rendezvous on 127.0.0.1."""
+    port = _free_port()
+    r = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
