@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 4
+#define PARO_ABI_VERSION 5
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -185,6 +185,27 @@ int paro_gemv_launch_shape(const paro_linear_t* L, int64_t rows, int* tiles_per_
 int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode, void* stream);
 
+/* Decode-layer fusions either side of the linear (the reference runs RMSNorm, SiLU*mul and the
+ * residual add as separate framework kernels around `rotate -> GEMM`):
+ *   prologue PARO_PROLOGUE_RMSNORM   y = GEMV(x) * rsqrt(mean_k(x_k^2) + eps).  The norm WEIGHT is not an argument:
+ *            fold it into `channel_scales` at load time (cs'[p][k] = cs[p][k] * w[k]); the remaining scalar
+ *            commutes with the rotation and the matmul, and sum(x^2) is gathered while the kernel seeds the rotation.
+ *   prologue PARO_PROLOGUE_SILU_MUL  x_k = silu(gate_k) * up_k, gate = x[row][0..K), up = x[row][K..2K) (the merged
+ *            gate_up projection's output), evaluated in fp32 before the rotation.
+ *   residual                          y[row][col] += residual[row][col]  (act_dtype, row stride N), or NULL.
+ * rows <= 4, krot <= 8 (in-kernel rotation); the launch shape is chosen automatically. */
+#define PARO_PROLOGUE_NONE 0
+#define PARO_PROLOGUE_RMSNORM 1
+#define PARO_PROLOGUE_SILU_MUL 2
+typedef struct paro_fusion {
+  int32_t prologue;
+  float eps;             /* RMSNorm epsilon */
+  int64_t x_stride;      /* elements between rows of x; 0 = dense (K, or 2 K for SILU_MUL) */
+  const void* residual;
+} paro_fusion_t;
+int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                          int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream);
+
 /* Prefill path (any rows): rotate pre-pass into the workspace, then an
  * LDS-staged MFMA GEMM with in-register INT4 dequant.
  * `variant` selects the kernel: 0 = auto (by rows / grid size / dtype);
@@ -201,6 +222,21 @@ int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows
 /* Dispatcher used by the Python operator: gemv for rows <= 16, gemm otherwise. */
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                       int64_t workspace_bytes, void* stream);
+
+/* Batch-1 decode attention of one layer in one launch (the decode harness; the reference leaves
+ * attention to HF generate() / vLLM, transformers/generator.py:37-67): optional per-head q / k RMSNorm (Qwen3),
+ * rotary embedding (rotate_half convention), KV-cache append at *pos, grouped-query attention over 0..*pos.
+ *   qkv     act_dtype [(n_heads + 2 n_kv_heads) * head_dim]   (output of the merged qkv projection)
+ *   kcache, vcache  act_dtype [n_kv_heads][max_positions][head_dim]
+ *   out     act_dtype [n_heads * head_dim]
+ *   pos     int32 in DEVICE memory (a captured graph replays for every token)
+ *   rope    fp32 [max_positions][head_dim]: cos then sin (head_dim / 2 each) of every position
+ * head_dim in {64, 128}; n_heads / n_kv_heads <= 8; the scores of all positions live in LDS
+ * (paro_attn_decode_lds_bytes(...) <= 160 KiB bounds max_positions). */
+int64_t paro_attn_decode_lds_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions);
+int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
+                     const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads, int n_kv_heads,
+                     int head_dim, int max_positions, int act_dtype, void* stream);
 
 /* Weight prefetch for decode harnesses that know the NEXT layer (no reference counterpart -- the
  * reference leaves scheduling to vLLM / HF generate).  Touches one dword per 128-byte line of up to

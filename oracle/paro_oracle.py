@@ -448,3 +448,59 @@ def rel_err(y, ref):
     y = np.asarray(y, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.max(np.abs(y - ref)) / max(np.max(np.abs(ref)), 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Decoder-layer pieces around the linears (decode harness).  The reference has no code for
+# these: it runs the HF model's own modules (transformers/generator.py:37-67, `transformers>=4.55`,
+# pyproject.toml:27); restated here in float64 from the published Llama / Qwen3 modelling code
+# (LlamaRMSNorm, LlamaMLP `down(act(gate) * up)`, `apply_rotary_pos_emb` with rotate_half, grouped-query attention).
+# ---------------------------------------------------------------------------------------------------------
+
+def rmsnorm(x, weight=None, eps: float = 1e-6):
+    x = np.asarray(x, dtype=np.float64)
+    y = x / np.sqrt((x * x).mean(-1, keepdims=True) + eps)
+    return y if weight is None else y * np.asarray(weight, dtype=np.float64)
+
+
+def silu_mul(gate_up, inter: int):
+    gu = np.asarray(gate_up, dtype=np.float64)
+    g, u = gu[..., :inter], gu[..., inter:2 * inter]
+    return g / (1.0 + np.exp(-g)) * u
+
+
+def rope_tables(head_dim: int, positions: int, theta: float = 10000.0):
+    half = head_dim // 2
+    inv = 1.0 / (theta ** (np.arange(half, dtype=np.float64) * 2.0 / head_dim))
+    ang = np.arange(positions, dtype=np.float64)[:, None] * inv[None, :]
+    return np.cos(ang), np.sin(ang)
+
+
+def rope_rotate_half(x, cos, sin):
+    """x [..., head_dim]; cos / sin [head_dim / 2] of the position: (x1, x2) -> (x1 c - x2 s, x2 c + x1 s)."""
+    half = x.shape[-1] // 2
+    x1, x2 = x[..., :half], x[..., half:]
+    return np.concatenate([x1 * cos - x2 * sin, x2 * cos + x1 * sin], axis=-1)
+
+
+def attention_decode(qkv, kcache, vcache, pos: int, n_heads: int, n_kv_heads: int, head_dim: int, cos, sin,
+                     q_norm_w=None, k_norm_w=None, eps: float = 1e-6):
+    """One token of grouped-query attention with a KV cache (float64).  qkv [(Hq + 2 Hkv) hd]; caches
+    [Hkv, T, hd] hold positions < pos (position pos is written here).  Returns (out [Hq hd], k_new, v_new)."""
+    qkv = np.asarray(qkv, dtype=np.float64)
+    q = qkv[: n_heads * head_dim].reshape(n_heads, head_dim)
+    k = qkv[n_heads * head_dim:(n_heads + n_kv_heads) * head_dim].reshape(n_kv_heads, head_dim)
+    v = qkv[(n_heads + n_kv_heads) * head_dim:].reshape(n_kv_heads, head_dim)
+    if q_norm_w is not None:
+        q, k = rmsnorm(q, q_norm_w, eps), rmsnorm(k, k_norm_w, eps)
+    q, k = rope_rotate_half(q, cos[pos], sin[pos]), rope_rotate_half(k, cos[pos], sin[pos])
+    K = np.asarray(kcache, dtype=np.float64)[:, :pos + 1].copy()
+    V = np.asarray(vcache, dtype=np.float64)[:, :pos + 1].copy()
+    K[:, pos], V[:, pos] = k, v
+    n_rep = n_heads // n_kv_heads
+    out = np.empty((n_heads, head_dim))
+    for h in range(n_heads):
+        s = K[h // n_rep] @ q[h] / np.sqrt(head_dim)
+        p = np.exp(s - s.max())
+        out[h] = (p / p.sum()) @ V[h // n_rep]
+    return out.reshape(-1), k, v

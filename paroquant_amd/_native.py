@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 4
+PARO_ABI_VERSION = 5
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
@@ -37,6 +37,9 @@ EXPORTS = (
     "paro_workspace_status",
     "paro_gemv_launch_shape",
     "paro_w4a16_gemv",
+    "paro_w4a16_gemv_fused",
+    "paro_attn_decode_lds_bytes",
+    "paro_attn_decode",
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
     "paro_dequant_packed",
@@ -65,6 +68,14 @@ class ParoLinearDesc(Structure):
         ("rmat", c_void_p),
     ]
 
+
+class ParoFusion(Structure):
+    """``paro_fusion_t`` (include/paro_abi.h)."""
+
+    _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p)]
+
+
+PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_MUL = 0, 1, 2
 
 _lib = None
 
@@ -111,6 +122,14 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemv.restype = c_int
     lib.paro_w4a16_gemv.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_int, c_int, c_int, c_void_p]
+    lib.paro_w4a16_gemv_fused.restype = c_int
+    lib.paro_w4a16_gemv_fused.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                          POINTER(ParoFusion), c_void_p]
+    lib.paro_attn_decode_lds_bytes.restype = c_int64
+    lib.paro_attn_decode_lds_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.paro_attn_decode.restype = c_int
+    lib.paro_attn_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.paro_w4a16_gemm.restype = c_int
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_void_p]

@@ -164,18 +164,37 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   return PARO_WS_COUNTER_BYTES + slabs + xrot + partial;
 }
 
-extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
-                               int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode,
-                               void* stream) {
-  using namespace paro;
+namespace paro {
+static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                     int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode,
+                     const paro_fusion_t* F, void* stream) {
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
+  const bool fused = F && (F->prologue != PARO_PROLOGUE_NONE || F->residual);
+  if (fused) {
+    if (F->prologue < PARO_PROLOGUE_NONE || F->prologue > PARO_PROLOGUE_SILU_MUL) return fail(PARO_ERR_INVALID, "unknown prologue %d", F->prologue);
+    if (rows > 4) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue is a decode path: at most 4 rows (got %lld)", (long long)rows);
+    if (L->krot > 8) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue needs the in-kernel rotation (krot <= 8)");
+    if (mode == 1) return fail(PARO_ERR_INVALID, "fused prologue / epilogue needs mode 0 (in-kernel rotation)");
+    mode = 0;
+    // sum(x^2) of the RMSNorm prologue is collected per workgroup: every workgroup must cover all of K
+    if (F->prologue == PARO_PROLOGUE_RMSNORM) {
+      if (ksplit > 1) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
+      ksplit = 1;
+    }
+    const int64_t min_stride = (F->prologue == PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
+    if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
+  }
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
   rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
   if (rc != PARO_OK) return rc;
+  if (fused) {
+    if (tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) tpw = 4;   // fused instantiations exist for 1 / 2 / 4 / 8 tiles
+    if (tpw == 8 && wv == 16) wv = 8;
+  }
   const int G = (int)(L->K / 128);
   hipStream_t st = (hipStream_t)stream;
 
@@ -202,6 +221,10 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
   static const int env_skew = getenv("PARO_GEMV_SKEW") ? atoi(getenv("PARO_GEMV_SKEW")) : 1;
   a.skew = env_skew;
+  a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
+  a.eps = fused ? F->eps : 0.f;
+  a.residual = fused ? (const unsigned short*)F->residual : nullptr;
+  a.xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue == PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
@@ -246,4 +269,16 @@ extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, i
   if (rc == PARO_ERR_NOT_RESIDENT) rc = PARO_ERR_UNSUPPORTED;
   if (rc != PARO_OK) return rc;
   return check_launch("paro_w4a16_gemv");
+}
+}  // namespace paro
+
+extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                               int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode,
+                               void* stream) {
+  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, tiles_per_wave, ksplit, waves, mode, nullptr, stream);
+}
+
+extern "C" int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                                     int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream) {
+  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, fusion, stream);
 }

@@ -49,6 +49,11 @@ struct GemvArgs {
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
   int skew;                              // 1: uneven unit split inside the workgroup (see the driver loop)
+  // ---- prologue / epilogue fusions (FUSED instantiations only; paro_w4a16_gemv_fused)
+  int prologue;                          // PARO_PROLOGUE_NONE / _RMSNORM / _SILU_MUL
+  float eps;                             // RMSNorm epsilon
+  long long xstride;                     // elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
+  const unsigned short* residual;        // [rows][N] added to the output, or null
   PartTable pt;
 };
 
@@ -58,7 +63,16 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 // tools/ablate_gemv.py, tools/timeline_gemv.py): 11 skips schedule + stages, 21 also the unpack + MFMA (pure
 // stream), 41 fetches the schedule but does not run the stages, 51 runs the stages without the cross-lane
 // fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps.
-template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD>
+// FUSED: the decode-layer fusions either side of the linear, selected at run time inside this
+// one extra instantiation so that the plain kernel's code is untouched:
+//   prologue RMSNORM   y = GEMV(x) * rsqrt(mean(x^2) + eps): the norm WEIGHT is folded into channel_scales at load
+//                      time, the scalar commutes with rotation and matmul.  sum(x^2) costs nothing extra: every
+//                      group of K is seeded by exactly one wave of the workgroup (K-split is refused for it).
+//   prologue SILU_MUL  x_k = silu(gate_k) * up_k computed in fp32 while seeding the rotation state, from the
+//                      gate_up projection's output [rows][2 K] (the MLX MoE path rotates the activation output the
+//                      same way before down_proj, mlx/modules.py:204-207).
+//   epilogue residual  y += residual[row][col] (the decoder's residual stream), in the final write.
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, bool FUSED = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -74,7 +88,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int RED_FLOATS = WAVES * TPW * MRT * 64;
   constexpr int WORK_BYTES = WAVES * XH_BYTES;
   constexpr int EX_BYTES = (PD / 10 == 6) ? WAVES * 256 : 0;   // diagnostic exchange slots
-  constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16;
+  constexpr int SS_BYTES = FUSED ? WAVES * MB * 4 : 0;        // per-wave sum(x^2) partials (RMSNorm prologue)
+  constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16 + SS_BYTES;
   // scale/zero words of a unit: one aligned vector load per 4 tiles when TPW is a power of two, else one
   // dword load per tile (TPW = 3, 5, 6, 7 exist so that wide outputs can be cut into ~256 column blocks)
   constexpr bool SZ_VEC = TPW == 1 || TPW == 2 || TPW == 4 || TPW == 8;
@@ -142,6 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
+    unsigned xu[FUSED ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
@@ -174,7 +190,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         const int rr = r < a.rows ? r : 0;  // clamp instead of branching: keeps the load count static
-        b.xv[r] = *(const unsigned*)(a.x + (int64_t)rr * a.K + g * 128 + 2 * lane);
+        if constexpr (FUSED) {
+          const unsigned short* xr = a.x + (int64_t)rr * a.xstride + g * 128 + 2 * lane;
+          b.xv[r] = *(const unsigned*)xr;
+          // unconditional (static load count): without the SiLU*mul prologue it re-reads the same word
+          b.xu[r] = *(const unsigned*)(xr + (a.prologue == PARO_PROLOGUE_SILU_MUL ? a.K : 0));
+        } else {
+          b.xv[r] = *(const unsigned*)(a.x + (int64_t)rr * a.K + g * 128 + 2 * lane);
+        }
       }
     }
   };
@@ -210,13 +233,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // state grows by 2^14 per stage; exact power-of-two bookkeeping keeps it in range: the state starts at
   // 2^-63 x, and the final stage's coefficients carry 2^(49 - 14 krot).
   // start: channels 2l, 2l+1 of the group (one coalesced load), times their channel scales
+  float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
+#pragma unroll
+  for (int r = 0; r < (FUSED ? MB : 1); ++r) ssq[r] = 0.f;
   auto seed = [&](const PBuf& b, float (&sa)[MB], float (&sb)[MB]) {
     const float c0 = f16_bits_to_f32(b.csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(b.csv >> 16) * 0x1p-63f;
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
       const unsigned xv = r < a.rows ? b.xv[r] : 0u;
-      sa[r] = A::to_f32(xv & 0xffffu) * c0;
-      sb[r] = A::to_f32(xv >> 16) * c1;
+      float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
+      if constexpr (FUSED) {
+        if (a.prologue == PARO_PROLOGUE_SILU_MUL) {
+          const unsigned uv = r < a.rows ? b.xu[r] : 0u;
+          // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x
+          x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x0));
+          x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x1));
+        } else if (a.prologue == PARO_PROLOGUE_RMSNORM) {
+          ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
+        }
+      }
+      sa[r] = x0 * c0;
+      sb[r] = x1 * c1;
     }
   };
   const float final_scale = __builtin_ldexpf(1.0f, 49 - 14 * a.krot);
@@ -329,6 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
   };
 
+  bool has_work_any = true;
   {
     // One unit at a time, distance-1 software pipeline.
     // (Tried and measured equal or slower, MI355X, every Llama-3-8B / Qwen3-4B shape: deeper prefetch
@@ -419,6 +457,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int r = 0; r < MRT; ++r) acc[j][r] = 0.f;
     }
+    has_work_any = has_work;
   }
 
   if constexpr (DIAG == 3) ts[5] = stamp_after(acc[0][0]);  // all units done
@@ -430,6 +469,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   for (int j = 0; j < TPW; ++j)
 #pragma unroll
     for (int r = 0; r < MRT; ++r) red[((wave * TPW + j) * MRT + r) * 64 + lane] = acc[j][r];
+  float* ssl = (float*)(lds + LDS_BYTES - SS_BYTES);   // [wave][row]
+  if constexpr (FUSED) {
+    if (a.prologue == PARO_PROLOGUE_RMSNORM) {
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        float v = has_work_any ? ssq[r] : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) ssl[wave * MB + r] = v;
+      }
+    }
+  }
   __syncthreads();
   if constexpr (DIAG == 3) ts[8] = __builtin_amdgcn_s_memtime();   // partials staged
 
@@ -443,7 +494,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MRT * 64];
     const int col = (tile0 + j) * 16 + (el & 15);
     if (direct) {
+      if constexpr (FUSED) {
+        if (a.prologue == PARO_PROLOGUE_RMSNORM) {
+          float ss = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) ss += ssl[w * MB + b];
+          v *= __builtin_amdgcn_rsqf(ss / (float)a.K + a.eps);
+        }
+      }
       if (a.bias) v += A::to_f32(a.bias[col]);
+      if constexpr (FUSED) {
+        if (a.residual) v += A::to_f32(a.residual[(int64_t)b * a.N + col]);
+      }
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     } else if (ks != a.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
@@ -475,6 +537,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         }
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
+      if constexpr (FUSED) {
+        if (a.residual) v += A::to_f32(a.residual[(int64_t)b * a.N + col]);
+      }
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     }
   }
@@ -527,6 +592,19 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
   return PARO_OK;
 }
 
+template <typename AT, int TPW, int MB, bool PREROT>
+int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if constexpr (!PREROT && MB <= 4 && tpw_is_pow2(TPW)) {
+    if constexpr (TPW < 8) {
+      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, true>, 1024>(a, grid, st);
+    }
+    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, true>, 512>(a, grid, st);
+    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, true>, 256>(a, grid, st);
+  }
+  return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue: not built for %d tiles per wave x %d waves x %d rows%s", TPW, waves,
+              MB, PREROT ? " (pre-rotated mode)" : "");
+}
+
 template <typename AT, int TPW, int MB, bool PREROT, int PD>
 int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (tpw_is_pow2(TPW) && TPW < 8 && MB <= 4) {   // 8 tiles x 16 waves does not fit 128 VGPRs
@@ -552,6 +630,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
+  if (a.prologue != PARO_PROLOGUE_NONE || a.residual) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

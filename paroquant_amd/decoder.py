@@ -1,0 +1,323 @@
+"""Decode harness / generator on the fused kernels (SURVEY 8 rows f2 + f3).
+
+What the reference does for end-to-end decode: ``TransformersGenerator`` drives HF ``generate()`` on a model whose
+quantised linears are ``RotateQuantizedLinear`` (transformers/generator.py:37-67), ``cli/benchmark.py:8-26`` times
+2 warm-up + 5 runs of 128 greedy tokens, and ``BaseGenerator.generate`` defines
+``tps = new_tokens / (t_end - t_first_token)`` (inference/base.py:62-77).  Per decoder layer and token that is
+RMSNorm, 3 x (rotate + GEMM) + cat, rope, attention, rotate + GEMM, residual add, RMSNorm, 2 x (rotate + GEMM) + cat,
+SiLU, mul, rotate + GEMM, residual add -- about 25 launches.
+
+Here a Llama / Qwen3-style decoder layer is FIVE launches, all captured with the rest of the step in one HIP graph:
+
+    qkv      fused GEMV, RMSNorm prologue (input_layernorm weight folded into the channel scales)     ops.w4a16_gemv_fused
+    attn     q/k norm + RoPE + KV append + GQA over the cache                                      ops.attn_decode
+    o        fused GEMV, residual epilogue
+    gate_up  fused GEMV, RMSNorm prologue (post_attention_layernorm folded)
+    down     fused GEMV, SiLU(gate) * up prologue, residual epilogue
+
+Embedding lookup, final norm, the (unquantised, fp16) lm_head and the greedy argmax are plain torch ops inside the
+same graph; the token and position live in device tensors, so a replay is one whole token with no host round trip.
+Prefill runs the same weights through ``PackedParoWeights.apply`` (MFMA GEMM) with torch attention.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _native as nat
+from . import ops
+from .linear import PackedParoWeights
+
+
+@dataclass
+class DecoderConfig:
+    hidden: int
+    inter: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    n_layers: int
+    vocab: int
+    rms_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    qk_norm: bool = False          # Qwen3: per-head RMSNorm on q and k before RoPE
+    max_positions: int = 2048
+
+    @classmethod
+    def from_hf(cls, c: dict, max_positions: int = 2048) -> "DecoderConfig":
+        c = c.get("text_config", c)
+        hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
+        rope_theta = c.get("rope_theta") or (c.get("rope_parameters") or {}).get("rope_theta", 10000.0)
+        return cls(c["hidden_size"], c["intermediate_size"], c["num_attention_heads"],
+                   c.get("num_key_value_heads", c["num_attention_heads"]), hd, c["num_hidden_layers"], c["vocab_size"],
+                   c.get("rms_norm_eps", 1e-6), float(rope_theta), c.get("model_type", "") in ("qwen3",), max_positions)
+
+
+MODEL_CONFIGS = {
+    # name: (hidden, inter, heads, kv_heads, head_dim, layers, vocab, qk_norm, rope_theta)
+    "qwen3-0.6b": (1024, 3072, 16, 8, 128, 28, 151936, True, 1e6),
+    "qwen3-4b": (2560, 9728, 32, 8, 128, 36, 151936, True, 1e6),
+    "llama3-8b": (4096, 14336, 32, 8, 128, 32, 128256, False, 5e5),
+}
+
+
+def named_config(name: str, max_positions: int = 2048) -> DecoderConfig:
+    h, i, nh, nkv, hd, L, V, qk, th = MODEL_CONFIGS[name]
+    return DecoderConfig(h, i, nh, nkv, hd, L, V, 1e-6, th, qk, max_positions)
+
+
+def rope_table(cfg: DecoderConfig, device) -> torch.Tensor:
+    """fp32 [max_positions, head_dim]: cos(pos * inv_freq) then sin(...), inv_freq[d] = theta^(-2d / head_dim)
+    (the default rotary embedding of HF Llama / Qwen3)."""
+    half = cfg.head_dim // 2
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, half, dtype=torch.float32, device=device) * 2.0 / cfg.head_dim))
+    ang = torch.arange(cfg.max_positions, dtype=torch.float32, device=device)[:, None] * inv[None, :]
+    return torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+
+
+class _Layer:
+    __slots__ = ("qkv", "o", "gate_up", "down", "q_norm", "k_norm", "kcache", "vcache", "in_norm", "post_norm")
+
+
+class ParoDecoderLM:
+    """Greedy decoder over ParoQuant linears.  Build with :meth:`from_checkpoint` (an HF ``*-PARO`` directory,
+    Llama / Qwen3 naming) or :meth:`random` (synthetic weights of a named architecture, for benchmarks)."""
+
+    def __init__(self, cfg: DecoderConfig, device, dtype=torch.float16):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.layers: List[_Layer] = []
+        self.embed = self.lm_head = self.final_norm = None
+        self.rope = rope_table(cfg, self.device)
+        self._graph = None
+
+    # ------------------------------------------------------------------ construction
+    def _alloc_cache(self, layer: _Layer):
+        c = self.cfg
+        layer.kcache = torch.zeros(c.n_kv_heads, c.max_positions, c.head_dim, dtype=self.dtype, device=self.device)
+        layer.vcache = torch.zeros_like(layer.kcache)
+
+    @classmethod
+    def random(cls, name_or_cfg, device, n_layers: Optional[int] = None, max_positions: int = 1024, seed: int = 0,
+               vocab: Optional[int] = None) -> "ParoDecoderLM":
+        import bench  # synthetic checkpoint-format layers (repo root on sys.path in tools / tests / bench)
+        cfg = named_config(name_or_cfg, max_positions) if isinstance(name_or_cfg, str) else name_or_cfg
+        if n_layers:
+            cfg.n_layers = n_layers
+        if vocab:
+            cfg.vocab = vocab
+        self = cls(cfg, device)
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        q, kv = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+        rnd = lambda *s: torch.randn(*s, device=self.device, generator=gen)
+        for _ in range(cfg.n_layers):
+            L = _Layer()
+            L.qkv = bench.synth_packed(cfg.hidden, [q, kv, kv], self.device, gen)
+            L.o = bench.synth_packed(q, [cfg.hidden], self.device, gen)
+            L.gate_up = bench.synth_packed(cfg.hidden, [cfg.inter, cfg.inter], self.device, gen)
+            L.down = bench.synth_packed(cfg.inter, [cfg.hidden], self.device, gen)
+            L.in_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
+            L.post_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
+            L.qkv.fold_norm_weight(L.in_norm)
+            L.gate_up.fold_norm_weight(L.post_norm)
+            L.q_norm = (1.0 + 0.05 * rnd(cfg.head_dim)).to(self.dtype) if cfg.qk_norm else None
+            L.k_norm = (1.0 + 0.05 * rnd(cfg.head_dim)).to(self.dtype) if cfg.qk_norm else None
+            self._alloc_cache(L)
+            self.layers.append(L)
+        self.embed = (rnd(cfg.vocab, cfg.hidden) * 0.5).to(self.dtype)
+        self.lm_head = (rnd(cfg.vocab, cfg.hidden) * (cfg.hidden ** -0.5)).to(self.dtype)
+        self.final_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
+        self._static()
+        return self
+
+    @classmethod
+    def from_checkpoint(cls, path: str, device, max_positions: int = 2048) -> "ParoDecoderLM":
+        """Load an HF ``*-PARO`` checkpoint directory (config.json + safetensors; tensor names of cli/convert.py:264-277
+        under the usual ``model.layers.N.{self_attn,mlp}.*_proj`` paths).  q/k/v and gate/up are merged into one
+        fused linear each (3 / 2 rotations), the layer norms are folded into the channel scales."""
+        from safetensors import safe_open
+        with open(os.path.join(path, "config.json")) as f:
+            hf = json.load(f)
+        cfg = DecoderConfig.from_hf(hf, max_positions)
+        self = cls(cfg, device)
+        t: Dict[str, torch.Tensor] = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                with safe_open(os.path.join(path, fn), framework="pt") as f:
+                    for k in f.keys():
+                        t[k] = f.get_tensor(k)
+        dev = self.device
+
+        def merged(prefix: str, names) -> PackedParoWeights:
+            g = lambda n, s: t[f"{prefix}.{n}.{s}"].to(dev)
+            sizes = [int(t[f"{prefix}.{n}.scales"].shape[1]) for n in names]
+            qw = torch.cat([g(n, "qweight") for n in names], dim=1)
+            qz = torch.cat([g(n, "qzeros") for n in names], dim=1)
+            sc = torch.cat([g(n, "scales") for n in names], dim=1)
+            th = torch.stack([g(n, "theta") for n in names])
+            pr = torch.stack([g(n, "pairs") for n in names])
+            cs = torch.stack([g(n, "channel_scales").reshape(1, -1) for n in names])
+            return PackedParoWeights(qw, qz, sc, th, pr, cs, sizes)
+
+        for l in range(cfg.n_layers):
+            p = f"model.layers.{l}"
+            L = _Layer()
+            L.qkv = merged(f"{p}.self_attn", ["q_proj", "k_proj", "v_proj"])
+            L.o = merged(f"{p}.self_attn", ["o_proj"])
+            L.gate_up = merged(f"{p}.mlp", ["gate_proj", "up_proj"])
+            L.down = merged(f"{p}.mlp", ["down_proj"])
+            L.in_norm = t[f"{p}.input_layernorm.weight"].to(dev, self.dtype)
+            L.post_norm = t[f"{p}.post_attention_layernorm.weight"].to(dev, self.dtype)
+            L.qkv.fold_norm_weight(L.in_norm)
+            L.gate_up.fold_norm_weight(L.post_norm)
+            qn, kn = f"{p}.self_attn.q_norm.weight", f"{p}.self_attn.k_norm.weight"
+            L.q_norm = t[qn].to(dev, self.dtype) if qn in t else None
+            L.k_norm = t[kn].to(dev, self.dtype) if kn in t else None
+            self._alloc_cache(L)
+            self.layers.append(L)
+        self.cfg.qk_norm = self.layers[0].q_norm is not None
+        self.embed = t["model.embed_tokens.weight"].to(dev, self.dtype)
+        self.lm_head = (t["lm_head.weight"] if "lm_head.weight" in t else t["model.embed_tokens.weight"]).to(dev, self.dtype)
+        self.final_norm = t["model.norm.weight"].to(dev, self.dtype)
+        self._static()
+        return self
+
+    def _static(self):
+        """Static buffers of the captured decode step (the graph replays on them)."""
+        c, dev, dt = self.cfg, self.device, self.dtype
+        self.tok = torch.zeros(1, dtype=torch.long, device=dev)        # current token id
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)       # its position
+        self.h = torch.zeros(1, c.hidden, dtype=dt, device=dev)        # residual stream (ping)
+        self.h2 = torch.zeros(1, c.hidden, dtype=dt, device=dev)       # residual stream (pong)
+        qkv_w = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim
+        self.qkv_buf = torch.zeros(1, qkv_w, dtype=dt, device=dev)
+        self.attn_buf = torch.zeros(1, c.n_heads * c.head_dim, dtype=dt, device=dev)
+        self.gu_buf = torch.zeros(1, 2 * c.inter, dtype=dt, device=dev)
+        self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
+        self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
+        self.bytes_per_token = sum(pk.nbytes() for L in self.layers for pk in (L.qkv, L.o, L.gate_up, L.down))
+
+    # ------------------------------------------------------------------ one decode token (capturable)
+    def _final(self, h: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        x = h.float()
+        x = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + c.rms_eps)).to(self.dtype) * self.final_norm
+        return torch.matmul(x, self.lm_head.t())
+
+    def decode_step(self) -> None:
+        """Consume ``self.tok`` at position ``self.pos``; leave the logits in ``self.logits``, the greedy next token in
+        ``self.tok`` and advance ``self.pos``.  No host synchronisation, no allocation by the fused ops."""
+        c = self.cfg
+        R, S = nat.PROLOGUE_RMSNORM, nat.PROLOGUE_SILU_MUL
+        torch.index_select(self.embed, 0, self.tok, out=self.h)
+        h, h2 = self.h, self.h2
+        for L in self.layers:
+            ops.w4a16_gemv_fused(h, L.qkv, R, c.rms_eps, out=self.qkv_buf)
+            ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, c.n_heads, c.n_kv_heads, c.head_dim,
+                            L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf)
+            ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                     # h2 = h + o(attn)
+            ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
+            ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                    # h = h2 + down(act)
+        torch.matmul(self._final_norm(h), self.lm_head.t(), out=self.logits)
+        self.out_tokens.index_copy_(0, self.pos.long(), self.tok)
+        torch.argmax(self.logits, dim=-1, out=self.tok)
+        self.pos.add_(1)
+
+    def _final_norm(self, h: torch.Tensor) -> torch.Tensor:
+        x = h.float()
+        return (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.cfg.rms_eps)).to(self.dtype) * self.final_norm
+
+    def capture(self) -> None:
+        """Capture :meth:`decode_step` in a HIP graph (one warm-up on a side stream first, as torch requires)."""
+        tok0, pos0 = self.tok.clone(), self.pos.clone()
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.decode_step()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self.tok.copy_(tok0); self.pos.copy_(pos0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.decode_step()
+        self.tok.copy_(tok0); self.pos.copy_(pos0)
+        self._graph = g
+
+    # ------------------------------------------------------------------ prefill (MFMA GEMM path + torch attention)
+    @torch.no_grad()
+    def prefill(self, ids: torch.Tensor) -> torch.Tensor:
+        """Run the prompt ``ids`` [T] through the model, fill the KV caches, return the logits of the last position and
+        set (tok, pos) for the first decode step."""
+        c, dt = self.cfg, self.dtype
+        T = int(ids.numel())
+        if T > c.max_positions:
+            raise ValueError("prompt longer than max_positions")
+        h = self.embed[ids.to(self.device)]                                           # [T, hidden]
+        rs = lambda x: torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + c.rms_eps)
+        half = c.head_dim // 2
+        cos = self.rope[:T, :half].to(dt)[:, None, :]
+        sin = self.rope[:T, half:].to(dt)[:, None, :]
+
+        def rope(x):                                                                  # [T, H, hd]
+            x1, x2 = x[..., :half], x[..., half:]
+            return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
+
+        def headnorm(x, w):
+            return x if w is None else ((x.float() * rs(x)).to(dt) * w)
+
+        for L in self.layers:
+            qkv = (L.qkv.apply(h).float() * rs(h)).to(dt)          # norm weight is folded into the channel scales
+            q, k, v = qkv.split([c.n_heads * c.head_dim, c.n_kv_heads * c.head_dim, c.n_kv_heads * c.head_dim], dim=-1)
+            q = rope(headnorm(q.view(T, c.n_heads, c.head_dim), L.q_norm))
+            k = rope(headnorm(k.view(T, c.n_kv_heads, c.head_dim), L.k_norm))
+            v = v.view(T, c.n_kv_heads, c.head_dim)
+            L.kcache[:, :T] = k.transpose(0, 1)
+            L.vcache[:, :T] = v.transpose(0, 1)
+            att = torch.nn.functional.scaled_dot_product_attention(
+                q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None], is_causal=True,
+                enable_gqa=c.n_heads != c.n_kv_heads)[0].transpose(0, 1).reshape(T, -1)
+            h = h + L.o.apply(att.contiguous())
+            gu = (L.gate_up.apply(h).float() * rs(h)).to(dt)
+            act = torch.nn.functional.silu(gu[:, :c.inter]) * gu[:, c.inter:]
+            h = h + L.down.apply(act.contiguous())
+        logits = torch.matmul(self._final_norm(h[-1:]), self.lm_head.t())
+        self.out_tokens[:T] = ids.to(self.device)
+        self.tok.copy_(torch.argmax(logits, dim=-1))
+        self.pos.fill_(T)
+        return logits
+
+    # ------------------------------------------------------------------ generation + the reference's benchmark protocol
+    @torch.no_grad()
+    def generate(self, ids: torch.Tensor, max_new_tokens: int, use_graph: bool = True):
+        """Greedy generation.  Returns (tokens [T + new], stats) with the reference's accounting
+        (inference/base.py:62-77): ttft = first token latency, tps = (new - 1) decode tokens / (t_end - t_first)."""
+        c = self.cfg
+        T = int(ids.numel())
+        n_new = min(max_new_tokens, c.max_positions - T)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        self.prefill(ids)
+        torch.cuda.synchronize(self.device)
+        t_first = time.perf_counter()
+        if use_graph and self._graph is None:
+            tok, pos = self.tok.clone(), self.pos.clone()
+            self.capture()
+            self.tok.copy_(tok); self.pos.copy_(pos)
+            torch.cuda.synchronize(self.device)
+            t_first = time.perf_counter()          # graph capture is a one-time cost, not decode time
+        for _ in range(n_new - 1):
+            if use_graph:
+                self._graph.replay()
+            else:
+                self.decode_step()
+        torch.cuda.synchronize(self.device)
+        t_end = time.perf_counter()
+        self.out_tokens.index_copy_(0, self.pos.long(), self.tok)
+        toks = self.out_tokens[: T + n_new].clone()
+        dec = max(n_new - 1, 1)
+        return toks, {"prompt_tokens": T, "new_tokens": n_new, "ttft_s": t_first - t0,
+                      "decode_tokens_per_s": dec / max(t_end - t_first, 1e-9), "ms_per_token": (t_end - t_first) * 1e3 / dec}

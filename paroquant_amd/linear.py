@@ -142,6 +142,16 @@ class PackedParoWeights:
                                            self.channel_scales, b, self.partition_sizes, self.workspace,
                                            self.wq_order, rmat)
 
+    def fold_norm_weight(self, weight: torch.Tensor) -> "PackedParoWeights":
+        """Fold the weight of the RMSNorm that feeds this linear into the channel scales
+        (``cs'[p, k] = cs[p, k] * w[k]``, fp32 product rounded once): with it the whole norm in front of the linear
+        reduces to the scalar ``rsqrt(mean(x^2) + eps)`` that the fused GEMV applies (``ops.w4a16_gemv_fused``,
+        prologue RMSNORM).  Call once, after loading."""
+        w = weight.to(self.channel_scales.device).float().view(1, self.K)
+        self.channel_scales = (self.channel_scales.float() * w).to(torch.float16).contiguous()
+        self._rmat = {}
+        return self
+
     def stream_buffers(self):
         """The buffers a decode launch streams from HBM (what ``ops.prefetch`` should touch for this layer)."""
         return [self.wq, self.sz, self.rot]

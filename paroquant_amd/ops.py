@@ -284,6 +284,56 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
     return out
 
 
+def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode-layer fusions around one fused linear (``paro_w4a16_gemv_fused``; rows <= 4):
+    ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
+    ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
+    gate_up output ``[rows, 2 K]`` and the linear consumes ``silu(gate) * up``; ``residual [rows, N]`` is added to
+    the output.  ``out`` may be given (e.g. a static buffer of a captured decode step)."""
+    lib = nat.load()
+    K, N = pk.K, pk.N
+    width = 2 * K if prologue == nat.PROLOGUE_SILU_MUL else K
+    if x.size(-1) != width:
+        raise ValueError(f"x must have {width} columns for this prologue, got {x.size(-1)}")
+    x2 = x.reshape(-1, width)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.size(0)
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"expected float16 or bfloat16 activations, got {x.dtype}")
+    y = out if out is not None else torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N or not residual.is_contiguous()):
+        raise ValueError("residual must be a contiguous [rows, N] tensor of the activation dtype")
+    d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                  pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order)
+    f = nat.ParoFusion()
+    f.prologue, f.eps, f.x_stride = int(prologue), float(eps), int(x2.stride(0))
+    f.residual = residual.data_ptr() if residual is not None else None
+    ws = pk.workspace
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                            ws.numel() * ws.element_size(), ctypes.byref(f), nat.current_stream_ptr(x.device)))
+    return y
+
+
+def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, rope: torch.Tensor,
+                n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decoder layer's batch-1 attention in one launch (``paro_attn_decode``): q/k norm + RoPE + KV-cache append at
+    ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache`` / ``vcache``: [n_kv_heads, T_max, head_dim]."""
+    lib = nat.load()
+    T_max = kcache.size(1)
+    y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        nat.check(lib.paro_attn_decode(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(),
+                                       rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
+                                       None if k_norm_w is None else k_norm_w.data_ptr(), float(eps), float(head_dim) ** -0.5,
+                                       n_heads, n_kv_heads, head_dim, T_max, nat.dtype_code(qkv.dtype),
+                                       nat.current_stream_ptr(qkv.device)))
+    return y
+
+
 def prefetch(tensors, workgroups: int = 64, checksum: Optional[torch.Tensor] = None) -> None:
     """Pull the given device buffers into the Infinity Cache on the CURRENT stream (``paro_prefetch``): one dword per
     128-byte line is touched and discarded.  Call it on a side stream of a captured decode step for the packed

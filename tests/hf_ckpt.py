@@ -13,10 +13,11 @@ LINEARS = (("self_attn.q_proj", "h", "q"), ("self_attn.k_proj", "h", "kv"), ("se
            ("self_attn.o_proj", "q", "h"), ("mlp.gate_proj", "h", "i"), ("mlp.up_proj", "h", "i"), ("mlp.down_proj", "i", "h"))
 
 
-def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=128, seed=0):
+def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=128, seed=0,
+                          model_type="llama", head_dim=None):
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
-    hd = hidden // heads
+    hd = head_dim or hidden // heads
     dims = {"h": hidden, "q": heads * hd, "kv": kv_heads * hd, "i": inter}
     rng = np.random.default_rng(seed)
     f16 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.float16)
@@ -28,6 +29,9 @@ def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2,
         pre = f"model.layers.{l}."
         tensors[pre + "input_layernorm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hidden))
         tensors[pre + "post_attention_layernorm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hidden))
+        if model_type == "qwen3":
+            tensors[pre + "self_attn.q_norm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hd))
+            tensors[pre + "self_attn.k_norm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hd))
         for name, kin, kout in LINEARS:
             L = po.make_layer(seed * 1000 + l * 10 + len(oracle_layers), dims[kin], [dims[kout]])
             oracle_layers[pre + name] = L
@@ -38,7 +42,7 @@ def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2,
             tensors[pre + name + ".pairs"] = torch.from_numpy(L["pairs"][0])
             tensors[pre + name + ".channel_scales"] = torch.from_numpy(L["channel_scales"][0]).reshape(1, -1)
     save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(path, "model.safetensors"))
-    cfg = {"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_size": hidden, "intermediate_size": inter,
+    cfg = {"architectures": ["Qwen3ForCausalLM" if model_type == "qwen3" else "LlamaForCausalLM"], "model_type": model_type, "hidden_size": hidden, "intermediate_size": inter,
            "num_hidden_layers": layers, "num_attention_heads": heads, "num_key_value_heads": kv_heads, "head_dim": hd,
            "vocab_size": vocab, "max_position_embeddings": 128, "rms_norm_eps": 1e-6, "rope_theta": 10000.0,
            "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False, "mlp_bias": False,

@@ -825,3 +825,125 @@ def test_hf_from_pretrained_end_to_end(dev, tmp_path):
     with torch.no_grad():
         gen = model.generate(ids, max_new_tokens=4, do_sample=False)
     assert gen.shape == (1, 13)
+
+
+# ---------------------------------------------------------------- f3: fused prologue / epilogue of the decode GEMV
+
+@pytest.mark.parametrize("K,sizes", [(2560, [4096, 1024, 1024]), (2560, [9728, 9728]), (1024, [3072, 3072]), (256, [48, 16])])
+@pytest.mark.parametrize("rows", [1, 3])
+def test_fused_rmsnorm_prologue(dev, K, sizes, rows):
+    """y = linear(rmsnorm(x) * w): the norm weight folded into the channel scales, the rsqrt scalar applied in the
+    kernel from the sum(x^2) it gathers while seeding the rotation -- against the oracle on the explicitly normalised x."""
+    from paroquant_amd import ops, _native as nat
+    L = po.make_layer(K + rows, K, sizes)
+    rng = np.random.default_rng(K)
+    w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    x = (rng.standard_normal((rows, K)) * 3.0).astype(np.float16)
+    pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+    res = rng.standard_normal((rows, sum(sizes))).astype(np.float16)
+    y = ops.w4a16_gemv_fused(_t(x, dev), pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=_t(res, dev))
+    xn = po.rmsnorm(x, w, 1e-6)
+    ideal = po.paro_linear_merged(xn, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, None, ideal=True) + res.astype(np.float64)
+    assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    # without the residual, and a call through a strided view of a wider buffer
+    wide = torch.zeros(rows, K + 64, device=dev, dtype=torch.float16)
+    wide[:, :K] = _t(x, dev)
+    y2 = ops.w4a16_gemv_fused(wide[:, :K], pk, nat.PROLOGUE_RMSNORM, 1e-6)
+    assert po.rel_err(_np(y2), ideal - res.astype(np.float64)) < TIGHT_F16
+
+
+@pytest.mark.parametrize("K,N", [(9728, 2560), (3072, 1024), (14336, 4096), (512, 48)])
+@pytest.mark.parametrize("rows", [1, 4])
+def test_fused_silu_mul_prologue_and_residual(dev, K, N, rows):
+    """down_proj with the SiLU(gate) * up prologue on the merged gate_up output and the residual epilogue (K-split
+    launch shapes included: 9728 -> 2560 and 14336 -> 4096 resolve to t4 k4 w8)."""
+    from paroquant_amd import ops, _native as nat
+    L = po.make_layer(K + N + rows, K, [N])
+    rng = np.random.default_rng(N)
+    gu = rng.standard_normal((rows, 2 * K)).astype(np.float16)
+    res = rng.standard_normal((rows, N)).astype(np.float16)
+    pk = _packed(L, dev)
+    y = ops.w4a16_gemv_fused(_t(gu, dev), pk, nat.PROLOGUE_SILU_MUL, residual=_t(res, dev))
+    act = po.silu_mul(gu, K)
+    ideal = po.paro_linear_merged(act, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], [N], None, ideal=True) + res.astype(np.float64)
+    assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    # residual only (no prologue) == plain linear + residual
+    x = rng.standard_normal((rows, K)).astype(np.float16)
+    y3 = ops.w4a16_gemv_fused(_t(x, dev), pk, nat.PROLOGUE_NONE, residual=_t(res, dev))
+    assert torch.equal(y3, (pk.apply(_t(x, dev)).float() + _t(res, dev).float()).half()) or \
+        po.rel_err(_np(y3), _np(pk.apply(_t(x, dev))) + res.astype(np.float64)) < 1e-3
+    torch.cuda.synchronize()
+    ops.check_workspace(pk.workspace)
+    with pytest.raises(RuntimeError, match="at most 4 rows"):
+        ops.w4a16_gemv_fused(torch.zeros(5, 2 * K, device=dev, dtype=torch.float16), pk, nat.PROLOGUE_SILU_MUL)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,qk_norm", [(128, 8, 2, True), (64, 4, 2, False), (128, 32, 8, True), (128, 4, 4, False)])
+@pytest.mark.parametrize("pos", [0, 5, 300, 1023])
+def test_attn_decode_matches_oracle(dev, hd, Hq, Hkv, qk_norm, pos):
+    """Decode attention (q/k norm + RoPE + KV append + GQA softmax) against the float64 oracle."""
+    from paroquant_amd import ops
+    rng = np.random.default_rng(hd + Hq + pos)
+    T = 1024
+    qkv = rng.standard_normal((Hq + 2 * Hkv) * hd).astype(np.float16)
+    kc = (rng.standard_normal((Hkv, T, hd))).astype(np.float16)
+    vc = (rng.standard_normal((Hkv, T, hd))).astype(np.float16)
+    qw = (1 + 0.2 * rng.standard_normal(hd)).astype(np.float16) if qk_norm else None
+    kw = (1 + 0.2 * rng.standard_normal(hd)).astype(np.float16) if qk_norm else None
+    cos, sin = po.rope_tables(hd, T, 1e4)
+    rope = torch.from_numpy(np.concatenate([cos, sin], axis=-1).astype(np.float32)).to(dev)
+    kct, vct = _t(kc, dev), _t(vc, dev)
+    out = ops.attn_decode(_t(qkv, dev), kct, vct, torch.tensor([pos], dtype=torch.int32, device=dev), rope, Hq, Hkv, hd,
+                          None if qw is None else _t(qw, dev), None if kw is None else _t(kw, dev), 1e-6)
+    ref, k_new, v_new = po.attention_decode(qkv, kc, vc, pos, Hq, Hkv, hd, cos, sin, qw, kw, 1e-6)
+    assert po.rel_err(_np(out), ref) < 4e-3
+    assert po.rel_err(_np(kct[:, pos]), k_new) < 2e-3 and po.rel_err(_np(vct[:, pos]), v_new) < 1e-6
+    if pos > 0:   # the rest of the cache is untouched
+        assert torch.equal(kct[:, :pos], _t(kc, dev)[:, :pos]) and torch.equal(vct[:, pos + 1:], _t(vc, dev)[:, pos + 1:])
+
+
+# ---------------------------------------------------------------- f2: the decode harness against HF on the same checkpoint
+
+@pytest.mark.parametrize("model_type,head_dim", [("llama", 64), ("qwen3", 128)])
+def test_decoder_harness_matches_hf(dev, tmp_path, model_type, head_dim):
+    """ParoDecoderLM (5 fused launches per layer, HIP-graph decode) against HF's own modelling code running our
+    RotateQuantizedLinear modules on the SAME synthetic PARO checkpoint: prefill logits, then greedy decode steps
+    (graph replays) against HF logits of the growing sequence."""
+    import paroquant_amd.hf_quantizer  # noqa: F401
+    from paroquant_amd.decoder import ParoDecoderLM
+    from tests.hf_ckpt import write_tiny_paro_llama
+    from transformers import AutoModelForCausalLM
+    write_tiny_paro_llama(str(tmp_path), hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=128,
+                          model_type=model_type, head_dim=head_dim, seed=3)
+    try:
+        hf = AutoModelForCausalLM.from_pretrained(str(tmp_path), dtype=torch.float16, device_map={"": "cuda:0"})
+    except TypeError:
+        hf = AutoModelForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.float16, device_map={"": "cuda:0"})
+    hf.eval()
+    lm = ParoDecoderLM.from_checkpoint(str(tmp_path), dev, max_positions=64)
+    assert lm.cfg.qk_norm == (model_type == "qwen3")
+    ids = torch.randint(0, 128, (11,), device=dev)
+    logits = lm.prefill(ids)
+    with torch.no_grad():
+        ref = hf(input_ids=ids[None]).logits[0, -1].float()
+    scale = ref.abs().max().item()
+    assert (logits[0].float() - ref).abs().max().item() < 2e-2 * scale
+    lm.capture()
+    seq = ids.clone()
+    for step in range(6):
+        tok = lm.tok.clone()
+        seq = torch.cat([seq, tok])
+        lm._graph.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = hf(input_ids=seq[None]).logits[0, -1].float()
+        got = lm.logits[0].float()
+        assert (got - ref).abs().max().item() < 3e-2 * ref.abs().max().item(), step
+        # greedy token agrees unless HF's own top-2 logits are closer than the tolerance
+        top2 = ref.topk(2).values
+        if (top2[0] - top2[1]).item() > 6e-2 * ref.abs().max().item():
+            assert int(lm.tok.item()) == int(ref.argmax().item())
+    toks, stats = ParoDecoderLM.from_checkpoint(str(tmp_path), dev, max_positions=64).generate(ids, 8)
+    assert toks.shape == (19,) and torch.equal(toks[:11], ids) and stats["new_tokens"] == 8
