@@ -231,12 +231,16 @@ int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t ro
  *   out     act_dtype [n_heads * head_dim]
  *   pos     int32 in DEVICE memory (a captured graph replays for every token)
  *   rope    fp32 [max_positions][head_dim]: cos then sin (head_dim / 2 each) of every position
- * head_dim in {64, 128}; n_heads / n_kv_heads <= 8; the scores of all positions live in LDS
- * (paro_attn_decode_lds_bytes(...) <= 160 KiB bounds max_positions). */
-int64_t paro_attn_decode_lds_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions);
+ * head_dim in {64, 128}; n_heads / n_kv_heads <= 8.  The grid is (KV heads) x (chunks of 256 positions) over
+ * max_positions, so that one captured graph serves every position; chunks beyond *pos exit at once.  With more than
+ * one active chunk the partial results are merged in-launch by the last workgroup of a KV head to arrive
+ * (ticket in `workspace`, agent-scope release / acquire, no spinning).
+ *   workspace  paro_attn_decode_workspace_bytes(...) bytes, zero-filled ONCE by the caller (the tickets return to zero). */
+int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions);
 int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
                      const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads, int n_kv_heads,
-                     int head_dim, int max_positions, int act_dtype, void* stream);
+                     int head_dim, int max_positions, int act_dtype, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 /* Weight prefetch for decode harnesses that know the NEXT layer (no reference counterpart -- the
  * reference leaves scheduling to vLLM / HF generate).  Touches one dword per 128-byte line of up to

@@ -38,7 +38,7 @@ EXPORTS = (
     "paro_gemv_launch_shape",
     "paro_w4a16_gemv",
     "paro_w4a16_gemv_fused",
-    "paro_attn_decode_lds_bytes",
+    "paro_attn_decode_workspace_bytes",
     "paro_attn_decode",
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
@@ -125,11 +125,12 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemv_fused.restype = c_int
     lib.paro_w4a16_gemv_fused.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                           POINTER(ParoFusion), c_void_p]
-    lib.paro_attn_decode_lds_bytes.restype = c_int64
-    lib.paro_attn_decode_lds_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.paro_attn_decode_workspace_bytes.restype = c_int64
+    lib.paro_attn_decode_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.paro_attn_decode.restype = c_int
     lib.paro_attn_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                     ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                                     c_void_p]
     lib.paro_w4a16_gemm.restype = c_int
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_void_p]

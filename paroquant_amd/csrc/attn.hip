@@ -4,11 +4,21 @@
 // here it exists so that a whole decode step is five launches per layer (qkv GEMV, this, o GEMV, gate_up GEMV,
 // down GEMV) inside one HIP graph, and the end-to-end tokens/s of north_star can be measured.
 //
-// One 256-thread workgroup per KV head (its n_rep = Hq / Hkv query heads share every K / V byte it reads).
-// The position comes from DEVICE memory (`pos`), so a captured graph replays for every token.
+// Grid = (KV heads, position chunks of 256).  A workgroup handles one chunk of one KV head for all of that head's
+// n_rep = Hq / Hkv query heads (they share every K / V byte): every global load of the chunk -- one K row per thread,
+// one channel pair of 64 V rows per thread -- is requested before anything else, scores one position per thread,
+// soft-max statistics through LDS, P V from the registers -- a CU ingests ~10 B / clock, so long contexts are spread over many CUs rather than one
+// workgroup per head.  With more than one active chunk the partial (max, sum, unnormalised output) triples go to
+// a workspace and the LAST workgroup of a KV head to arrive (agent-scope release -> ticket -> acquire; no spinning,
+// so no dependence on dispatch order) merges them.  The position comes from DEVICE memory, so one captured graph
+// replays for every token: the grid always covers max_positions, chunks beyond `pos` exit at once.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace paro {
+
+constexpr int kChunk = 256;
 
 struct AttnArgs {
   const unsigned short* qkv;   // [(Hq + 2 Hkv) * hd]: q heads, k heads, v heads of this token
@@ -19,33 +29,68 @@ struct AttnArgs {
   const float* rope;           // [T_max][hd]: cos[0 .. hd/2) then sin[0 .. hd/2) of every position
   const unsigned short* qnw;   // [hd] q-norm weight or null
   const unsigned short* knw;   // [hd] k-norm weight or null
+  float* part;                 // workspace: [Hkv][chunks][n_rep][hd + 2] partial results
+  unsigned* ticket;            // workspace: [Hkv] arrival counters (zero between launches)
   float eps, scale;
-  int Hq, Hkv, hd, T_max;
+  int Hq, Hkv, hd, T_max, chunks;
+  int dbg;                     // PARO_ATTN_DBG: stop after phase N (timing ablation; wrong results)
 };
 
-template <typename AT>
+// NREP = query heads per KV head rounded up to a power of two: a COMPILE-TIME bound, so that the score and P V
+// loops unroll without a branch per iteration (with a run-time bound every iteration became its own basic block and
+// paid the LDS latency of its probability reads: the P V phase alone took 18 us for 256 positions).  Padding heads
+// have zero queries and are never stored.
+template <typename AT, int HD, int NREP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   typedef Act<AT> A;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int hd = HD, half = HD / 2;
+  constexpr int GROUPS = 256 / half;           // thread = (group, channel pair) in the P V phase: 4 (hd 128) / 8 (hd 64)
+  constexpr int VN = kChunk / GROUPS;          // cache rows per thread in the P V phase
+  __shared__ __attribute__((aligned(16))) float qs[NREP * HD];        // [NREP][hd] roped queries * scale
+  __shared__ __attribute__((aligned(16))) float sc[NREP * kChunk];    // [NREP][chunk] scores -> probabilities (0 past the chunk)
+  __shared__ __attribute__((aligned(16))) float accs[GROUPS * NREP * HD];  // [groups][NREP][hd] partial outputs
+  __shared__ float knew[HD], red[8 * 8];
+  __shared__ unsigned last_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x;
-  const int hd = a.hd, half = hd >> 1;
+  const int h = blockIdx.x, s = blockIdx.y;
   const int n_rep = a.Hq / a.Hkv;
   const int pos = *a.pos;
-  const int T = pos + 1;
-  // LDS: q [n_rep][hd] f32 | knew [hd] f32 | vnew [hd] f32 | red [n_rep][8] f32 | acc [parts][n_rep][hd] f32 | sc [n_rep][T] f32
-  float* qs = (float*)smem;
-  float* knew = qs + n_rep * hd;
-  float* vnew = knew + hd;
-  float* red = vnew + hd;
-  const int parts = 256 / hd;
-  float* accs = red + n_rep * 8;
-  float* sc = accs + parts * n_rep * hd;
+  const int p0 = s * kChunk;
+  if (p0 > pos) return;                               // chunk beyond the current position (wave-uniform)
+  const int n_act = pos / kChunk + 1;                 // chunks that take part
+  const int cn = min(kChunk, pos + 1 - p0);           // positions of this chunk
+  const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position
 
-  // ---- step 1: per-head RMSNorm (optional) + rotary embedding of the n_rep query heads and the new key
+  // ---- every global load of the chunk is requested up front (a dependent global access costs ~1-2 us at this
+  // occupancy): the K row of this thread's position, and this thread's channel pair of VN cache rows
+  u32x4 kw[HD / 8];
+  {
+    const bool ld = tid < cn && (p0 + tid) != pos;
+    const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + p0 + (ld ? tid : 0)) * hd);
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) kw[c] = ld ? kr[c] : (u32x4){0u, 0u, 0u, 0u};
+  }
+  const int dq = tid % half, grp = tid / half;
+  unsigned vv[VN];
+  {
+    const unsigned* vbase = (const unsigned*)(a.vcache + ((int64_t)h * a.T_max + p0) * hd) + dq;
+    const unsigned* vtok = (const unsigned*)(a.qkv + (int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd) + dq;   // this token's v
+#pragma unroll
+    for (int u = 0; u < VN; ++u) {
+      const int p = grp + u * GROUPS;
+      vv[u] = (p < cn) ? ((p0 + p) != pos ? vbase[(int64_t)p * half] : *vtok) : 0u;
+    }
+  }
+  // padding query heads are zero, scores past the chunk are zero: the loops below need no bounds
+  for (int e = tid; e < NREP * HD; e += 256) qs[e] = 0.f;
+  for (int e = tid; e < NREP * kChunk; e += 256) sc[e] = 0.f;
+  __syncthreads();
+
+  // ---- step 1: per-head RMSNorm (optional) + rotary embedding of the n_rep query heads (and of the new key)
   const float* rp = a.rope + (int64_t)pos * hd;
   for (int v = wave; v <= n_rep; v += 4) {          // vector v < n_rep: query head, v == n_rep: the key
     const bool isk = v == n_rep;
+    if (isk && !own_new) continue;
     const unsigned short* src = isk ? a.qkv + (int64_t)a.Hq * hd + (int64_t)h * hd : a.qkv + ((int64_t)h * n_rep + v) * hd;
     const unsigned short* nw = isk ? a.knw : a.qnw;
     const bool act = lane < half;
@@ -57,16 +102,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       const float r = __builtin_amdgcn_rsqf(ss / (float)hd + a.eps);
       // HF: normalise in fp32, round to the activation dtype, then multiply by the weight
       if (act) {
-        x0 = A::to_f32(A::from_f32(x0 * r)) * A::to_f32(nw[lane]);
-        x1 = A::to_f32(A::from_f32(x1 * r)) * A::to_f32(nw[lane + half]);
-        x0 = A::to_f32(A::from_f32(x0));
-        x1 = A::to_f32(A::from_f32(x1));
+        x0 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(x0 * r)) * A::to_f32(nw[lane])));
+        x1 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(x1 * r)) * A::to_f32(nw[lane + half])));
       }
     }
     if (act) {
       // rotate_half convention, cos / sin rounded to the activation dtype like HF's rotary embedding does
-      const float c = A::to_f32(A::from_f32(rp[lane])), s = A::to_f32(A::from_f32(rp[half + lane]));
-      const float y0 = A::to_f32(A::from_f32(x0 * c - x1 * s)), y1 = A::to_f32(A::from_f32(x1 * c + x0 * s));
+      const float c = A::to_f32(A::from_f32(rp[lane])), sn = A::to_f32(A::from_f32(rp[half + lane]));
+      const float y0 = A::to_f32(A::from_f32(x0 * c - x1 * sn)), y1 = A::to_f32(A::from_f32(x1 * c + x0 * sn));
       if (isk) {
         knew[lane] = y0;
         knew[lane + half] = y1;
@@ -79,120 +122,168 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       }
     }
   }
-  if (tid < hd) {
-    const unsigned short vv = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + tid];
-    vnew[tid] = A::to_f32(vv);
-    a.vcache[((int64_t)h * a.T_max + pos) * hd + tid] = vv;
-  }
+  if (own_new && tid < hd)
+    a.vcache[((int64_t)h * a.T_max + pos) * hd + tid] = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + tid];
   __syncthreads();
+  if (a.dbg == 1) return;
 
-  // ---- step 2: scores s[j][p] = q_j . K[p]; one position per thread and pass
-  const unsigned short* kbase = a.kcache + (int64_t)h * a.T_max * hd;
-  for (int p = tid; p < T; p += 256) {
-    float dot[8];
+  // ---- step 2: scores s[j][p] = q_j . K[p]; one position per thread
+  if (tid < cn) {
+    const int p = tid;
+    float dot[NREP];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dot[j] = 0.f;
-    if (p == pos) {
-      for (int d = 0; d < hd; ++d) {
-        const float kv = knew[d];
+    for (int j = 0; j < NREP; ++j) dot[j] = 0.f;
+    const bool is_new = (p0 + p) == pos;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < n_rep) dot[j] = __builtin_fmaf(qs[j * hd + d], kv, dot[j]);
+    for (int c = 0; c < HD / 8; ++c) {
+      float kf[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kf[2 * e] = A::to_f32(kw[c][e] & 0xffffu);
+        kf[2 * e + 1] = A::to_f32(kw[c][e] >> 16);
       }
-    } else {
-      const u32x4* kr = (const u32x4*)(kbase + (int64_t)p * hd);
-      for (int c = 0; c < hd / 8; ++c) {
-        const u32x4 w = kr[c];
+      if (is_new) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kf[e] = knew[c * 8 + e];
+      }
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const f32x4 q0 = *(const f32x4*)(qs + j * hd + c * 8), q1 = *(const f32x4*)(qs + j * hd + c * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float k0 = A::to_f32(w[e] & 0xffffu), k1 = A::to_f32(w[e] >> 16);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < n_rep) {
-              dot[j] = __builtin_fmaf(qs[j * hd + c * 8 + 2 * e], k0, dot[j]);
-              dot[j] = __builtin_fmaf(qs[j * hd + c * 8 + 2 * e + 1], k1, dot[j]);
-            }
+          dot[j] = __builtin_fmaf(q0[e], kf[e], dot[j]);
+          dot[j] = __builtin_fmaf(q1[e], kf[4 + e], dot[j]);
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < n_rep) sc[(int64_t)j * T + p] = dot[j];
+    for (int j = 0; j < NREP; ++j) sc[j * kChunk + p] = dot[j];
   }
   __syncthreads();
+  if (a.dbg == 2) return;
 
-  // ---- step 3: softmax over p for every query head (max, exp, sum through LDS)
-  for (int j = 0; j < n_rep; ++j) {
+  // ---- step 3: chunk-local soft-max statistics: m_j = max_p s, e = exp(s - m), l_j = sum e
+  for (int j = wave; j < n_rep; j += 4) {             // one wave per query head
     float m = -3.0e38f;
-    for (int p = tid; p < T; p += 256) m = fmaxf(m, sc[(int64_t)j * T + p]);
+    for (int p = lane; p < cn; p += 64) m = fmaxf(m, sc[j * kChunk + p]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) red[j * 8 + wave] = m;
-  }
-  __syncthreads();
-  for (int j = 0; j < n_rep; ++j) {
-    const float m = fmaxf(fmaxf(red[j * 8 + 0], red[j * 8 + 1]), fmaxf(red[j * 8 + 2], red[j * 8 + 3]));
     float l = 0.f;
-    for (int p = tid; p < T; p += 256) {
-      const float e = __builtin_amdgcn_exp2f((sc[(int64_t)j * T + p] - m) * 1.4426950408889634f);
-      sc[(int64_t)j * T + p] = e;
+    for (int p = lane; p < cn; p += 64) {
+      const float e = __builtin_amdgcn_exp2f((sc[j * kChunk + p] - m) * 1.4426950408889634f);
+      sc[j * kChunk + p] = e;
       l += e;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) l += __shfl_xor(l, off, 64);
-    if (lane == 0) red[j * 8 + 4 + wave] = l;
-  }
-  __syncthreads();
-
-  // ---- step 4: o_j[d] = sum_p P_j[p] V[p][d] / l_j; thread = (part, d), parts interleave the positions
-  {
-    const int d = tid % hd, part = tid / hd;
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    const unsigned short* vbase = a.vcache + (int64_t)h * a.T_max * hd;
-    if (part < parts) {
-      for (int p = part; p < T; p += parts) {
-        const float vv = (p == pos) ? vnew[d] : A::to_f32(vbase[(int64_t)p * hd + d]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < n_rep) o[j] = __builtin_fmaf(sc[(int64_t)j * T + p], vv, o[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < n_rep) accs[(part * n_rep + j) * hd + d] = o[j];
+    if (lane == 0) {
+      red[j * 8] = m;
+      red[j * 8 + 1] = l;
     }
   }
   __syncthreads();
+  if (a.dbg == 3) return;
+
+  // ---- step 4: o_j[d] = sum_p e_j[p] V[p][d] from the rows requested at the top (probabilities past the chunk are 0)
+  {
+    float o0[NREP], o1[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) o0[j] = o1[j] = 0.f;
+    const float* scg = sc + grp;
+#pragma unroll
+    for (int u = 0; u < VN; ++u) {
+      const float v0 = A::to_f32(vv[u] & 0xffffu), v1 = A::to_f32(vv[u] >> 16);
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const float e = scg[j * kChunk + u * GROUPS];
+        o0[j] = __builtin_fmaf(e, v0, o0[j]);
+        o1[j] = __builtin_fmaf(e, v1, o1[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      accs[(grp * NREP + j) * hd + 2 * dq] = o0[j];
+      accs[(grp * NREP + j) * hd + 2 * dq + 1] = o1[j];
+    }
+  }
+  __syncthreads();
+  if (n_act == 1) {
+    // the only chunk: normalise and write the output
+    for (int e = tid; e < n_rep * hd; e += 256) {
+      const int j = e / hd, d = e % hd;
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) v += accs[(g * NREP + j) * hd + d];
+      a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(v / red[j * 8 + 1]);
+    }
+    return;
+  }
+  // ---- several chunks: publish this chunk's (o, m, l), the last arriver of the KV head merges
+  float* mine = a.part + (((int64_t)h * a.chunks + s) * n_rep) * (hd + 2);
   for (int e = tid; e < n_rep * hd; e += 256) {
     const int j = e / hd, d = e % hd;
     float v = 0.f;
-    for (int part = 0; part < parts; ++part) v += accs[(part * n_rep + j) * hd + d];
-    const float l = red[j * 8 + 4] + red[j * 8 + 5] + red[j * 8 + 6] + red[j * 8 + 7];
-    a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(v / l);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) v += accs[(g * NREP + j) * hd + d];
+    mine[j * (hd + 2) + d] = v;
+  }
+  if (tid < n_rep) {
+    mine[tid * (hd + 2) + hd] = red[tid * 8];
+    mine[tid * (hd + 2) + hd + 1] = red[tid * 8 + 1];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the release's write-back has drained before the ticket is taken
+    const unsigned t = __hip_atomic_fetch_add(a.ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (t == (unsigned)(n_act - 1)) ? 1u : 0u;
+    if (last_flag) {
+      __hip_atomic_store(a.ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  const float* base = a.part + ((int64_t)h * a.chunks) * n_rep * (hd + 2);
+  for (int e = tid; e < n_rep * hd; e += 256) {
+    const int j = e / hd, d = e % hd;
+    float M = -3.0e38f;
+    for (int c = 0; c < n_act; ++c) M = fmaxf(M, base[((int64_t)c * n_rep + j) * (hd + 2) + hd]);
+    float num = 0.f, den = 0.f;
+    for (int c = 0; c < n_act; ++c) {
+      const float* pc = base + ((int64_t)c * n_rep + j) * (hd + 2);
+      const float w = __builtin_amdgcn_exp2f((pc[hd] - M) * 1.4426950408889634f);
+      num = __builtin_fmaf(w, pc[d], num);
+      den = __builtin_fmaf(w, pc[hd + 1], den);
+    }
+    a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(num / den);
   }
 }
 
 }  // namespace paro
 
-extern "C" int64_t paro_attn_decode_lds_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions) {
-  if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 2) return -1;
-  const int64_t n_rep = n_heads / n_kv_heads, parts = 256 / head_dim;
-  return 4 * (n_rep * head_dim + 2 * head_dim + n_rep * 8 + parts * n_rep * head_dim + n_rep * (int64_t)max_positions);
+extern "C" int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions) {
+  if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 2 || max_positions < 1) return -1;
+  const int64_t n_rep = n_heads / n_kv_heads, chunks = (max_positions + paro::kChunk - 1) / paro::kChunk;
+  return 256 + (int64_t)n_kv_heads * chunks * n_rep * (head_dim + 2) * 4;   // tickets (zero-filled by the caller once) + partials
 }
 
 extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
                                 const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads,
-                                int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* stream) {
+                                int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
   using namespace paro;
   if (!qkv || !kcache || !vcache || !out || !pos || !rope) return fail(PARO_ERR_INVALID, "null pointer");
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0) return fail(PARO_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (n_kv_heads > 64) return fail(PARO_ERR_UNSUPPORTED, "at most 64 KV heads");
   if (n_heads / n_kv_heads > 8) return fail(PARO_ERR_UNSUPPORTED, "at most 8 query heads per KV head (got %d)", n_heads / n_kv_heads);
   if (head_dim != 64 && head_dim != 128) return fail(PARO_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
   if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return fail(PARO_ERR_INVALID, "q / k norm weights come together");
-  const int64_t lds = paro_attn_decode_lds_bytes(n_heads, n_kv_heads, head_dim, max_positions);
-  if (max_positions < 1 || lds > 160 * 1024)
-    return fail(PARO_ERR_UNSUPPORTED, "max_positions %d needs %lld bytes of LDS for the scores (limit 163840)", max_positions, (long long)lds);
+  const int64_t need = paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions);
+  if (max_positions < 1 || max_positions > 65535 * kChunk) return fail(PARO_ERR_INVALID, "max_positions out of range");
+  if (!workspace || workspace_bytes < need)
+    return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;
   a.qkv = (const unsigned short*)qkv;
   a.kcache = (unsigned short*)kcache;
@@ -202,21 +293,37 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
   a.rope = rope;
   a.qnw = (const unsigned short*)q_norm_w;
   a.knw = (const unsigned short*)k_norm_w;
+  a.ticket = (unsigned*)workspace;
+  a.part = (float*)((char*)workspace + 256);
   a.eps = eps;
   a.scale = scale;
   a.Hq = n_heads;
   a.Hkv = n_kv_heads;
   a.hd = head_dim;
   a.T_max = max_positions;
+  a.chunks = (max_positions + kChunk - 1) / kChunk;
+  static const int env_dbg = getenv("PARO_ATTN_DBG") ? atoi(getenv("PARO_ATTN_DBG")) : 0;
+  a.dbg = env_dbg;
   hipStream_t st = (hipStream_t)stream;
-  if (act_dtype == PARO_DTYPE_F16) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_decode_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_decode_kernel<f16>, dim3((unsigned)n_kv_heads), dim3(256), (size_t)lds, st, a);
-  } else if (act_dtype == PARO_DTYPE_BF16) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_decode_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_decode_kernel<bf16>, dim3((unsigned)n_kv_heads), dim3(256), (size_t)lds, st, a);
+  dim3 grid((unsigned)n_kv_heads, (unsigned)a.chunks);
+  if (act_dtype != PARO_DTYPE_F16 && act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  const bool h16 = act_dtype == PARO_DTYPE_F16;
+  const int n_rep = n_heads / n_kv_heads;
+  const int nr = n_rep <= 1 ? 1 : (n_rep <= 2 ? 2 : (n_rep <= 4 ? 4 : 8));
+#define PARO_ATTN_LAUNCH(T, HD, NR) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR>), grid, dim3(256), 0, st, a)
+#define PARO_ATTN_NR(T, HD) \
+  do { \
+    if (nr == 1) PARO_ATTN_LAUNCH(T, HD, 1); \
+    else if (nr == 2) PARO_ATTN_LAUNCH(T, HD, 2); \
+    else if (nr == 4) PARO_ATTN_LAUNCH(T, HD, 4); \
+    else PARO_ATTN_LAUNCH(T, HD, 8); \
+  } while (0)
+  if (head_dim == 128) {
+    if (h16) PARO_ATTN_NR(f16, 128); else PARO_ATTN_NR(bf16, 128);
   } else {
-    return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+    if (h16) PARO_ATTN_NR(f16, 64); else PARO_ATTN_NR(bf16, 64);
   }
+#undef PARO_ATTN_NR
+#undef PARO_ATTN_LAUNCH
   return check_launch("paro_attn_decode");
 }

@@ -63,8 +63,9 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 // tools/ablate_gemv.py, tools/timeline_gemv.py): 11 skips schedule + stages, 21 also the unpack + MFMA (pure
 // stream), 41 fetches the schedule but does not run the stages, 51 runs the stages without the cross-lane
 // fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps.
-// FUSED: the decode-layer fusions either side of the linear, selected at run time inside this
-// one extra instantiation so that the plain kernel's code is untouched:
+// FUSED (1: RMSNorm prologue and / or residual epilogue, 2: SiLU*mul prologue (+ residual)): the decode-layer
+// fusions either side of the linear, in extra instantiations so that the plain kernel's code is
+// untouched:
 //   prologue RMSNORM   y = GEMV(x) * rsqrt(mean(x^2) + eps): the norm WEIGHT is folded into channel_scales at load
 //                      time, the scalar commutes with rotation and matmul.  sum(x^2) costs nothing extra: every
 //                      group of K is seeded by exactly one wave of the workgroup (K-split is refused for it).
@@ -72,7 +73,7 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 //                      gate_up projection's output [rows][2 K] (the MLX MoE path rotates the activation output the
 //                      same way before down_proj, mlx/modules.py:204-207).
 //   epilogue residual  y += residual[row][col] (the decoder's residual stream), in the final write.
-template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, bool FUSED = false>
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
-    unsigned xu[FUSED ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
+    unsigned xu[FUSED == 2 ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
@@ -193,8 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         if constexpr (FUSED) {
           const unsigned short* xr = a.x + (int64_t)rr * a.xstride + g * 128 + 2 * lane;
           b.xv[r] = *(const unsigned*)xr;
-          // unconditional (static load count): without the SiLU*mul prologue it re-reads the same word
-          b.xu[r] = *(const unsigned*)(xr + (a.prologue == PARO_PROLOGUE_SILU_MUL ? a.K : 0));
+          if constexpr (FUSED == 2) b.xu[r] = *(const unsigned*)(xr + a.K);
         } else {
           b.xv[r] = *(const unsigned*)(a.x + (int64_t)rr * a.K + g * 128 + 2 * lane);
         }
@@ -233,6 +233,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // state grows by 2^14 per stage; exact power-of-two bookkeeping keeps it in range: the state starts at
   // 2^-63 x, and the final stage's coefficients carry 2^(49 - 14 krot).
   // start: channels 2l, 2l+1 of the group (one coalesced load), times their channel scales
+  // residual epilogue: the value this thread will add to its FIRST output is requested here, at kernel entry, not
+  // as a dependent load after the reduction (a global access at the tail is ~1 us of pure latency)
+  float res_first = 0.f;
+  if constexpr (FUSED) {
+    if (a.residual && tid < TPW * MRT * 64 && ks == a.ksplit - 1) {   // only the workgroup that writes y
+      const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
+      const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
+      if (j < nt && b < a.rows) res_first = A::to_f32(a.residual[(int64_t)b * a.N + (tile0 + j) * 16 + (el & 15)]);
+    }
+  }
   float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
 #pragma unroll
   for (int r = 0; r < (FUSED ? MB : 1); ++r) ssq[r] = 0.f;
@@ -242,15 +252,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int r = 0; r < MB; ++r) {
       const unsigned xv = r < a.rows ? b.xv[r] : 0u;
       float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
-      if constexpr (FUSED) {
-        if (a.prologue == PARO_PROLOGUE_SILU_MUL) {
+      if constexpr (FUSED == 2) {
+        {
           const unsigned uv = r < a.rows ? b.xu[r] : 0u;
           // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x
           x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x0));
           x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x1));
-        } else if (a.prologue == PARO_PROLOGUE_RMSNORM) {
-          ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
         }
+      } else if constexpr (FUSED == 1) {
+        if (a.prologue == PARO_PROLOGUE_RMSNORM) ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
       }
       sa[r] = x0 * c0;
       sb[r] = x1 * c1;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < MRT; ++r) red[((wave * TPW + j) * MRT + r) * 64 + lane] = acc[j][r];
   float* ssl = (float*)(lds + LDS_BYTES - SS_BYTES);   // [wave][row]
-  if constexpr (FUSED) {
+  if constexpr (FUSED == 1) {
     if (a.prologue == PARO_PROLOGUE_RMSNORM) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MRT * 64];
     const int col = (tile0 + j) * 16 + (el & 15);
     if (direct) {
-      if constexpr (FUSED) {
+      if constexpr (FUSED == 1) {
         if (a.prologue == PARO_PROLOGUE_RMSNORM) {
           float ss = 0.f;
 #pragma unroll
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     } else if (ks != a.ksplit - 1) {
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
       a.y[(int64_t)b * a.N + col] = A::from_f32(v);
     }
@@ -592,17 +602,22 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
   return PARO_OK;
 }
 
-template <typename AT, int TPW, int MB, bool PREROT>
-int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+template <typename AT, int TPW, int MB, bool PREROT, int FUSED>
+int launch_waves_fused_mode(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (!PREROT && MB <= 4 && tpw_is_pow2(TPW)) {
     if constexpr (TPW < 8) {
-      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, true>, 1024>(a, grid, st);
+      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, FUSED>, 1024>(a, grid, st);
     }
-    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, true>, 512>(a, grid, st);
-    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, true>, 256>(a, grid, st);
+    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, FUSED>, 512>(a, grid, st);
+    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, FUSED>, 256>(a, grid, st);
   }
   return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue: not built for %d tiles per wave x %d waves x %d rows%s", TPW, waves,
               MB, PREROT ? " (pre-rotated mode)" : "");
+}
+template <typename AT, int TPW, int MB, bool PREROT>
+int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
+  return launch_waves_fused_mode<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 
 template <typename AT, int TPW, int MB, bool PREROT, int PD>

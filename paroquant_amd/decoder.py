@@ -200,15 +200,10 @@ class ParoDecoderLM:
         self.gu_buf = torch.zeros(1, 2 * c.inter, dtype=dt, device=dev)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
+        self.attn_ws = ops.attn_workspace(dev, c.n_heads, c.n_kv_heads, c.head_dim, c.max_positions)
         self.bytes_per_token = sum(pk.nbytes() for L in self.layers for pk in (L.qkv, L.o, L.gate_up, L.down))
 
     # ------------------------------------------------------------------ one decode token (capturable)
-    def _final(self, h: torch.Tensor) -> torch.Tensor:
-        c = self.cfg
-        x = h.float()
-        x = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + c.rms_eps)).to(self.dtype) * self.final_norm
-        return torch.matmul(x, self.lm_head.t())
-
     def decode_step(self) -> None:
         """Consume ``self.tok`` at position ``self.pos``; leave the logits in ``self.logits``, the greedy next token in
         ``self.tok`` and advance ``self.pos``.  No host synchronisation, no allocation by the fused ops."""
@@ -219,7 +214,7 @@ class ParoDecoderLM:
         for L in self.layers:
             ops.w4a16_gemv_fused(h, L.qkv, R, c.rms_eps, out=self.qkv_buf)
             ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, c.n_heads, c.n_kv_heads, c.head_dim,
-                            L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf)
+                            L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws)
             ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                     # h2 = h + o(attn)
             ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
             ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                    # h = h2 + down(act)

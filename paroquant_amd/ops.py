@@ -317,20 +317,40 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     return y
 
 
+_attn_ws: dict = {}
+
+
+def attn_workspace(device, n_heads: int, n_kv_heads: int, head_dim: int, max_positions: int) -> torch.Tensor:
+    """Zero-filled scratch of ``paro_attn_decode`` (arrival tickets + partial results of the position chunks); one per
+    (device, geometry), shared by all layers of a model that run on one stream."""
+    lib = nat.load()
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n_heads, n_kv_heads, head_dim, max_positions)
+    ws = _attn_ws.get(key)
+    if ws is None:
+        need = lib.paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions)
+        if need < 0:
+            raise ValueError("bad attention geometry")
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
+    return ws
+
+
 def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, rope: torch.Tensor,
                 n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decoder layer's batch-1 attention in one launch (``paro_attn_decode``): q/k norm + RoPE + KV-cache append at
     ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache`` / ``vcache``: [n_kv_heads, T_max, head_dim]."""
     lib = nat.load()
     T_max = kcache.size(1)
     y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    ws = workspace if workspace is not None else attn_workspace(qkv.device, n_heads, n_kv_heads, head_dim, T_max)
     with torch.cuda.device(qkv.device):
         nat.check(lib.paro_attn_decode(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(),
                                        rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
                                        None if k_norm_w is None else k_norm_w.data_ptr(), float(eps), float(head_dim) ** -0.5,
-                                       n_heads, n_kv_heads, head_dim, T_max, nat.dtype_code(qkv.dtype),
-                                       nat.current_stream_ptr(qkv.device)))
+                                       n_heads, n_kv_heads, head_dim, T_max, nat.dtype_code(qkv.dtype), ws.data_ptr(),
+                                       ws.numel(), nat.current_stream_ptr(qkv.device)))
     return y
 
 
