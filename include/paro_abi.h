@@ -242,6 +242,20 @@ int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, con
                      int head_dim, int max_positions, int act_dtype, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* Tail of a decode step (decode harness): final RMSNorm + the unquantised lm_head as an HBM-bound
+ * fp16 / bf16 matrix-vector product, then the greedy argmax.
+ *   paro_lm_head         logits[v] = sum_k W[v][k] xn[k],  xn = rmsnorm(x; norm_weight, eps) with HF's rounding;
+ *                        W act_dtype [vocab][hidden] row-major, hidden = 512 x 1..8; also leaves every
+ *                        workgroup's (max logit, lowest index) in `workspace` (paro_lm_head_workspace_bytes).
+ *   paro_argmax_advance  out_tokens[*pos] = *token (the token just consumed; skipped when out_tokens is NULL);
+ *                        *token = argmax(logits) (lowest index on ties); *pos += 1.   All three live in device memory,
+ *                        so a captured decode step replays without a host round trip. */
+int64_t paro_lm_head_workspace_bytes(int64_t vocab);
+int paro_lm_head(const void* x, const void* norm_weight, const void* W, void* logits, int64_t vocab, int64_t hidden,
+                 float eps, int act_dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int paro_argmax_advance(const void* workspace, int64_t vocab, int64_t* token, int32_t* pos, int64_t* out_tokens,
+                        int64_t out_len, void* stream);
+
 /* Weight prefetch for decode harnesses that know the NEXT layer (no reference counterpart -- the
  * reference leaves scheduling to vLLM / HF generate).  Touches one dword per 128-byte line of up to
  * PARO_MAX_PREFETCH buffers (128-byte aligned) with `workgroups` x 256 threads and discards the data, pulling the

@@ -40,6 +40,9 @@ EXPORTS = (
     "paro_w4a16_gemv_fused",
     "paro_attn_decode_workspace_bytes",
     "paro_attn_decode",
+    "paro_lm_head_workspace_bytes",
+    "paro_lm_head",
+    "paro_argmax_advance",
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
     "paro_dequant_packed",
@@ -131,6 +134,13 @@ def load() -> ctypes.CDLL:
     lib.paro_attn_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                                      c_void_p]
+    lib.paro_lm_head_workspace_bytes.restype = c_int64
+    lib.paro_lm_head_workspace_bytes.argtypes = [c_int64]
+    lib.paro_lm_head.restype = c_int
+    lib.paro_lm_head.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_float, c_int, c_void_p,
+                                 c_int64, c_void_p]
+    lib.paro_argmax_advance.restype = c_int
+    lib.paro_argmax_advance.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.paro_w4a16_gemm.restype = c_int
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_void_p]

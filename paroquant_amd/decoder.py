@@ -201,6 +201,11 @@ class ParoDecoderLM:
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         self.attn_ws = ops.attn_workspace(dev, c.n_heads, c.n_kv_heads, c.head_dim, c.max_positions)
+        self.lm_ws = ops.lm_head_workspace(dev, c.vocab)
+        self.lm_head = self.lm_head.contiguous()
+        # the fused tail (final norm + lm_head GEMV + argmax, 2 launches) needs hidden = 512 * 1..8;
+        # otherwise the torch ops (about 10 launches incl. a hipBLASLt GEMV) take its place
+        self.fused_tail = c.hidden % 512 == 0 and c.hidden <= 4096
         self.bytes_per_token = sum(pk.nbytes() for L in self.layers for pk in (L.qkv, L.o, L.gate_up, L.down))
 
     # ------------------------------------------------------------------ one decode token (capturable)
@@ -218,10 +223,14 @@ class ParoDecoderLM:
             ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                     # h2 = h + o(attn)
             ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
             ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                    # h = h2 + down(act)
-        torch.matmul(self._final_norm(h), self.lm_head.t(), out=self.logits)
-        self.out_tokens.index_copy_(0, self.pos.long(), self.tok)
-        torch.argmax(self.logits, dim=-1, out=self.tok)
-        self.pos.add_(1)
+        if self.fused_tail:
+            ops.lm_head(h, self.final_norm, self.lm_head, self.logits, c.rms_eps, self.lm_ws)
+            ops.argmax_advance(self.lm_ws, c.vocab, self.tok, self.pos, self.out_tokens)
+        else:
+            torch.matmul(self._final_norm(h), self.lm_head.t(), out=self.logits)
+            self.out_tokens.index_copy_(0, self.pos.long(), self.tok)
+            torch.argmax(self.logits, dim=-1, out=self.tok)
+            self.pos.add_(1)
 
     def _final_norm(self, h: torch.Tensor) -> torch.Tensor:
         x = h.float()

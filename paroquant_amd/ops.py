@@ -354,6 +354,34 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
     return y
 
 
+def lm_head_workspace(device, vocab: int) -> torch.Tensor:
+    lib = nat.load()
+    return torch.zeros(lib.paro_lm_head_workspace_bytes(int(vocab)), dtype=torch.uint8, device=device)
+
+
+def lm_head(x: torch.Tensor, norm_weight: torch.Tensor, weight: torch.Tensor, logits: torch.Tensor, eps: float,
+            workspace: torch.Tensor) -> torch.Tensor:
+    """``logits = lm_head(rmsnorm(x))`` for one token (``paro_lm_head``): x [hidden], weight [vocab, hidden] contiguous."""
+    lib = nat.load()
+    V, H = weight.shape
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_lm_head(x.data_ptr(), norm_weight.data_ptr(), weight.data_ptr(), logits.data_ptr(), V, H, float(eps),
+                                   nat.dtype_code(x.dtype), workspace.data_ptr(), workspace.numel(), nat.current_stream_ptr(x.device)))
+    return logits
+
+
+def argmax_advance(workspace: torch.Tensor, vocab: int, token: torch.Tensor, pos: torch.Tensor, out_tokens: Optional[torch.Tensor]) -> None:
+    """Greedy next token from the partial maxima ``lm_head`` left in ``workspace``: ``out_tokens[pos] = token``;
+    ``token = argmax``; ``pos += 1`` -- all on the device (``paro_argmax_advance``)."""
+    lib = nat.load()
+    if token.dtype != torch.int64 or pos.dtype != torch.int32 or (out_tokens is not None and out_tokens.dtype != torch.int64):
+        raise RuntimeError("token / out_tokens must be int64 and pos int32")
+    with torch.cuda.device(token.device):
+        nat.check(lib.paro_argmax_advance(workspace.data_ptr(), int(vocab), token.data_ptr(), pos.data_ptr(),
+                                          None if out_tokens is None else out_tokens.data_ptr(),
+                                          0 if out_tokens is None else out_tokens.numel(), nat.current_stream_ptr(token.device)))
+
+
 def prefetch(tensors, workgroups: int = 64, checksum: Optional[torch.Tensor] = None) -> None:
     """Pull the given device buffers into the Infinity Cache on the CURRENT stream (``paro_prefetch``): one dword per
     128-byte line is touched and discarded.  Call it on a side stream of a captured decode step for the packed

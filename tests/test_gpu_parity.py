@@ -915,7 +915,8 @@ def test_decoder_harness_matches_hf(dev, tmp_path, model_type, head_dim):
     from paroquant_amd.decoder import ParoDecoderLM
     from tests.hf_ckpt import write_tiny_paro_llama
     from transformers import AutoModelForCausalLM
-    write_tiny_paro_llama(str(tmp_path), hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=128,
+    # hidden 512 so that the fused tail (final norm + lm_head GEMV + argmax kernels) is on the tested path
+    write_tiny_paro_llama(str(tmp_path), hidden=512, inter=1024, heads=8 if head_dim == 64 else 4, kv_heads=2, layers=2, vocab=200,
                           model_type=model_type, head_dim=head_dim, seed=3)
     try:
         hf = AutoModelForCausalLM.from_pretrained(str(tmp_path), dtype=torch.float16, device_map={"": "cuda:0"})
@@ -923,8 +924,8 @@ def test_decoder_harness_matches_hf(dev, tmp_path, model_type, head_dim):
         hf = AutoModelForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.float16, device_map={"": "cuda:0"})
     hf.eval()
     lm = ParoDecoderLM.from_checkpoint(str(tmp_path), dev, max_positions=64)
-    assert lm.cfg.qk_norm == (model_type == "qwen3")
-    ids = torch.randint(0, 128, (11,), device=dev)
+    assert lm.cfg.qk_norm == (model_type == "qwen3") and lm.fused_tail
+    ids = torch.randint(0, 200, (11,), device=dev)
     logits = lm.prefill(ids)
     with torch.no_grad():
         ref = hf(input_ids=ids[None]).logits[0, -1].float()
@@ -947,3 +948,27 @@ def test_decoder_harness_matches_hf(dev, tmp_path, model_type, head_dim):
             assert int(lm.tok.item()) == int(ref.argmax().item())
     toks, stats = ParoDecoderLM.from_checkpoint(str(tmp_path), dev, max_positions=64).generate(ids, 8)
     assert toks.shape == (19,) and torch.equal(toks[:11], ids) and stats["new_tokens"] == 8
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("V,H", [(1000, 512), (151936, 2560), (4099, 4096)])
+def test_lm_head_and_argmax(dev, dtype, V, H):
+    """Final RMSNorm + lm_head GEMV + greedy argmax kernels against torch on the same tensors."""
+    from paroquant_amd import ops
+    gen = torch.Generator(device=dev); gen.manual_seed(V + H)
+    W = (torch.randn(V, H, device=dev, generator=gen) * H ** -0.5).to(dtype)
+    x = (torch.randn(1, H, device=dev, generator=gen) * 3).to(dtype)
+    nw = (1 + 0.1 * torch.randn(H, device=dev, generator=gen)).to(dtype)
+    logits = torch.empty(1, V, device=dev, dtype=dtype)
+    ws = ops.lm_head_workspace(dev, V)
+    ops.lm_head(x, nw, W, logits, 1e-6, ws)
+    xf = x.float()
+    xn = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype) * nw)
+    ref = (xn.double() @ W.double().t())
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    assert ((logits.double() - ref).abs().max() / ref.abs().max()).item() < tol
+    tok = torch.tensor([7], dtype=torch.int64, device=dev)
+    pos = torch.tensor([3], dtype=torch.int32, device=dev)
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    ops.argmax_advance(ws, V, tok, pos, out)
+    assert int(tok.item()) == int(torch.argmax(logits, dim=-1).item()) and int(pos.item()) == 4 and int(out[3].item()) == 7
