@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 5
+#define PARO_ABI_VERSION 6
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -205,6 +205,26 @@ typedef struct paro_fusion {
 } paro_fusion_t;
 int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                           int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream);
+
+/* Mixture-of-experts decode: the SAME fused GEMV over `n_slots` (token, expert) slots in one launch.
+ * All experts of a projection share one rotation (cli/convert.py:280-379 exports one pairs / theta / channel_scales
+ * set per projection; mlx/modules.py:159-212 applies it once before gate/up and once before down), so `L` carries
+ * that rotation and the packed buffers of expert 0, and slot s reads
+ *     wq + expert_idx[s] * wq_stride_bytes,  sz + expert_idx[s] * sz_stride_bytes,
+ *     x + (s / x_slot_div) * x_slot_stride,  writes y + s * y_slot_stride.
+ * expert_idx lives in DEVICE memory (router output; graph-capturable).  With the SILU_MUL prologue this is the
+ * experts' down projection on the slot's own gate|up vector; without a prologue the merged gate_up projection
+ * (x_slot_div = experts per token: the k slots of a token share its x).  rows <= 4, no K-split, no residual. */
+typedef struct paro_experts {
+  const int32_t* expert_idx;
+  int32_t n_slots;
+  int32_t x_slot_div;
+  int64_t wq_stride_bytes, sz_stride_bytes;
+  int64_t x_slot_stride, y_slot_stride;   /* elements */
+} paro_experts_t;
+int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                            int64_t workspace_bytes, const paro_fusion_t* fusion, const paro_experts_t* experts,
+                            void* stream);
 
 /* Prefill path (any rows): rotate pre-pass into the workspace, then an
  * LDS-staged MFMA GEMM with in-register INT4 dequant.

@@ -504,3 +504,75 @@ def attention_decode(qkv, kcache, vcache, pos: int, n_heads: int, n_kv_heads: in
         p = np.exp(s - s.max())
         out[h] = (p / p.sum()) @ V[h // n_rep]
     return out.reshape(-1), k, v
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Mixture-of-experts.  Export: cli/convert.py:280-379 (`_quantize_moe`): gate_up [E, 2 I, H] and
+# down [E, H, I] are rotated / quantised with ONE rotation per projection shared by all experts; the first half of
+# the gate_up rows is gate_proj, the second half up_proj (:343-347); every expert gets its own AWQ buffers.
+# Forward: mlx/modules.py:159-212 (`RotateSwitchGLU.__call__`): rotate x once, gate / up of the selected experts,
+# activation(up, gate) = silu(gate) * up, rotate the activation with the down rotation, down of the same experts.
+# ---------------------------------------------------------------------------------------------------------
+
+def quantize_moe(gate_up, down, gu_pairs, gu_theta, gu_cs, gu_scale, gu_zp, dn_pairs, dn_theta, dn_cs, dn_scale, dn_zp,
+                 bits: int = 4, group_size: int = 128):
+    """Restates `_quantize_moe`: returns ({proj: {qweight, qzeros, scales} stacked over experts}, rotation buffers)."""
+    E, two_i, H = gate_up.shape
+    _, H2, I = down.shape
+    assert H2 == H
+    gq, gs, gz = quantize_rotated_weight(gate_up.reshape(-1, H), gu_pairs, gu_theta, gu_cs, gu_scale, gu_zp, bits, group_size)
+    dq, ds, dz = quantize_rotated_weight(down.reshape(-1, I), dn_pairs, dn_theta, dn_cs, dn_scale, dn_zp, bits, group_size)
+    half = two_i // 2
+    gq, gs, gz = gq.reshape(E, two_i, H), gs.reshape(E, two_i, -1), gz.reshape(E, two_i, -1)
+    dq, ds, dz = dq.reshape(E, H, I), ds.reshape(E, H, -1), dz.reshape(E, H, -1)
+    out = {}
+    for proj, q, sc, zp in (("gate_proj", gq[:, :half], gs[:, :half], gz[:, :half]),
+                            ("up_proj", gq[:, half:], gs[:, half:], gz[:, half:]), ("down_proj", dq, ds, dz)):
+        bufs = [to_awq_buffers(q[e], sc[e], zp[e]) for e in range(E)]
+        out[proj] = {k: np.stack([b[k] for b in bufs]) for k in ("qweight", "qzeros", "scales")}
+    rot = {"gate_up_weight_theta": np.asarray(gu_theta, dtype=np.float16), "gate_up_weight_pairs": np.asarray(gu_pairs, dtype=np.int16),
+           "gate_up_weight_channel_scales": (1.0 / np.asarray(gu_cs, dtype=np.float32)).astype(np.float16).reshape(1, -1),
+           "down_weight_theta": np.asarray(dn_theta, dtype=np.float16), "down_weight_pairs": np.asarray(dn_pairs, dtype=np.int16),
+           "down_weight_channel_scales": (1.0 / np.asarray(dn_cs, dtype=np.float32)).astype(np.float16).reshape(1, -1)}
+    return out, rot
+
+
+def moe_experts_forward(x, indices, experts, rot, group_size: int = 128):
+    """float64 forward of the routed experts: x [T, H], indices [T, k] -> [T, k, H] (no routing weights: the MoE
+    block applies them outside, as with the reference's RotateSwitchGLU)."""
+    x = np.asarray(x, dtype=np.float64)
+    T, k = indices.shape
+    xr = rotate(x, rot["gate_up_weight_pairs"], rot["gate_up_weight_theta"].astype(np.float64),
+                rot["gate_up_weight_channel_scales"].astype(np.float64).reshape(-1), group_size, "ideal")
+    deq = lambda proj, e: dequant_awq(experts[proj]["qweight"][e], experts[proj]["qzeros"][e], experts[proj]["scales"][e],
+                                      group_size, np.float16).astype(np.float64)
+    out = None
+    for t in range(T):
+        for s in range(k):
+            e = int(indices[t, s])
+            g, u = xr[t] @ deq("gate_proj", e), xr[t] @ deq("up_proj", e)
+            act = (g / (1.0 + np.exp(-g)) * u)[None, :]
+            ar = rotate(act, rot["down_weight_pairs"], rot["down_weight_theta"].astype(np.float64),
+                        rot["down_weight_channel_scales"].astype(np.float64).reshape(-1), group_size, "ideal")
+            y = ar[0] @ deq("down_proj", e)
+            if out is None:
+                out = np.zeros((T, k, y.shape[0]))
+            out[t, s] = y
+    return out
+
+
+def make_moe(seed: int, E: int, H: int, I: int, krot: int = 8, group_size: int = 128):
+    """Synthetic MoE expert block in checkpoint format (random INT4, shared rotations)."""
+    rng = np.random.default_rng(seed)
+    def proj(K, N):
+        return {"qweight": np.stack([rng.integers(-2**31, 2**31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32) for _ in range(E)]),
+                "qzeros": np.stack([rng.integers(-2**31, 2**31 - 1, size=(K // group_size, N // 8), dtype=np.int64).astype(np.int32) for _ in range(E)]),
+                "scales": np.stack([rng.uniform(0.002, 0.02, size=(K // group_size, N)).astype(np.float16) for _ in range(E)])}
+    experts = {"gate_proj": proj(H, I), "up_proj": proj(H, I), "down_proj": proj(I, H)}
+    rot = {"gate_up_weight_theta": (rng.standard_normal((krot, H // 2)) * 0.1).astype(np.float16),
+           "gate_up_weight_pairs": random_pairs(rng, krot, H, group_size),
+           "gate_up_weight_channel_scales": rng.uniform(0.5, 2.0, size=(1, H)).astype(np.float16),
+           "down_weight_theta": (rng.standard_normal((krot, I // 2)) * 0.1).astype(np.float16),
+           "down_weight_pairs": random_pairs(rng, krot, I, group_size),
+           "down_weight_channel_scales": rng.uniform(0.5, 2.0, size=(1, I)).astype(np.float16)}
+    return experts, rot

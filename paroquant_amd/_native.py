@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 5
+PARO_ABI_VERSION = 6
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
@@ -38,6 +38,7 @@ EXPORTS = (
     "paro_gemv_launch_shape",
     "paro_w4a16_gemv",
     "paro_w4a16_gemv_fused",
+    "paro_w4a16_gemv_experts",
     "paro_attn_decode_workspace_bytes",
     "paro_attn_decode",
     "paro_lm_head_workspace_bytes",
@@ -76,6 +77,13 @@ class ParoFusion(Structure):
     """``paro_fusion_t`` (include/paro_abi.h)."""
 
     _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p)]
+
+
+class ParoExperts(Structure):
+    """``paro_experts_t`` (include/paro_abi.h)."""
+
+    _fields_ = [("expert_idx", c_void_p), ("n_slots", c_int32), ("x_slot_div", c_int32), ("wq_stride_bytes", c_int64),
+                ("sz_stride_bytes", c_int64), ("x_slot_stride", c_int64), ("y_slot_stride", c_int64)]
 
 
 PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_MUL = 0, 1, 2
@@ -128,6 +136,9 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemv_fused.restype = c_int
     lib.paro_w4a16_gemv_fused.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                           POINTER(ParoFusion), c_void_p]
+    lib.paro_w4a16_gemv_experts.restype = c_int
+    lib.paro_w4a16_gemv_experts.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                            POINTER(ParoFusion), POINTER(ParoExperts), c_void_p]
     lib.paro_attn_decode_workspace_bytes.restype = c_int64
     lib.paro_attn_decode_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.paro_attn_decode.restype = c_int

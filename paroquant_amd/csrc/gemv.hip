@@ -167,13 +167,22 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
 namespace paro {
 static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                      int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode,
-                     const paro_fusion_t* F, void* stream) {
+                     const paro_fusion_t* F, const paro_experts_t* E, void* stream) {
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
-  const bool fused = F && (F->prologue != PARO_PROLOGUE_NONE || F->residual);
+  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E;
+  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr};
+  if (E) {
+    if (!F) F = &no_fusion;
+    if (!E->expert_idx || E->n_slots < 1 || E->n_slots > 65535) return fail(PARO_ERR_INVALID, "bad expert slot table");
+    if (E->x_slot_div < 1) return fail(PARO_ERR_INVALID, "x_slot_div must be >= 1");
+    if (F->residual) return fail(PARO_ERR_UNSUPPORTED, "the residual epilogue is not defined for expert slots");
+    if (ksplit > 1) return fail(PARO_ERR_INVALID, "expert launches do not K-split (the slots already fill the grid)");
+    ksplit = 1;
+  }
   if (fused) {
     if (F->prologue < PARO_PROLOGUE_NONE || F->prologue > PARO_PROLOGUE_SILU_MUL) return fail(PARO_ERR_INVALID, "unknown prologue %d", F->prologue);
     if (rows > 4) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue is a decode path: at most 4 rows (got %lld)", (long long)rows);
@@ -225,6 +234,12 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.eps = fused ? F->eps : 0.f;
   a.residual = fused ? (const unsigned short*)F->residual : nullptr;
   a.xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue == PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
+  a.expert_idx = E ? E->expert_idx : nullptr;
+  a.wq_estride = E ? E->wq_stride_bytes : 0;
+  a.sz_estride = E ? E->sz_stride_bytes : 0;
+  a.x_sstride = E ? E->x_slot_stride : 0;
+  a.y_sstride = E ? E->y_slot_stride : 0;
+  a.x_div = E ? E->x_slot_div : 1;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
@@ -247,7 +262,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (rc != PARO_OK) return rc;
     a.x = xrot;
   }
-  dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit);
+  dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
   // [type][pre-rotated][tiles per wave - 1]; 3, 5, 6, 7 tiles exist for the fused mode only
   static const launch_fn table[2][2][8] = {
@@ -275,10 +290,17 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
 extern "C" int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                int64_t workspace_bytes, int tiles_per_wave, int ksplit, int waves, int mode,
                                void* stream) {
-  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, tiles_per_wave, ksplit, waves, mode, nullptr, stream);
+  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, tiles_per_wave, ksplit, waves, mode, nullptr, nullptr, stream);
 }
 
 extern "C" int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                      int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream) {
-  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, fusion, stream);
+  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, fusion, nullptr, stream);
+}
+
+extern "C" int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
+                                       int64_t workspace_bytes, const paro_fusion_t* fusion, const paro_experts_t* experts,
+                                       void* stream) {
+  if (!experts) return paro::fail(PARO_ERR_INVALID, "null expert descriptor");
+  return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, fusion, experts, stream);
 }

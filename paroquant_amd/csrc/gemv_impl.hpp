@@ -54,6 +54,12 @@ struct GemvArgs {
   float eps;                             // RMSNorm epsilon
   long long xstride;                     // elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
   const unsigned short* residual;        // [rows][N] added to the output, or null
+  // ---- expert slots (FUSED instantiations only; paro_w4a16_gemv_experts): blockIdx.z = slot, the slot's expert id
+  // is read from DEVICE memory; all experts share the rotation (cli/convert.py:280-379, mlx/modules.py:159-212)
+  const int* expert_idx;                 // [slots] or null
+  long long wq_estride, sz_estride;      // bytes between experts in wq / sz
+  long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
+  int x_div;
   PartTable pt;
 };
 
@@ -108,6 +114,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // rounds (each a scalar-cache miss at kernel start).
   asm volatile("" ::"s"(a.wq), "s"(a.sz), "s"(a.rot), "s"(a.cs), "s"(a.x), "s"(a.K), "s"(a.G), "s"(a.rows),
                "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts));
+  const u32x4* wq_p = a.wq;
+  const unsigned* sz_p = a.sz;
+  const unsigned short* x_p = a.x;
+  unsigned short* y_p = a.y;
+  if constexpr (FUSED != 0) {
+    if (a.expert_idx) {
+      const int z = blockIdx.z;
+      const long long ex = a.expert_idx[z];
+      wq_p = (const u32x4*)((const unsigned char*)a.wq + ex * a.wq_estride);
+      sz_p = (const unsigned*)((const unsigned char*)a.sz + ex * a.sz_estride);
+      x_p = a.x + (long long)(z / a.x_div) * a.x_sstride;
+      y_p = a.y + (long long)z * a.y_sstride;
+    }
+  }
   // DIAG 3: phase stamps (s_memtime, shader clock) into a.slabs
   unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (DIAG == 3) ts[0] = __builtin_amdgcn_s_memtime();
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     unsigned szw[TPW];
   };
 
-  const unsigned short* xrot_p = a.x + (PREROT ? (int64_t)p * a.rows * a.K : 0);
+  const unsigned short* xrot_p = x_p + (PREROT ? (int64_t)p * a.rows * a.K : 0);
   const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;  // words per group row of the scale/zero array
 
   auto load_p = [&](PBuf& b, int g) {
@@ -192,11 +212,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       for (int r = 0; r < MB; ++r) {
         const int rr = r < a.rows ? r : 0;  // clamp instead of branching: keeps the load count static
         if constexpr (FUSED) {
-          const unsigned short* xr = a.x + (int64_t)rr * a.xstride + g * 128 + 2 * lane;
+          const unsigned short* xr = x_p + (int64_t)rr * a.xstride + g * 128 + 2 * lane;
           b.xv[r] = *(const unsigned*)xr;
           if constexpr (FUSED == 2) b.xu[r] = *(const unsigned*)(xr + a.K);
         } else {
-          b.xv[r] = *(const unsigned*)(a.x + (int64_t)rr * a.K + g * 128 + 2 * lane);
+          b.xv[r] = *(const unsigned*)(x_p + (int64_t)rr * a.K + g * 128 + 2 * lane);
         }
       }
     }
@@ -208,10 +228,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int jj = j < nt ? j : nt - 1;
-      b.q[j] = __builtin_nontemporal_load(a.wq + ((int64_t)(tile0 + jj) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
+      b.q[j] = __builtin_nontemporal_load(wq_p + ((int64_t)(tile0 + jj) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
     }
     if constexpr (SZ_VEC) {
-      const unsigned* sp = a.sz + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
+      const unsigned* sp = sz_p + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
 #pragma unroll
       for (int v = 0; v < NSZ; ++v) {
         const SZV q = *(const SZV*)(sp + v * 64);
@@ -222,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int ts = ts0 + (j < nt ? j : nt - 1);
-        b.szw[j] = a.sz[(int64_t)g * szrow + ((int64_t)(ts >> 2) * 16 + n) * 4 + (ts & 3)];
+        b.szw[j] = sz_p[(int64_t)g * szrow + ((int64_t)(ts >> 2) * 16 + n) * 4 + (ts & 3)];
       }
     }
   };
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if constexpr (FUSED) {
         if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
-      a.y[(int64_t)b * a.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
     } else if (ks != a.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if constexpr (FUSED) {
         if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
-      a.y[(int64_t)b * a.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
     }
   }
   if constexpr (DIAG == 3) {
@@ -645,7 +665,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || a.residual) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || a.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

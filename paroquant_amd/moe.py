@@ -1,0 +1,106 @@
+"""Mixture-of-experts experts on the fused kernels.
+
+The reference exports MoE experts with ONE rotation per projection shared by all experts
+(``cli/convert.py:280-379``: ``{base}.{e}.{gate,up,down}_proj.{qweight,qzeros,scales}`` per expert plus
+``{base}.gate_up_weight_{theta,pairs,channel_scales}`` / ``{base}.down_weight_*``) and runs them in its MLX back-end as
+``RotateSwitchGLU`` (``mlx/modules.py:159-212``): rotate x once, gate / up of the routed experts, ``silu(gate) * up``,
+rotate the activation with the down rotation, down of the same experts -- returning the per-(token, expert) outputs;
+the router's weights are applied by the surrounding MoE block.
+
+Here, for decode-sized inputs (few tokens) the routed experts of all tokens are TWO launches: the merged gate|up
+projection of every (token, expert) slot, then the down projection with the SiLU*mul prologue -- the fused GEMV with
+``blockIdx.z`` = slot and the slot's expert id read from device memory (``paro_w4a16_gemv_experts``), the shared
+rotation packed once.  Larger token counts group the tokens by expert and run each expert's rows through the
+prefill GEMM path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as nat
+from . import ops
+from .linear import PackedParoWeights
+
+_DECODE_SLOTS = 64      # (tokens x experts-per-token) up to which the slot kernels are used
+
+
+class ParoMoEExperts:
+    """The routed experts of one MoE layer.  ``tensors``: the checkpoint tensors under the experts' base prefix --
+    ``"{e}.gate_proj.qweight"`` ..., ``"gate_up_weight_theta"``, ``"down_weight_pairs"`` ... (cli/convert.py:381-405)."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], num_experts: int, device):
+        dev = torch.device(device)
+        g = lambda k: tensors[k].to(dev)
+        self.E = int(num_experts)
+        self.H = int(tensors["0.gate_proj.qweight"].shape[0])
+        self.I = int(tensors["0.down_proj.qweight"].shape[0])
+        self.device = dev
+        self.gate_up, self.down = [], []
+        gu_rot = (g("gate_up_weight_theta"), g("gate_up_weight_pairs"), g("gate_up_weight_channel_scales"))
+        dn_rot = (g("down_weight_theta"), g("down_weight_pairs"), g("down_weight_channel_scales"))
+        for e in range(self.E):
+            qw = torch.cat([g(f"{e}.gate_proj.qweight"), g(f"{e}.up_proj.qweight")], dim=1)
+            qz = torch.cat([g(f"{e}.gate_proj.qzeros"), g(f"{e}.up_proj.qzeros")], dim=1)
+            sc = torch.cat([g(f"{e}.gate_proj.scales"), g(f"{e}.up_proj.scales")], dim=1)
+            # gate|up is ONE rotation partition of 2 I columns (both halves see the same rotated x)
+            self.gate_up.append(PackedParoWeights(qw, qz, sc, *gu_rot, [2 * self.I], wq_order=0))
+            self.down.append(PackedParoWeights(g(f"{e}.down_proj.qweight"), g(f"{e}.down_proj.qzeros"), g(f"{e}.down_proj.scales"),
+                                               *dn_rot, [self.H], wq_order=0))
+        # the slot kernels index experts with a uniform byte stride: stack the packed buffers
+        self.gu_wq = torch.stack([p.wq for p in self.gate_up]).contiguous()
+        self.gu_sz = torch.stack([p.sz for p in self.gate_up]).contiguous()
+        self.dn_wq = torch.stack([p.wq for p in self.down]).contiguous()
+        self.dn_sz = torch.stack([p.sz for p in self.down]).contiguous()
+        for e in range(self.E):     # the per-expert views now alias the stacks (one copy of the weights)
+            self.gate_up[e].wq, self.gate_up[e].sz = self.gu_wq[e], self.gu_sz[e]
+            self.down[e].wq, self.down[e].sz = self.dn_wq[e], self.dn_sz[e]
+
+    # ------------------------------------------------------------------ decode: two launches for all slots
+    def _slots(self, pk0: PackedParoWeights, wq: torch.Tensor, sz: torch.Tensor, x: torch.Tensor, y: torch.Tensor,
+               idx: torch.Tensor, x_div: int, prologue: int) -> None:
+        lib = nat.load()
+        d = ops.make_desc(pk0.K, pk0.partition_sizes, int(pk0.pairs.size(1)), x.dtype, wq, sz, pk0.rot, pk0.pairs, pk0.theta,
+                          pk0.channel_scales, None, 0)
+        f = nat.ParoFusion()
+        f.prologue, f.eps, f.x_stride, f.residual = int(prologue), 0.0, 0, None
+        e = nat.ParoExperts()
+        e.expert_idx, e.n_slots, e.x_slot_div = idx.data_ptr(), int(idx.numel()), int(x_div)
+        e.wq_stride_bytes, e.sz_stride_bytes = wq.stride(0) * 4, sz.stride(0) * 4
+        e.x_slot_stride, e.y_slot_stride = x.stride(0), y.stride(0)
+        ws = pk0.workspace
+        with torch.cuda.device(x.device):
+            nat.check(lib.paro_w4a16_gemv_experts(ctypes.byref(d), x.data_ptr(), y.data_ptr(), 1, ws.data_ptr(),
+                                                  ws.numel(), ctypes.byref(f), ctypes.byref(e), nat.current_stream_ptr(x.device)))
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+        """x [T, H] (fp16 / bf16), indices [T, k] expert ids -> [T, k, H] per-slot expert outputs."""
+        T, k = indices.shape
+        x = x.reshape(T, self.H).contiguous()
+        out = torch.empty(T, k, self.H, dtype=x.dtype, device=x.device)
+        if T * k <= _DECODE_SLOTS:
+            idx = indices.reshape(-1).to(torch.int32).contiguous()
+            gu = torch.empty(T * k, 2 * self.I, dtype=x.dtype, device=x.device)
+            self._slots(self.gate_up[0], self.gu_wq, self.gu_sz, x, gu, idx, k, nat.PROLOGUE_NONE)
+            self._slots(self.down[0], self.dn_wq, self.dn_sz, gu, out.view(T * k, self.H), idx, 1, nat.PROLOGUE_SILU_MUL)
+            return out
+        # prefill: group the (token, slot) pairs by expert, run each expert's rows through the GEMM path
+        flat = indices.reshape(-1)
+        order = torch.argsort(flat, stable=True)
+        counts = torch.bincount(flat, minlength=self.E).tolist()
+        tok = (order // k)
+        outf = out.view(T * k, self.H)
+        start = 0
+        for e, n in enumerate(counts):
+            if n == 0:
+                continue
+            sel = order[start:start + n]
+            xe = x[tok[start:start + n]]
+            gu = self.gate_up[e].apply(xe)
+            act = torch.nn.functional.silu(gu[:, :self.I]) * gu[:, self.I:]
+            outf[sel] = self.down[e].apply(act.contiguous())
+            start += n
+        return out

@@ -972,3 +972,44 @@ def test_lm_head_and_argmax(dev, dtype, V, H):
     out = torch.zeros(16, dtype=torch.int64, device=dev)
     ops.argmax_advance(ws, V, tok, pos, out)
     assert int(tok.item()) == int(torch.argmax(logits, dim=-1).item()) and int(pos.item()) == 4 and int(out[3].item()) == 7
+
+
+# ---------------------------------------------------------------- f4: mixture-of-experts (shared rotation, routed experts)
+
+@pytest.mark.parametrize("E,H,I,T,k", [(8, 512, 256, 1, 2), (16, 2048, 768, 1, 8), (8, 512, 256, 3, 4), (4, 256, 128, 40, 2)])
+def test_moe_experts_match_oracle(dev, E, H, I, T, k):
+    """Routed experts with one shared rotation per projection (cli/convert.py:280-379, mlx/modules.py:159-212): the
+    slot kernels (decode: T * k <= 64, two launches for all slots) and the grouped prefill path against the oracle."""
+    from paroquant_amd.moe import ParoMoEExperts
+    experts, rot = po.make_moe(E * 1000 + H + T, E, H, I)
+    tensors = {}
+    for proj, d in experts.items():
+        for name, stack in d.items():
+            for e in range(E):
+                tensors[f"{e}.{proj}.{name}"] = torch.from_numpy(stack[e])
+    for name, v in rot.items():
+        tensors[name] = torch.from_numpy(v)
+    moe = ParoMoEExperts(tensors, E, dev)
+    rng = np.random.default_rng(T + k)
+    x = rng.standard_normal((T, H)).astype(np.float16)
+    idx = np.stack([rng.choice(E, size=k, replace=False) for _ in range(T)]).astype(np.int64)
+    y = moe(_t(x, dev), _t(idx, dev))
+    assert y.shape == (T, k, H) and y.dtype == torch.float16
+    ref = po.moe_experts_forward(x, idx, experts, rot)
+    assert po.rel_err(_np(y), ref) < 4e-3
+    # deterministic, and capturable at decode size (expert ids come from device memory)
+    if T * k <= 64:
+        assert torch.equal(moe(_t(x, dev), _t(idx, dev)), y)
+        xs, ids = _t(x, dev), _t(idx, dev)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            moe(xs, ids)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            yg = moe(xs, ids)
+        ids.copy_(torch.flip(ids, dims=[1]))        # other experts per slot, same graph
+        g.replay()
+        torch.cuda.synchronize()
+        assert po.rel_err(_np(yg), ref[:, ::-1]) < 4e-3

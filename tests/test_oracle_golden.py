@@ -119,6 +119,34 @@ def test_g6_quantize_layer_end_to_end(golden_dir):
     assert po.rel_err(y, y_ref) < 2e-3    # only fp16 storage of scales / channel_scales / theta separates the two
 
 
+# ---- G9: MoE expert export (cli/convert.py:280-379) --------------------------------------------------------
+
+def test_g9_quantize_moe(golden_dir):
+    """`_quantize_moe` run by the reference on a synthetic 3-expert block: the oracle's restatement reproduces every
+    per-expert AWQ buffer bit for bit (gate = first half of the gate_up rows, up = second half) and the shared
+    rotation buffers (channel scales inverted, theta fp16, pairs int16) with their checkpoint names."""
+    g = _load(golden_dir, "quantize_moe.npz")
+    i = lambda k: g["in_" + k]
+    bufs, rot = po.quantize_moe(i("gate_up_weight"), i("down_weight"), i("gate_up_pairs_grouped"), i("gate_up_angles_grouped"),
+                                i("gate_up_channel_scales"), i("gate_up_quantizer__scale"), i("gate_up_quantizer__zero_point_float"),
+                                i("down_pairs_grouped"), i("down_angles_grouped"), i("down_channel_scales"),
+                                i("down_quantizer__scale"), i("down_quantizer__zero_point_float"), int(g["bits"]), int(g["group_size"]))
+    for proj in ("gate_proj", "up_proj", "down_proj"):
+        for k in ("qweight", "qzeros", "scales"):
+            a, b = bufs[proj][k], g[f"out_{proj}_{k}"]
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (proj, k)
+    for k, v in rot.items():
+        b = g["rot_" + k]
+        assert v.shape == b.shape and v.dtype == b.dtype and np.array_equal(v.view(np.uint8), b.view(np.uint8)), k
+    assert int(g["krot"]) == 8
+    # the exported experts run through the oracle forward: finite, and expert order matters (routing is not a no-op)
+    x = np.random.default_rng(0).standard_normal((2, 256))
+    y01 = po.moe_experts_forward(x, np.array([[0, 1], [2, 0]]), bufs, rot)
+    y10 = po.moe_experts_forward(x, np.array([[1, 0], [0, 2]]), bufs, rot)
+    assert y01.shape == (2, 2, 256) and np.isfinite(y01).all()
+    assert np.allclose(y01[:, 0], y10[:, 1]) and np.allclose(y01[:, 1], y10[:, 0]) and not np.allclose(y01[:, 0], y01[:, 1])
+
+
 # ---- G7: rotation orientation + pair layout pinned by the reference's analytic d/dtheta ---------------
 # (kernels/cuda/autograd.py:40-52, evaluated by importing the reference -- tests/golden/make_golden_g7.py)
 
