@@ -22,7 +22,8 @@ PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
 PARO_WS_STATUS_GIVEUP = 0xDEAD
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libparo_mi355x.so")
+# PARO_LIB_DIR: directory (relative to the package) of an experiment build of the library (A/B runs of kernel variants)
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PARO_LIB_DIR", "_lib"), "libparo_mi355x.so")
 
 EXPORTS = (
     "paro_abi_version",

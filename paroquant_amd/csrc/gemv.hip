@@ -230,6 +230,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
   static const int env_skew = getenv("PARO_GEMV_SKEW") ? atoi(getenv("PARO_GEMV_SKEW")) : 1;
   a.skew = env_skew;
+  static const int env_prio = getenv("PARO_GEMV_PRIO") ? atoi(getenv("PARO_GEMV_PRIO")) : 1;
+  a.prio = env_prio;
   a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
   a.eps = fused ? F->eps : 0.f;
   a.residual = fused ? (const unsigned short*)F->residual : nullptr;

@@ -49,6 +49,7 @@ struct GemvArgs {
   int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
   int skew;                              // 1: uneven unit split inside the workgroup (see the driver loop)
+  int prio;                              // 1: coefficient requests of ALL waves go out before any tile request (s_setprio)
   // ---- prologue / epilogue fusions (FUSED instantiations only; paro_w4a16_gemv_fused)
   int prologue;                          // PARO_PROLOGUE_NONE / _RMSNORM / _SILU_MUL
   float eps;                             // RMSNorm epsilon
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // block with ONE batch of scalar loads and one wait instead of sinking them into three dependent
   // rounds (each a scalar-cache miss at kernel start).
   asm volatile("" ::"s"(a.wq), "s"(a.sz), "s"(a.rot), "s"(a.cs), "s"(a.x), "s"(a.K), "s"(a.G), "s"(a.rows),
-               "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts));
+               "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts), "s"(a.skew), "s"(a.prio),
+               "s"(a.krot), "s"(a.ksplit), "s"(a.pt.cb_start[1]), "s"(a.pt.cb_start[2]), "s"(a.pt.cb_start[7]));
   const u32x4* wq_p = a.wq;
   const unsigned* sz_p = a.sz;
   const unsigned short* x_p = a.x;
@@ -143,8 +145,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // the whole argument block is then fetched in ONE batch of scalar loads instead of six dependent
   // round trips (measured: 2300 cycles from workgroup start to the first global load before this).
   int p = 0, p_cb0 = a.pt.cb_start[0], p_t0 = a.pt.tile_start[0], p_t1 = a.pt.tile_start[1], p_sz0 = a.pt.szt_start[0];
+#ifndef PARO_NP_LIMIT
+#define PARO_NP_LIMIT PARO_MAX_PARTS
+#endif
 #pragma unroll
-  for (int q = 1; q < PARO_MAX_PARTS; ++q) {
+  for (int q = 1; q < PARO_NP_LIMIT; ++q) {
     const bool in = q < a.pt.nparts && cb >= a.pt.cb_start[q];
     p = in ? q : p;
     p_cb0 = in ? a.pt.cb_start[q] : p_cb0;
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   unsigned short* xh = (unsigned short*)(lds + wave * XH_BYTES);
   if constexpr (!PREROT) {
-    for (int c = lane; c < kXhStride; c += 64) xh[MB * kXhStride + c] = 0;  // zero row
+    // zero row (136 halves): one predicated 8-byte store instead of three 2-byte ones
+    static_assert(kXhStride % 4 == 0 && (XH_BYTES % 16) == 0, "zero-row store alignment");
+    if (lane < kXhStride / 4) *(u32x2*)(xh + MB * kXhStride + 4 * lane) = (u32x2){0u, 0u};
   }
 
   const int n = lane & 15, mq = lane >> 4;
@@ -473,7 +480,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     };
     const bool has_work = my_count > 0;
     const int gf = has_work ? unit_group(0) : a.G - 1;
+    // The CU returns vector-memory data in request order.  Left alone, each SIMD issues [wave 0: coefficients, tiles]
+    // [wave 4: coefficients, tiles] ..., so the small L2-resident coefficient loads of the later waves come back
+    // behind the earlier waves' HBM tile loads (per-wave timeline: first coefficients at 2400 / 3100 / 4100 / 5200
+    // cycles for the four waves of a SIMD, and they finish that much apart).  Every wave therefore runs at priority 3
+    // until its first coefficient requests are out and drops to 0 before its tile requests: the issue arbiter
+    // (priority, then age) then lets every wave's coefficients go first.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     load_p(pc, gf);
+    if (a.prio) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+    }
     load_t(tc, gf);
     if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
     for (int i = 0; i + 1 < my_count; ++i) {

@@ -1,0 +1,8 @@
+#!/bin/bash
+O=gpurun_out/r02; mkdir -p $O
+for lib in _lib _lib_np3 _lib _lib_np3; do
+  for wl in qwen3-4b llama3-8b; do
+    PARO_LIB_DIR=$lib PARO_GEMV_PRIO=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline --per-shape 2> $O/s17_tmp.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', '$wl', d['value'], 'tok/s', d['roofline']['frac'])"
+    grep us_per_launch $O/s17_tmp.jsonl | python -c "import sys,json; print('   ', [ (json.loads(l)['linear'], json.loads(l)['us_per_launch']) for l in sys.stdin])"
+  done
+done | tee $O/s17_np3.txt

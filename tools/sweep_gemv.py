@@ -66,8 +66,11 @@ def main():
 
             def run(i, tpw=tpw, ksp=ksp, wv=wv, mode=mode):
                 return ops.w4a16_gemv_tuned(x, packs[i % copies], tpw, ksp, wv, mode)
-            for i in range(3):
-                run(i)
+            try:
+                for i in range(3):
+                    run(i)
+            except RuntimeError:        # launch shape not built / K-split grid not resident: not a candidate
+                continue
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
