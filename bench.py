@@ -242,6 +242,33 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
                       f"tokens/s = 1 / (ms_per_layer * {L})"}
 
 
+def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5, warmup: int = 2):
+    """End-to-end batch-1 greedy decode of the whole model on the fused harness (paroquant_amd/decoder.py: five launches
+    per layer + final norm / lm_head / argmax, one HIP graph per token), with the reference's benchmark protocol
+    (cli/benchmark.py:8-26: 2 warm-up + 5 runs, 128 new tokens; inference/base.py:62-77: tps = decode tokens /
+    (t_end - t_first_token)).  Synthetic weights of the architecture, full vocabulary."""
+    from paroquant_amd.decoder import MODEL_CONFIGS, ParoDecoderLM
+    if model not in MODEL_CONFIGS:
+        return None
+    lm = ParoDecoderLM.random(model, dev, max_positions=prompt + new + 8)
+    ids = torch.randint(0, lm.cfg.vocab, (prompt,), device=dev)
+    stats = []
+    for i in range(warmup + runs):
+        _, st = lm.generate(ids, new)
+        if i >= warmup:
+            stats.append(st)
+    tps = float(np.median([s_["decode_tokens_per_s"] for s_ in stats]))
+    ms = float(np.median([s_["ms_per_token"] for s_ in stats]))
+    lm_head_bytes = lm.cfg.vocab * lm.cfg.hidden * 2
+    return {"value": round(tps, 1), "unit": "tokens/s", "ms_per_token": round(ms, 4),
+            "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
+            "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
+            "launches_per_token": 5 * lm.cfg.n_layers + 3,
+            "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),
+            "GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),
+            "note": "whole model: fused GEMVs (RMSNorm / SiLU*mul / residual fused), decode attention with KV cache, fp16 lm_head"}
+
+
 def newest_pmc_file(model: str, explicit: str = ""):
     """profiles/rNN_pmc_bench_<model>.json of the latest round (or the file named on the command line)."""
     import glob
@@ -263,6 +290,7 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end decode leg (fused harness: attention, norms, lm_head)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table to stderr")
     ap.add_argument("--pmc-file", default="", help="PMC summary json for roofline.traffic (default: newest profiles/rNN_pmc_bench_<model>.json)")
@@ -420,6 +448,34 @@ def run(args, rank: int, local_rank: int, world: int):
         "roofline": roofline,
     }
 
+    if tp_mode and world > 1:
+        # like-for-like reference for the scaling curve: the SAME model unsharded on one GPU (rank 0), measured on a few
+        # layers and scaled to the full depth (per-layer time is depth-independent: distinct weights per layer)
+        ref = None
+        if rank == 0:
+            try:
+                nl = min(8, MODELS[model][4])
+                s1 = DecodeStack(model, dev, n_layers=nl, tp=1, rank=0, seed=123)
+                s1.step(s1.x)
+                torch.cuda.synchronize(dev)
+                g1 = torch.cuda.CUDAGraph()
+                sst = torch.cuda.Stream(dev)
+                sst.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(sst):
+                    s1.step(s1.x)
+                torch.cuda.current_stream(dev).wait_stream(sst)
+                with torch.cuda.graph(g1):
+                    s1.step(s1.x)
+                _, ev1 = time_steps(g1.replay, 20, 3, 1, dev)
+                ms_layer = ev1 / 20 / nl
+                ref = {"tokens_per_s": round(1e3 / (ms_layer * MODELS[model][4]), 2), "layers_measured": nl,
+                       "note": "same model, TP=1, one GPU; per-layer time x full depth"}
+                del s1, g1
+            except Exception as e:
+                ref = {"error": f"{type(e).__name__}: {e}"}
+        dist.barrier()
+        result["config"]["tp1_reference"] = ref
+
     if rank == 0:
         if args.per_shape:
             for row in per_shape_table(model, dev):
@@ -428,6 +484,13 @@ def run(args, rank: int, local_rank: int, world: int):
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
         else:
             result["cpu_baseline"] = None
+        if not args.no_e2e and world == 1 and not tp_mode and stack.n_layers == MODELS[model][4]:
+            del stack
+            torch.cuda.empty_cache()
+            try:
+                result["end_to_end"] = end_to_end(model, dev)
+            except Exception as e:       # reported, never fatal for the contract line
+                result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -22,7 +22,10 @@ def short(name: str) -> str:
         at = "f16" if m.group(1) == "DF16_" else "bf16"
         return f"paro::gemv_kernel<{at},tpw={m.group(2)},rows<={m.group(3)},waves={m.group(4)},prerot={m.group(5)},pd={m.group(6)}>"
     m = re.search(r"paro::(\w+)", name)
-    return ("paro::" + m.group(1)) if m else name[:60]
+    if m:
+        return "paro::" + m.group(1)
+    m = re.search(r"_ZN4paro\d+(\w+?_kernel)I(\w*?)EEv", name)      # other mangled templates: attn / gemm3 / lm_head
+    return ("paro::" + m.group(1) + "<" + m.group(2) + ">") if m else name[:60]
 
 
 def counter_rows(d):
