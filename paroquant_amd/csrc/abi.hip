@@ -52,7 +52,7 @@ extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y,
   // two column tiles fit a wave, and every workgroup re-reads all of x_rot -- wide outputs above 32 rows stay
   // on the GEMM).  PARO_SKINNY=0 routes everything above 16 rows to the GEMM (A/B runs).
   static const int skinny = getenv("PARO_SKINNY") ? atoi(getenv("PARO_SKINNY")) : 1;
-  if (skinny && rows <= 64 && L && L->act_dtype == PARO_DTYPE_F16 && !(rows > 32 && L->N / 16 >= 1024))
+  if (skinny && rows <= 64 && L && !(rows > 32 && L->N / 16 >= 1024))   // fp16 and bf16 alike
     return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 1, stream);
   return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, PARO_GEMM_AUTO, stream);
 }

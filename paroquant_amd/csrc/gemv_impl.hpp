@@ -144,25 +144,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // Partition lookup with compile-time kernarg offsets only (select chain, no data-dependent s_load):
   // the whole argument block is then fetched in ONE batch of scalar loads instead of six dependent
   // round trips (measured: 2300 cycles from workgroup start to the first global load before this).
-  int p = 0, p_cb0 = a.pt.cb_start[0], p_t0 = a.pt.tile_start[0], p_t1 = a.pt.tile_start[1], p_sz0 = a.pt.szt_start[0];
+  // The FIRST thing a wave requests is its first unit's coefficients (exchange schedule, channel scales, x): they need
+  // only the partition index and the wave's first group, so those are computed -- and the requests issued -- before
+  // the tile bookkeeping below (the scalar prologues of the waves that share a SIMD run one after the other: every
+  // scalar instruction in front of the first request delays the later waves' requests several times over).
+  int p = 0;
 #ifndef PARO_NP_LIMIT
 #define PARO_NP_LIMIT PARO_MAX_PARTS
 #endif
 #pragma unroll
-  for (int q = 1; q < PARO_NP_LIMIT; ++q) {
-    const bool in = q < a.pt.nparts && cb >= a.pt.cb_start[q];
-    p = in ? q : p;
-    p_cb0 = in ? a.pt.cb_start[q] : p_cb0;
-    p_t0 = in ? a.pt.tile_start[q] : p_t0;
-    p_t1 = in ? a.pt.tile_start[q + 1] : p_t1;
-    p_sz0 = in ? a.pt.szt_start[q] : p_sz0;
-  }
-  const int ltile0 = (cb - p_cb0) * TPW;
-  const int tile0 = p_t0 + ltile0;
-  const int nt = min(TPW, p_t1 - tile0);
-  const int ts0 = p_sz0 + ltile0;
+  for (int q = 1; q < PARO_NP_LIMIT; ++q) p = (q < a.pt.nparts && cb >= a.pt.cb_start[q]) ? q : p;
   const int g_begin = ks * a.gps;
   const int g_end = min(a.G, g_begin + a.gps);
+  const int n_local = g_end - g_begin;
+  const int gf_first = wave < n_local ? g_begin + wave : a.G - 1;   // == unit_group(0), or the clamped dummy unit
 
   unsigned short* xh = (unsigned short*)(lds + wave * XH_BYTES);
   if constexpr (!PREROT) {
@@ -196,7 +191,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   };
 
   const unsigned short* xrot_p = x_p + (PREROT ? (int64_t)p * a.rows * a.K : 0);
-  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;  // words per group row of the scale/zero array
 
   auto load_p = [&](PBuf& b, int g) {
     if constexpr (PREROT) {
@@ -228,6 +222,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
     }
   };
+  // ---- first unit's coefficient requests, at priority 3 (see the note at the driver loop), then the bookkeeping
+  PBuf pc_first;
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
+  load_p(pc_first, gf_first);
+  __builtin_amdgcn_sched_barrier(0);
+  if (a.prio) __builtin_amdgcn_s_setprio(0);
+
+  // ---- tile bookkeeping of this column block (after the coefficient requests are out)
+  int p_cb0 = a.pt.cb_start[0], p_t0 = a.pt.tile_start[0], p_t1 = a.pt.tile_start[1], p_sz0 = a.pt.szt_start[0];
+#pragma unroll
+  for (int q = 1; q < PARO_NP_LIMIT; ++q) {
+    const bool in = q < a.pt.nparts && cb >= a.pt.cb_start[q];
+    p_cb0 = in ? a.pt.cb_start[q] : p_cb0;
+    p_t0 = in ? a.pt.tile_start[q] : p_t0;
+    p_t1 = in ? a.pt.tile_start[q + 1] : p_t1;
+    p_sz0 = in ? a.pt.szt_start[q] : p_sz0;
+  }
+  const int ltile0 = (cb - p_cb0) * TPW;
+  const int tile0 = p_t0 + ltile0;
+  const int nt = min(TPW, p_t1 - tile0);
+  const int ts0 = p_sz0 + ltile0;
+  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;  // words per group row of the scale/zero array
+
   // Every load is unconditional (ragged column blocks re-read their last tile and mask it later; waves
   // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
   // for coefficients never waits for the younger tile loads (vmcnt retires in order).
@@ -460,7 +477,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // a.skew the first wave of every SIMD therefore takes one unit more and the last one unit less (static,
     // so results stay bit-reproducible): rounds 0 .. c-2 as before, round c-1 without the last rank, round c
     // for the first rank only.
-    const int n_local = g_end - g_begin;
     constexpr int RANKS = WAVES / 4;
     const int c_even = n_local / WAVES;
     const bool skew = a.skew && RANKS >= 2 && n_local == c_even * WAVES && c_even >= (RANKS == 2 ? 3 : 2);
@@ -480,18 +496,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     };
     const bool has_work = my_count > 0;
     const int gf = has_work ? unit_group(0) : a.G - 1;
-    // The CU returns vector-memory data in request order.  Left alone, each SIMD issues [wave 0: coefficients, tiles]
-    // [wave 4: coefficients, tiles] ..., so the small L2-resident coefficient loads of the later waves come back
-    // behind the earlier waves' HBM tile loads (per-wave timeline: first coefficients at 2400 / 3100 / 4100 / 5200
-    // cycles for the four waves of a SIMD, and they finish that much apart).  Every wave therefore runs at priority 3
-    // until its first coefficient requests are out and drops to 0 before its tile requests: the issue arbiter
-    // (priority, then age) then lets every wave's coefficients go first.
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    load_p(pc, gf);
-    if (a.prio) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
-    }
+    // (the first unit's coefficient requests went out at kernel entry: `pc_first`, group gf == gf_first)
+    // Issue priority: the CU returns vector-memory data in request order.  Left alone, each SIMD issues
+    // [wave 0: coefficients, tiles][wave 4: coefficients, tiles] ..., so the small L2-resident coefficient loads of
+    // the later waves come back behind the earlier waves' HBM tile loads.  Every wave therefore ran at priority 3
+    // until its first coefficient requests were out and dropped to 0 before its tile requests (a.prio).
+    pc = pc_first;
     load_t(tc, gf);
     if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
     for (int i = 0; i + 1 < my_count; ++i) {

@@ -398,6 +398,19 @@ def test_gemm_and_gemv_agree(dev, wq_order):
     assert (y1.float() - y2.float()).abs().max().item() <= 2e-3 * y1.float().abs().max().item()
 
 
+@pytest.mark.parametrize("rows", [17, 32, 48, 64])
+def test_skinny_rows_bf16(dev, rows):
+    """17..64 rows with bf16 activations take the pre-rotated GEMV with 2 / 4 MFMA row tiles (as fp16 does)."""
+    K, sizes = 2048, [1024, 256]
+    L = po.make_layer(rows, K, sizes)
+    x = torch.randn(rows, K, device=dev).to(torch.bfloat16)
+    y = _packed(L, dev).apply(x)
+    assert y.dtype == torch.bfloat16
+    ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, None, ideal=True)
+    assert po.rel_err(_np(y), ideal) < TIGHT_BF16
+
+
 def test_gemm_bf16(dev):
     K, sizes, rows = 1024, [512], 200
     L = po.make_layer(55, K, sizes)
