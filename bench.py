@@ -294,6 +294,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table to stderr")
     ap.add_argument("--pmc-file", default="", help="PMC summary json for roofline.traffic (default: newest profiles/rNN_pmc_bench_<model>.json)")
+    ap.add_argument("--tp-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the N > 1 run; gloo (+ --same-device) lets the whole TP path -- sharded HIP kernels, "
+                         "all-reduce placement, max-over-ranks clock -- run with N processes on ONE GPU (tests; eager, no graph)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (only with --tp-backend gloo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise only the multi-process plumbing (spawn, rendezvous, barrier, max-over-ranks timing, JSON) "
                          "with backend gloo and a trivial CPU step -- used by the CPU test-suite; prints data: 'dry-run'")
@@ -311,7 +315,7 @@ def main(argv=None):
     # plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU, rendezvous on 127.0.0.1)
     import socket
     import torch.multiprocessing as mp
-    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+    if not args.dry_run and not args.same_device and torch.cuda.device_count() < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -368,11 +372,17 @@ def run(args, rank: int, local_rank: int, world: int):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the ParoQuant hot path)")
-    dev = torch.device("cuda", local_rank)
+    if args.same_device and args.tp_backend != "gloo":
+        raise SystemExit("--same-device needs --tp-backend gloo (RCCL refuses two ranks on one GPU)")
+    dev = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.tp_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.no_graph = True          # a gloo collective is a host operation: nothing to capture
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import paroquant_amd  # noqa: F401
     from paroquant_amd import _native
@@ -444,7 +454,8 @@ def run(args, rank: int, local_rank: int, world: int):
                                f"W4A16 g128 krot8, {'TP=%d (RCCL all-reduce after o / down)' % tp if tp_mode else 'replica per GPU'}",
                    "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
-                   "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world)},
+                   "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
+                   "collective_backend": (args.tp_backend if world > 1 and tp_mode else None)},
         "roofline": roofline,
     }
 

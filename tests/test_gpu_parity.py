@@ -1026,3 +1026,27 @@ def test_moe_experts_match_oracle(dev, E, H, I, T, k):
         g.replay()
         torch.cuda.synchronize()
         assert po.rel_err(_np(yg), ref[:, ::-1]) < 4e-3
+
+
+# ---------------------------------------------------------------- e: the tensor-parallel bench path on real kernels
+
+@pytest.mark.parametrize("world,workload", [(2, "llama3-70b-tp"), (4, "qwen3-32b-tp")])
+def test_tp_bench_path_on_one_gpu(dev, world, workload):
+    """`bench.py --gpus N --workload <70B-class>-tp` with N processes sharing this one GPU (gloo instead of RCCL, which
+    refuses two ranks per device): every rank builds its Megatron shard, runs it through the HIP kernels, all-reduces
+    after o / down, and rank 0 prints the contract line with n_gpus = N, scaling strong and the TP = 1 reference."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", "2",
+                          "--tp-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == world and r["scaling"] == "strong" and r["config"]["parallelism"] == f"tp{world}"
+    assert r["value"] > 0 and r["config"]["tp1_reference"]["tokens_per_s"] > 0
+    assert r["roofline"]["launches_per_step"] == 8
