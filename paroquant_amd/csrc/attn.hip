@@ -14,6 +14,8 @@
 // replays for every token: the grid always covers max_positions, chunks beyond `pos` exit at once.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace paro {
@@ -50,39 +52,49 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sc[NREP * kChunk];    // [NREP][chunk] scores -> probabilities (0 past the chunk)
   __shared__ __attribute__((aligned(16))) float accs[GROUPS * NREP * HD];  // [groups][NREP][hd] partial outputs
   __shared__ float knew[HD], red[8 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short q16[16 * HD];   // [16 MFMA rows][hd] roped queries (activation dtype), rows >= n_rep zero
   __shared__ unsigned last_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, s = blockIdx.y;
   const int n_rep = a.Hq / a.Hkv;
-  const int pos = *a.pos;
   const int p0 = s * kChunk;
+  // ---- every global load of the chunk is requested up front (a dependent global access costs ~1-2 us at this
+  // occupancy).  K in v_mfma_f32_16x16x32 B-fragment order: wave w owns positions 64 w .. 64 w + 63 of the chunk as four
+  // tiles of 16; lane (kb = l >> 4, n = l & 15) holds dims 32 i + 8 kb .. + 7 of position 16 t + n for k-step i: kw[t][i].
+  // V: this thread's channel pair of VN cache rows.  Chunk 0 always takes part, so ITS loads do not wait for the
+  // position to arrive from device memory (rows clamped to the cache, masked once `pos` is known); later chunks first
+  // learn from `pos` whether they run at all.
+  constexpr int KS = HD / 32;
+  u32x4 kw[4][KS];
+  const int dq = tid % half, grp = tid / half;
+  unsigned vv[VN];
+  const unsigned vtok = *((const unsigned*)(a.qkv + (int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd) + dq);   // this token's v
+  // the loads themselves are unconditional and clamped to the cache (a load inside a select becomes a branch per row:
+  // 64 serialised round trips); rows past the chunk and the new token's row are masked where they are consumed
+  auto issue_loads = [&]() {
+    const int kb = lane >> 4, nn = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = min(p0 + wave * 64 + t * 16 + nn, a.T_max - 1);
+      const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + row) * hd) + kb;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) kw[t][i] = kr[4 * i];
+    }
+    const unsigned* vbase = (const unsigned*)(a.vcache + (int64_t)h * a.T_max * hd) + dq;
+#pragma unroll
+    for (int u = 0; u < VN; ++u) vv[u] = vbase[(int64_t)min(p0 + grp + u * GROUPS, a.T_max - 1) * half];
+  };
+  if (s == 0) issue_loads();
+  const int pos = *a.pos;
   if (p0 > pos) return;                               // chunk beyond the current position (wave-uniform)
   const int n_act = pos / kChunk + 1;                 // chunks that take part
   const int cn = min(kChunk, pos + 1 - p0);           // positions of this chunk
   const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position
+  if (s != 0) issue_loads();
 
-  // ---- every global load of the chunk is requested up front (a dependent global access costs ~1-2 us at this
-  // occupancy): the K row of this thread's position, and this thread's channel pair of VN cache rows
-  u32x4 kw[HD / 8];
-  {
-    const bool ld = tid < cn && (p0 + tid) != pos;
-    const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + p0 + (ld ? tid : 0)) * hd);
-#pragma unroll
-    for (int c = 0; c < HD / 8; ++c) kw[c] = ld ? kr[c] : (u32x4){0u, 0u, 0u, 0u};
-  }
-  const int dq = tid % half, grp = tid / half;
-  unsigned vv[VN];
-  {
-    const unsigned* vbase = (const unsigned*)(a.vcache + ((int64_t)h * a.T_max + p0) * hd) + dq;
-    const unsigned* vtok = (const unsigned*)(a.qkv + (int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd) + dq;   // this token's v
-#pragma unroll
-    for (int u = 0; u < VN; ++u) {
-      const int p = grp + u * GROUPS;
-      vv[u] = (p < cn) ? ((p0 + p) != pos ? vbase[(int64_t)p * half] : *vtok) : 0u;
-    }
-  }
   // padding query heads are zero, scores past the chunk are zero: the loops below need no bounds
   for (int e = tid; e < NREP * HD; e += 256) qs[e] = 0.f;
+  for (int e = tid; e < 16 * HD / 2; e += 256) ((unsigned*)q16)[e] = 0u;
   for (int e = tid; e < NREP * kChunk; e += 256) sc[e] = 0.f;
   __syncthreads();
 
@@ -119,6 +131,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       } else {
         qs[v * hd + lane] = y0 * a.scale;
         qs[v * hd + lane + half] = y1 * a.scale;
+        q16[v * hd + lane] = A::from_f32(y0);            // exact: y0 / y1 are already rounded to the activation dtype
+        q16[v * hd + lane + half] = A::from_f32(y1);
       }
     }
   }
@@ -127,37 +141,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   __syncthreads();
   if (a.dbg == 1) return;
 
-  // ---- step 2: scores s[j][p] = q_j . K[p]; one position per thread
-  if (tid < cn) {
-    const int p = tid;
-    float dot[NREP];
+  // ---- step 2: scores s[j][p] = q_j . K[p] on the matrix cores: A = queries (row m = head, zero rows past n_rep),
+  // B = the K fragments requested at the top; D[row 4 (l >> 4) + r][col l & 15] = (head, position)
+  {
+    typedef typename A::vec8 vec8;
+    vec8 qa[KS];
+    const int kb = lane >> 4, mm = lane & 15;
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) dot[j] = 0.f;
-    const bool is_new = (p0 + p) == pos;
+    for (int i = 0; i < KS; ++i) qa[i] = *(const vec8*)(q16 + mm * hd + 32 * i + 8 * kb);
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      float kf[8];
+    for (int t = 0; t < 4; ++t) {
+      f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        kf[2 * e] = A::to_f32(kw[c][e] & 0xffffu);
-        kf[2 * e + 1] = A::to_f32(kw[c][e] >> 16);
-      }
-      if (is_new) {
+      for (int i = 0; i < KS; ++i) dacc = A::mfma(qa[i], __builtin_bit_cast(vec8, kw[t][i]), dacc);
+      const int pp = wave * 64 + t * 16 + mm;
+      if (pp < cn) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) kf[e] = knew[c * 8 + e];
-      }
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const f32x4 q0 = *(const f32x4*)(qs + j * hd + c * 8), q1 = *(const f32x4*)(qs + j * hd + c * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dot[j] = __builtin_fmaf(q0[e], kf[e], dot[j]);
-          dot[j] = __builtin_fmaf(q1[e], kf[4 + e], dot[j]);
+        for (int r = 0; r < 4; ++r) {
+          const int j = 4 * kb + r;
+          if (j < NREP) sc[j * kChunk + pp] = dacc[r] * a.scale;
         }
       }
     }
+  }
+  __syncthreads();
+  // the new token's key is not in the cache yet (it was written above by this workgroup): its column is recomputed
+  // from the LDS copy, one wave per query head
+  if (own_new) {
+    for (int j = wave; j < n_rep; j += 4) {
+      float d = 0.f;
+      for (int e = lane; e < hd; e += 64) d = __builtin_fmaf(qs[j * hd + e], knew[e], d);
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) sc[j * kChunk + p] = dot[j];
+      for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+      if (lane == 0) sc[j * kChunk + (pos - p0)] = d;
+    }
   }
   __syncthreads();
   if (a.dbg == 2) return;
@@ -192,7 +209,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     const float* scg = sc + grp;
 #pragma unroll
     for (int u = 0; u < VN; ++u) {
-      const float v0 = A::to_f32(vv[u] & 0xffffu), v1 = A::to_f32(vv[u] >> 16);
+      const int p = grp + u * GROUPS;                 // rows past the chunk -> 0, the new row -> this token's v
+      const unsigned vw = (p < cn) ? ((p0 + p) != pos ? vv[u] : vtok) : 0u;
+      const float v0 = A::to_f32(vw & 0xffffu), v1 = A::to_f32(vw >> 16);
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
         const float e = scg[j * kChunk + u * GROUPS];
