@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   };
   if (s == 0) issue_loads();
   const int pos = *a.pos;
-  if (p0 > pos) return;                               // chunk beyond the current position (wave-uniform)
+  if (p0 > pos || pos >= a.T_max || pos < 0) return;  // chunk beyond the current position; a position outside the cache writes nothing
   const int n_act = pos / kChunk + 1;                 // chunks that take part
   const int cn = min(kChunk, pos + 1 - p0);           // positions of this chunk
   const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position

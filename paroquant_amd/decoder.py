@@ -200,7 +200,10 @@ class ParoDecoderLM:
         self.gu_buf = torch.zeros(1, 2 * c.inter, dtype=dt, device=dev)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
-        self.attn_ws = ops.attn_workspace(dev, c.n_heads, c.n_kv_heads, c.head_dim, c.max_positions)
+        # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
+        # different streams at the same time and must not share tickets
+        self.attn_ws = torch.zeros(nat.load().paro_attn_decode_workspace_bytes(c.n_heads, c.n_kv_heads, c.head_dim, c.max_positions),
+                                   dtype=torch.uint8, device=dev)
         self.lm_ws = ops.lm_head_workspace(dev, c.vocab)
         self.lm_head = self.lm_head.contiguous()
         # the fused tail (final norm + lm_head GEMV + argmax, 2 launches) needs hidden = 512 * 1..8;

@@ -147,8 +147,11 @@ class PackedParoWeights:
         (``cs'[p, k] = cs[p, k] * w[k]``, fp32 product rounded once): with it the whole norm in front of the linear
         reduces to the scalar ``rsqrt(mean(x^2) + eps)`` that the fused GEMV applies (``ops.w4a16_gemv_fused``,
         prologue RMSNORM).  Call once, after loading."""
+        if getattr(self, "_norm_folded", False):
+            raise RuntimeError("a norm weight has already been folded into these channel scales")
         w = weight.to(self.channel_scales.device).float().view(1, self.K)
         self.channel_scales = (self.channel_scales.float() * w).to(torch.float16).contiguous()
+        self._norm_folded = True
         self._rmat = {}
         return self
 

@@ -322,7 +322,8 @@ _attn_ws: dict = {}
 
 def attn_workspace(device, n_heads: int, n_kv_heads: int, head_dim: int, max_positions: int) -> torch.Tensor:
     """Zero-filled scratch of ``paro_attn_decode`` (arrival tickets + partial results of the position chunks); one per
-    (device, geometry), shared by all layers of a model that run on one stream."""
+    (device, geometry), shared by every caller that does not pass its own -- fine for launches on ONE stream; anything
+    that may overlap in time (two models, two streams) must own its workspace (``ParoDecoderLM`` does)."""
     lib = nat.load()
     device = torch.device(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), n_heads, n_kv_heads, head_dim, max_positions)
