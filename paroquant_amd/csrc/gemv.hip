@@ -208,34 +208,31 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   hipStream_t st = (hipStream_t)stream;
 
   GemvArgs a;
-  a.wq = (const u32x4*)L->wq;
-  a.sz = (const unsigned*)L->sz;
-  a.rot = (const unsigned*)L->rot;
-  a.cs = (const unsigned short*)L->channel_scales;
-  a.bias = (const unsigned short*)L->bias;
-  a.x = (const unsigned short*)x;
-  a.y = (unsigned short*)y;
-  a.K = (int)L->K;
-  a.N = (int)L->N;
-  a.G = G;
-  a.rows = (int)rows;
-  a.krot = L->krot;
-  a.tstride = L->wq_order ? 1 : G;
-  a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  a.gps = (G + ksp - 1) / ksp;
-  a.ksplit = (G + a.gps - 1) / a.gps;  // drop empty splits
-  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, tpw)) return fail(PARO_ERR_INVALID, "bad partition table");
-  a.slabs = nullptr;
-  a.counters = nullptr;
+  PartTable pt;
+  if (!fill_part_table(pt, L->n_parts, L->part_cols, tpw)) return fail(PARO_ERR_INVALID, "bad partition table");
   static const int env_pd = getenv("PARO_GEMV_PD") ? atoi(getenv("PARO_GEMV_PD")) : 0;
   static const int env_skew = getenv("PARO_GEMV_SKEW") ? atoi(getenv("PARO_GEMV_SKEW")) : 1;
-  a.skew = env_skew;
   static const int env_prio = getenv("PARO_GEMV_PRIO") ? atoi(getenv("PARO_GEMV_PRIO")) : 1;
-  a.prio = env_prio;
+  a.hot.wq = (const u32x4*)L->wq;
+  a.hot.sz = (const unsigned*)L->sz;
+  a.hot.rot = (const unsigned*)L->rot;
+  a.hot.cs = (const unsigned short*)L->channel_scales;
+  a.hot.x = (const unsigned short*)x;
+  a.hot.G = (unsigned)G;
+  a.hot.tstride = L->wq_order ? 1 : G;
+  a.hot.gstride = L->wq_order ? (int)(L->N / 16) : 1;
+  a.hot.residual = fused ? (const unsigned short*)F->residual : nullptr;
+  a.hot.N = (int)L->N;
+  a.hot.eps = fused ? F->eps : 0.f;
+  a.bias = (const unsigned short*)L->bias;
+  a.y = (unsigned short*)y;
+  a.rows = (int)rows;
+  int gps = (G + ksp - 1) / ksp;
+  a.ksplit = (G + gps - 1) / gps;  // drop empty splits
+  a.slabs = nullptr;
+  a.counters = nullptr;
   a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
-  a.eps = fused ? F->eps : 0.f;
-  a.residual = fused ? (const unsigned short*)F->residual : nullptr;
-  a.xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue == PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
+  const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue == PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.expert_idx = E ? E->expert_idx : nullptr;
   a.wq_estride = E ? E->wq_stride_bytes : 0;
   a.sz_estride = E ? E->sz_stride_bytes : 0;
@@ -243,6 +240,10 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.y_sstride = E ? E->y_slot_stride : 0;
   a.x_div = E ? E->x_slot_div : 1;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
+  auto repack_hot = [&]() {
+    return pack_hot(a.hot, pt, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride);
+  };
+  if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 
   const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
@@ -250,11 +251,11 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (slab_bytes + xrot_bytes > 0) {
     if (!workspace || workspace_bytes < need)
       return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
-    if ((int64_t)a.pt.cbs * 4 > PARO_WS_COUNTER_BYTES) return fail(PARO_ERR_INVALID, "too many column blocks for the counter area");
+    if ((int64_t)pt.cbs * 4 > PARO_WS_COUNTER_BYTES) return fail(PARO_ERR_INVALID, "too many column blocks for the counter area");
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
-  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)a.pt.cbs * 640)
+  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
   if (mode == 1) {
     unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);
@@ -262,9 +263,9 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
                        PARO_DTYPE_F16, st, L->n_parts);
     if (rc != PARO_OK) return rc;
-    a.x = xrot;
+    a.hot.x = xrot;
   }
-  dim3 grid((unsigned)a.pt.cbs, (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
+  dim3 grid((unsigned)pt.cbs, (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
   // [type][pre-rotated][tiles per wave - 1]; 3, 5, 6, 7 tiles exist for the fused mode only
   static const launch_fn table[2][2][8] = {
@@ -280,8 +281,9 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1) {
     // the automatic K-split does not fit this instantiation's real occupancy: run unsplit (always legal)
     a.ksplit = 1;
-    a.gps = G;
-    rc = fn(a, wv, dim3((unsigned)a.pt.cbs, 1), st);
+    gps = G;
+    repack_hot();
+    rc = fn(a, wv, dim3((unsigned)pt.cbs, 1), st);
   }
   if (rc == PARO_ERR_NOT_RESIDENT) rc = PARO_ERR_UNSUPPORTED;
   if (rc != PARO_OK) return rc;

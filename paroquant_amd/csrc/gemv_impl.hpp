@@ -29,40 +29,75 @@
 //     write-through (sc1) store per output and exit; the last split polls them (sc1 loads, bounded
 //     spin), re-arms them, and writes y exactly once -- no fences, no tickets, one round trip.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "common.hpp"
 
 namespace paro {
 
+// Kernel-argument bytes 0..127: EVERYTHING a wave needs before its first global loads are out, fetched by one pair of
+// s_load_dwordx16 and one wait (the compiler's own argument fetch came out as three to four DEPENDENT scalar-load
+// round trips, ~600 cycles each at kernel start: 2000..2600 cycles from workgroup start to the first global load in
+// the per-wave timeline).  Sixteen-bit partition tables (host-checked) keep it inside 32 dwords.
+struct alignas(16) GemvHot {
+  const u32x4* wq;               // dwords 0..1
+  const unsigned* sz;            // 2..3
+  const unsigned* rot;           // 4..5
+  const unsigned short* cs;      // 6..7
+  const unsigned short* x;       // 8..9   [rows][K], or pre-rotated [nparts][rows][K] when PREROT
+  unsigned G;                    // 10     K / 128
+  unsigned meta;                 // 11     rows | krot << 8 | ksplit << 16 | skew << 24 | prio << 25 | prologue << 26 | experts << 28
+  unsigned gps_tsz;              // 12     groups per K-split | scale/zero tiles per group row << 16
+  int tstride, gstride;          // 13, 14 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
+  unsigned xstride;              // 15     elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
+  unsigned short cbs[8];         // 16..19 first column block of partition q = 1..7 at [q - 1]; 0xffff beyond the last
+  unsigned short tst[8];         // 20..23 first tile of partition q = 1..8 at [q - 1] (== all tiles beyond the last)
+  unsigned short szt[8];         // 24..27 first scale/zero tile of partition q = 1..7 at [q - 1]
+  const unsigned short* residual;  // 28..29 [rows][N] added to the output, or null (FUSED)
+  int N;                         // 30
+  float eps;                     // 31     RMSNorm epsilon (FUSED)
+};
+static_assert(sizeof(GemvHot) == 128, "the hot argument block is two s_load_dwordx16");
+
 struct GemvArgs {
-  const u32x4* wq;
-  const unsigned* sz;
-  const unsigned* rot;
-  const unsigned short* cs;
+  GemvHot hot;                   // must stay first: the kernel reads it at kernarg offset 0
+  // ---- cold: first used once the first global loads are in flight
   const unsigned short* bias;
-  const unsigned short* x;  // [rows][K], or pre-rotated [nparts][rows][K] when PREROT
   unsigned short* y;
-  unsigned long long* slabs;  // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]
+  unsigned long long* slabs;     // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]
   unsigned* counters;
-  int K, N, G, rows, krot, ksplit, gps;  // gps = groups per K-split
-  int tstride, gstride;                  // 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
-  int pd;                                // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41)
-  int skew;                              // 1: uneven unit split inside the workgroup (see the driver loop)
-  int prio;                              // 1: coefficient requests of ALL waves go out before any tile request (s_setprio)
-  // ---- prologue / epilogue fusions (FUSED instantiations only; paro_w4a16_gemv_fused)
-  int prologue;                          // PARO_PROLOGUE_NONE / _RMSNORM / _SILU_MUL
-  float eps;                             // RMSNorm epsilon
-  long long xstride;                     // elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
-  const unsigned short* residual;        // [rows][N] added to the output, or null
-  // ---- expert slots (FUSED instantiations only; paro_w4a16_gemv_experts): blockIdx.z = slot, the slot's expert id
+  // expert slots (FUSED instantiations only; paro_w4a16_gemv_experts): blockIdx.z = slot, the slot's expert id
   // is read from DEVICE memory; all experts share the rotation (cli/convert.py:280-379, mlx/modules.py:159-212)
-  const int* expert_idx;                 // [slots] or null
+  const int* expert_idx;         // [slots] or null
   long long wq_estride, sz_estride;      // bytes between experts in wq / sz
   long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
   int x_div;
-  PartTable pt;
+  // ---- host side only (instantiation choice; the kernel never reads these)
+  int rows, ksplit, prologue;
+  int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
+static_assert(offsetof(GemvArgs, hot) == 0, "hot block at kernarg offset 0");
+
+// host: pack the hot block; false when a table entry does not fit 16 bits
+inline bool pack_hot(GemvHot& h, const PartTable& pt, int rows, int krot, int ksplit, int gps, int skew, int prio, int prologue,
+                     bool experts, long long xstride) {
+  if (pt.tiles >= 0xffff || pt.tsz >= 0xffff || gps > 0xffff || xstride < 0 || xstride > 0xffffffffll) return false;
+  h.meta = (unsigned)rows | ((unsigned)krot << 8) | ((unsigned)ksplit << 16) | ((unsigned)(skew != 0) << 24) |
+           ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28);
+  h.gps_tsz = (unsigned)gps | ((unsigned)pt.tsz << 16);
+  h.xstride = (unsigned)xstride;
+  for (int q = 1; q <= 8; ++q) {
+    h.cbs[q - 1] = (unsigned short)((q < pt.nparts) ? pt.cb_start[q] : 0xffff);
+    h.tst[q - 1] = (unsigned short)pt.tile_start[q];
+    h.szt[q - 1] = (unsigned short)pt.szt_start[q];
+  }
+  return true;
+}
+
+// a pointer into GLOBAL memory (address space 1)
+template <typename T>
+using GP = const __attribute__((address_space(1))) T*;
 
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
@@ -110,24 +145,76 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x, ks = blockIdx.y;
-  // Pin every argument the first loads need into SGPRs right here: the compiler then fetches the argument
-  // block with ONE batch of scalar loads and one wait instead of sinking them into three dependent
-  // rounds (each a scalar-cache miss at kernel start).
-  asm volatile("" ::"s"(a.wq), "s"(a.sz), "s"(a.rot), "s"(a.cs), "s"(a.x), "s"(a.K), "s"(a.G), "s"(a.rows),
-               "s"(a.gps), "s"(a.tstride), "s"(a.gstride), "s"(a.pt.tsz), "s"(a.pt.nparts), "s"(a.skew), "s"(a.prio),
-               "s"(a.krot), "s"(a.ksplit), "s"(a.pt.cb_start[1]), "s"(a.pt.cb_start[2]), "s"(a.pt.cb_start[7]));
-  const u32x4* wq_p = a.wq;
-  const unsigned* sz_p = a.sz;
-  const unsigned short* x_p = a.x;
-  unsigned short* y_p = a.y;
+  // The hot argument block (kernarg bytes 0..127) with two back-to-back scalar loads and ONE wait, by hand: left to
+  // the compiler the argument fetch was three to four dependent scalar-load round trips before the first global load.
+  typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+  u32x16 k0, k1;
+  {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(k0), "=&s"(k1)
+                 : "s"(kp)
+                 : "memory");
+  }
+  // pointers rebuilt from argument dwords carry no address space: name it (global), or every access through them
+  // becomes a flat load that also counts against lgkmcnt
+  struct Hot {
+    GP<u32x4> wq;
+    GP<unsigned> sz;
+    GP<unsigned> rot;
+    GP<unsigned short> cs;
+    GP<unsigned short> x;
+    GP<unsigned short> residual;
+    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
+    long long xstride;
+    float eps;
+  } h;
+  {
+    auto ptr = [](unsigned lo, unsigned hi) { return ((unsigned long long)hi << 32) | (unsigned long long)lo; };
+    h.wq = (GP<u32x4>)ptr(k0[0], k0[1]);
+    h.sz = (GP<unsigned>)ptr(k0[2], k0[3]);
+    h.rot = (GP<unsigned>)ptr(k0[4], k0[5]);
+    h.cs = (GP<unsigned short>)ptr(k0[6], k0[7]);
+    h.x = (GP<unsigned short>)ptr(k0[8], k0[9]);
+    h.G = (int)k0[10];
+    h.K = h.G * 128;
+    const unsigned meta = k0[11];
+    h.rows = (int)(meta & 0xffu);
+    h.krot = (int)((meta >> 8) & 0xffu);
+    h.ksplit = (int)((meta >> 16) & 0xffu);
+    h.skew = (int)((meta >> 24) & 1u);
+    h.prio = (int)((meta >> 25) & 1u);
+    h.prologue = (int)((meta >> 26) & 3u);
+    h.experts = (int)((meta >> 28) & 1u);
+    h.gps = (int)(k0[12] & 0xffffu);
+    h.tsz = (int)(k0[12] >> 16);
+    h.tstride = (int)k0[13];
+    h.gstride = (int)k0[14];
+    h.xstride = (long long)k0[15];
+    h.residual = (GP<unsigned short>)ptr(k1[12], k1[13]);
+    h.N = (int)k1[14];
+    // the element is taken as an INTEGER and pinned before the cast: a float bit_cast of an element of an
+    // asm-defined SGPR vector is folded to element 0 by this compiler (hipcc 7.2, reproduced stand-alone)
+    unsigned eps_bits = k1[15];
+    asm volatile("" : "+s"(eps_bits));
+    h.eps = __builtin_bit_cast(float, eps_bits);
+  }
+  // 16-bit table entry i of the four dwords starting at k1[base]
+  auto half = [&](int base, int i) -> int {
+    const unsigned w = k1[base + (i >> 1)];
+    return (int)((i & 1) ? (w >> 16) : (w & 0xffffu));
+  };
+  GP<u32x4> wq_p = h.wq;
+  GP<unsigned> sz_p = h.sz;
+  GP<unsigned short> x_p = h.x;
+  int slot = 0;
   if constexpr (FUSED != 0) {
-    if (a.expert_idx) {
-      const int z = blockIdx.z;
-      const long long ex = a.expert_idx[z];
-      wq_p = (const u32x4*)((const unsigned char*)a.wq + ex * a.wq_estride);
-      sz_p = (const unsigned*)((const unsigned char*)a.sz + ex * a.sz_estride);
-      x_p = a.x + (long long)(z / a.x_div) * a.x_sstride;
-      y_p = a.y + (long long)z * a.y_sstride;
+    if (h.experts) {
+      slot = blockIdx.z;
+      const long long ex = a.expert_idx[slot];
+      wq_p = (GP<u32x4>)((GP<unsigned char>)h.wq + ex * a.wq_estride);
+      sz_p = (GP<unsigned>)((GP<unsigned char>)h.sz + ex * a.sz_estride);
+      x_p = h.x + (long long)(slot / a.x_div) * a.x_sstride;
     }
   }
   // DIAG 3: phase stamps (s_memtime, shader clock) into a.slabs
@@ -149,15 +236,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // the tile bookkeeping below (the scalar prologues of the waves that share a SIMD run one after the other: every
   // scalar instruction in front of the first request delays the later waves' requests several times over).
   int p = 0;
-#ifndef PARO_NP_LIMIT
-#define PARO_NP_LIMIT PARO_MAX_PARTS
-#endif
 #pragma unroll
-  for (int q = 1; q < PARO_NP_LIMIT; ++q) p = (q < a.pt.nparts && cb >= a.pt.cb_start[q]) ? q : p;
-  const int g_begin = ks * a.gps;
-  const int g_end = min(a.G, g_begin + a.gps);
+  for (int q = 1; q < PARO_MAX_PARTS; ++q) p = (cb >= half(0, q - 1)) ? q : p;   // entries beyond the last partition hold 0xffff
+  const int g_begin = ks * h.gps;
+  const int g_end = min(h.G, g_begin + h.gps);
   const int n_local = g_end - g_begin;
-  const int gf_first = wave < n_local ? g_begin + wave : a.G - 1;   // == unit_group(0), or the clamped dummy unit
+  const int gf_first = wave < n_local ? g_begin + wave : h.G - 1;   // == unit_group(0), or the clamped dummy unit
 
   unsigned short* xh = (unsigned short*)(lds + wave * XH_BYTES);
   if constexpr (!PREROT) {
@@ -170,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // A-fragment source row of this lane: MFMA row m' = lane & 15 carries batch row (m'>>2)*MR + (m'&3)
   const int mrow = lane & 15;
   const int brow = (mrow >> 2) * MR + (mrow & 3);
-  const bool avalid = ((mrow & 3) < MR) && (brow < a.rows);
+  const bool avalid = ((mrow & 3) < MR) && (brow < h.rows);
 
   float acc[TPW][MRT];   // [tile][row tile * MR + r]
 #pragma unroll
@@ -190,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     unsigned szw[TPW];
   };
 
-  const unsigned short* xrot_p = x_p + (PREROT ? (int64_t)p * a.rows * a.K : 0);
+  GP<unsigned short> xrot_p = x_p + (PREROT ? (int64_t)p * h.rows * h.K : 0);
 
   auto load_p = [&](PBuf& b, int g) {
     if constexpr (PREROT) {
@@ -200,50 +284,50 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         for (int i = 0; i < 4; ++i) {
           const int row = rt * 16 + brow;
           b.xa[rt * 4 + i] = (u32x4){0u, 0u, 0u, 0u};
-          if (((mrow & 3) < MR) && row < a.rows)
-            b.xa[rt * 4 + i] = *(const u32x4*)(xrot_p + (int64_t)row * a.K + g * 128 + 32 * i + 8 * mq);
+          if (((mrow & 3) < MR) && row < h.rows)
+            b.xa[rt * 4 + i] = *(GP<u32x4>)(xrot_p + (int64_t)row * h.K + g * 128 + 32 * i + 8 * mq);
         }
     } else {
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
-      const u32x4* rp = (const u32x4*)a.rot + ((int64_t)p * a.G + g) * 192 + lane;
+      GP<u32x4> rp = (GP<u32x4>)h.rot + ((int64_t)p * h.G + g) * 192 + lane;
 #pragma unroll
       for (int q = 0; q < 3; ++q) b.rc[q] = rp[q * 64];
-      b.csv = *(const unsigned*)(a.cs + (int64_t)p * a.K + g * 128 + 2 * lane);
+      b.csv = *(GP<unsigned>)(h.cs + (int64_t)p * h.K + g * 128 + 2 * lane);
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
-        const int rr = r < a.rows ? r : 0;  // clamp instead of branching: keeps the load count static
+        const int rr = r < h.rows ? r : 0;  // clamp instead of branching: keeps the load count static
         if constexpr (FUSED) {
-          const unsigned short* xr = x_p + (int64_t)rr * a.xstride + g * 128 + 2 * lane;
-          b.xv[r] = *(const unsigned*)xr;
-          if constexpr (FUSED == 2) b.xu[r] = *(const unsigned*)(xr + a.K);
+          GP<unsigned short> xr = x_p + (int64_t)rr * h.xstride + g * 128 + 2 * lane;
+          b.xv[r] = *(GP<unsigned>)xr;
+          if constexpr (FUSED == 2) b.xu[r] = *(GP<unsigned>)(xr + h.K);
         } else {
-          b.xv[r] = *(const unsigned*)(x_p + (int64_t)rr * a.K + g * 128 + 2 * lane);
+          b.xv[r] = *(GP<unsigned>)(x_p + (int64_t)rr * h.K + g * 128 + 2 * lane);
         }
       }
     }
   };
   // ---- first unit's coefficient requests, at priority 3 (see the note at the driver loop), then the bookkeeping
   PBuf pc_first;
-  if (a.prio) __builtin_amdgcn_s_setprio(3);
+  if (h.prio) __builtin_amdgcn_s_setprio(3);
   load_p(pc_first, gf_first);
   __builtin_amdgcn_sched_barrier(0);
-  if (a.prio) __builtin_amdgcn_s_setprio(0);
+  if (h.prio) __builtin_amdgcn_s_setprio(0);
 
   // ---- tile bookkeeping of this column block (after the coefficient requests are out)
-  int p_cb0 = a.pt.cb_start[0], p_t0 = a.pt.tile_start[0], p_t1 = a.pt.tile_start[1], p_sz0 = a.pt.szt_start[0];
+  int p_cb0 = 0, p_t0 = 0, p_t1 = half(4, 0), p_sz0 = 0;
 #pragma unroll
-  for (int q = 1; q < PARO_NP_LIMIT; ++q) {
-    const bool in = q < a.pt.nparts && cb >= a.pt.cb_start[q];
-    p_cb0 = in ? a.pt.cb_start[q] : p_cb0;
-    p_t0 = in ? a.pt.tile_start[q] : p_t0;
-    p_t1 = in ? a.pt.tile_start[q + 1] : p_t1;
-    p_sz0 = in ? a.pt.szt_start[q] : p_sz0;
+  for (int q = 1; q < PARO_MAX_PARTS; ++q) {
+    const bool in = cb >= half(0, q - 1);
+    p_cb0 = in ? half(0, q - 1) : p_cb0;
+    p_t0 = in ? half(4, q - 1) : p_t0;
+    p_t1 = in ? half(4, q) : p_t1;
+    p_sz0 = in ? half(8, q - 1) : p_sz0;
   }
   const int ltile0 = (cb - p_cb0) * TPW;
   const int tile0 = p_t0 + ltile0;
   const int nt = min(TPW, p_t1 - tile0);
   const int ts0 = p_sz0 + ltile0;
-  const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;  // words per group row of the scale/zero array
+  const int64_t szrow = (int64_t)(h.tsz >> 2) * 64;  // words per group row of the scale/zero array
 
   // Every load is unconditional (ragged column blocks re-read their last tile and mask it later; waves
   // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
@@ -252,13 +336,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int jj = j < nt ? j : nt - 1;
-      b.q[j] = __builtin_nontemporal_load(wq_p + ((int64_t)(tile0 + jj) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
+      b.q[j] = __builtin_nontemporal_load(wq_p + ((int64_t)(tile0 + jj) * h.tstride + (int64_t)g * h.gstride) * 64 + lane);
     }
     if constexpr (SZ_VEC) {
-      const unsigned* sp = sz_p + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
+      GP<unsigned> sp = sz_p + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
 #pragma unroll
       for (int v = 0; v < NSZ; ++v) {
-        const SZV q = *(const SZV*)(sp + v * 64);
+        const SZV q = *(GP<SZV>)(sp + v * 64);
 #pragma unroll
         for (int e = 0; e < SZW; ++e) b.szw[v * 4 + e] = q[e];
       }
@@ -281,10 +365,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // as a dependent load after the reduction (a global access at the tail is ~1 us of pure latency)
   float res_first = 0.f;
   if constexpr (FUSED) {
-    if (a.residual && tid < TPW * MRT * 64 && ks == a.ksplit - 1) {   // only the workgroup that writes y
+    if (h.residual && tid < TPW * MRT * 64 && ks == h.ksplit - 1) {   // only the workgroup that writes y
       const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
       const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
-      if (j < nt && b < a.rows) res_first = A::to_f32(a.residual[(int64_t)b * a.N + (tile0 + j) * 16 + (el & 15)]);
+      if (j < nt && b < h.rows) res_first = A::to_f32(h.residual[(int64_t)b * h.N + (tile0 + j) * 16 + (el & 15)]);
     }
   }
   float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
@@ -294,23 +378,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     const float c0 = f16_bits_to_f32(b.csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(b.csv >> 16) * 0x1p-63f;
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
-      const unsigned xv = r < a.rows ? b.xv[r] : 0u;
+      const unsigned xv = r < h.rows ? b.xv[r] : 0u;
       float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
       if constexpr (FUSED == 2) {
         {
-          const unsigned uv = r < a.rows ? b.xu[r] : 0u;
+          const unsigned uv = r < h.rows ? b.xu[r] : 0u;
           // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x
           x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x0));
           x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x1));
         }
       } else if constexpr (FUSED == 1) {
-        if (a.prologue == PARO_PROLOGUE_RMSNORM) ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
+        if (h.prologue == PARO_PROLOGUE_RMSNORM) ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
       }
       sa[r] = x0 * c0;
       sb[r] = x1 * c1;
     }
   };
-  const float final_scale = __builtin_ldexpf(1.0f, 49 - 14 * a.krot);
+  const float final_scale = __builtin_ldexpf(1.0f, 49 - 14 * h.krot);
   // Stage t: keep' = P A + Q B, give' = P B - Q A, then ONE cross-lane fetch: the lane keeps keep' and
   // pulls the give' of lane `src` (ds_bpermute_b32: no LDS memory, no bank conflicts).  Which member is
   // kept, the pair orientation and the running signs are folded into (P, Q) at load time (repack.hip).
@@ -450,7 +534,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
-            if (t < a.krot) stage(pc, t, sa, sb);
+            if (t < h.krot) stage(pc, t, sa, sb);
           }
         }
         if constexpr (DIAG == 4) touch(pc, sa);
@@ -474,12 +558,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // waves that share a SIMD do not start together, though: the per-wave timeline shows the second / third /
     // fourth wave of a SIMD receiving its first coefficients one step later each (3800 vs 9150 cycles with
     // 8 tiles per wave; 2250 / 3080 / 4080 / 5530 with 16 waves) and finishing that much later.  With
-    // a.skew the first wave of every SIMD therefore takes one unit more and the last one unit less (static,
+    // h.skew the first wave of every SIMD therefore takes one unit more and the last one unit less (static,
     // so results stay bit-reproducible): rounds 0 .. c-2 as before, round c-1 without the last rank, round c
     // for the first rank only.
     constexpr int RANKS = WAVES / 4;
     const int c_even = n_local / WAVES;
-    const bool skew = a.skew && RANKS >= 2 && n_local == c_even * WAVES && c_even >= (RANKS == 2 ? 3 : 2);
+    const bool skew = h.skew && RANKS >= 2 && n_local == c_even * WAVES && c_even >= (RANKS == 2 ? 3 : 2);
     const int rank = wave >> 2;
     int my_count;
     if (skew)
@@ -495,12 +579,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       return g_begin + li;
     };
     const bool has_work = my_count > 0;
-    const int gf = has_work ? unit_group(0) : a.G - 1;
+    const int gf = has_work ? unit_group(0) : h.G - 1;
     // (the first unit's coefficient requests went out at kernel entry: `pc_first`, group gf == gf_first)
     // Issue priority: the CU returns vector-memory data in request order.  Left alone, each SIMD issues
     // [wave 0: coefficients, tiles][wave 4: coefficients, tiles] ..., so the small L2-resident coefficient loads of
     // the later waves come back behind the earlier waves' HBM tile loads.  Every wave therefore ran at priority 3
-    // until its first coefficient requests were out and dropped to 0 before its tile requests (a.prio).
+    // until its first coefficient requests were out and dropped to 0 before its tile requests (h.prio).
     pc = pc_first;
     load_t(tc, gf);
     if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
@@ -529,7 +613,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int r = 0; r < MRT; ++r) red[((wave * TPW + j) * MRT + r) * 64 + lane] = acc[j][r];
   float* ssl = (float*)(lds + LDS_BYTES - SS_BYTES);   // [wave][row]
   if constexpr (FUSED == 1) {
-    if (a.prologue == PARO_PROLOGUE_RMSNORM) {
+    if (h.prologue == PARO_PROLOGUE_RMSNORM) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         float v = has_work_any ? ssq[r] : 0.f;
@@ -542,40 +626,44 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   __syncthreads();
   if constexpr (DIAG == 3) ts[8] = __builtin_amdgcn_s_memtime();   // partials staged
 
-  const bool direct = (a.ksplit == 1);
+  unsigned short* y_p = a.y;
+  if constexpr (FUSED != 0) {
+    if (h.experts) y_p = a.y + (long long)slot * a.y_sstride;
+  }
+  const bool direct = (h.ksplit == 1);
   for (int e = tid; e < TPW * MRT * 64; e += WAVES * 64) {
     const int el = e & 63, q = (e >> 6) % MRT, j = e / (MRT * 64);
     const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);   // row tile * 16 + row inside the tile
-    if (j >= nt || b >= a.rows) continue;
+    if (j >= nt || b >= h.rows) continue;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MRT * 64];
     const int col = (tile0 + j) * 16 + (el & 15);
     if (direct) {
       if constexpr (FUSED == 1) {
-        if (a.prologue == PARO_PROLOGUE_RMSNORM) {
+        if (h.prologue == PARO_PROLOGUE_RMSNORM) {
           float ss = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) ss += ssl[w * MB + b];
-          v *= __builtin_amdgcn_rsqf(ss / (float)a.K + a.eps);
+          v *= __builtin_amdgcn_rsqf(ss / (float)h.K + h.eps);
         }
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (h.residual) v += (e == tid) ? res_first : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
-      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
-    } else if (ks != a.ksplit - 1) {
+      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
+    } else if (ks != h.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
       const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
-      __hip_atomic_store(a.slabs + ((int64_t)ks * a.rows + b) * a.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * h.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
       // partial in registers, poll the other splits' granules until their tags appear (bounded),
       // re-arm them to zero for the next launch, write y once.
-      for (int s = 0; s < a.ksplit - 1; ++s) {
-        unsigned long long* gp = a.slabs + ((int64_t)s * a.rows + b) * a.N + col;
+      for (int s = 0; s < h.ksplit - 1; ++s) {
+        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
         unsigned long long gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
           __builtin_amdgcn_s_sleep(2);
@@ -596,9 +684,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (h.residual) v += (e == tid) ? res_first : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
-      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
     }
   }
   if constexpr (DIAG == 3) {
@@ -693,7 +781,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || a.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || a.hot.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 
