@@ -221,9 +221,9 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.hot.G = (unsigned)G;
   a.hot.tstride = L->wq_order ? 1 : G;
   a.hot.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  a.hot.residual = fused ? (const unsigned short*)F->residual : nullptr;
-  a.hot.N = (int)L->N;
-  a.hot.eps = fused ? F->eps : 0.f;
+  a.residual = fused ? (const unsigned short*)F->residual : nullptr;
+  a.N = (int)L->N;
+  a.eps = fused ? F->eps : 0.f;
   a.bias = (const unsigned short*)L->bias;
   a.y = (unsigned short*)y;
   a.rows = (int)rows;

@@ -38,8 +38,10 @@ namespace paro {
 
 // Kernel-argument bytes 0..127: EVERYTHING a wave needs before its first global loads are out, fetched by one pair of
 // s_load_dwordx16 and one wait (the compiler's own argument fetch came out as three to four DEPENDENT scalar-load
-// round trips, ~600 cycles each at kernel start: 2000..2600 cycles from workgroup start to the first global load in
-// the per-wave timeline).  Sixteen-bit partition tables (host-checked) keep it inside 32 dwords.
+// round trips at kernel start).  The second half is the partition table in a form the lookup can index with
+// s_movrels: the scalar prologue is executed by EVERY wave and all waves of a CU share one scalar unit -- with 16
+// waves per CU, each scalar instruction in front of the first loads costs the workgroup ~16 cycles (the select
+// chains the compiler made of the lookup were ~90 of the ~220 scalar instructions there).
 struct alignas(16) GemvHot {
   const u32x4* wq;               // dwords 0..1
   const unsigned* sz;            // 2..3
@@ -51,18 +53,17 @@ struct alignas(16) GemvHot {
   unsigned gps_tsz;              // 12     groups per K-split | scale/zero tiles per group row << 16
   int tstride, gstride;          // 13, 14 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
   unsigned xstride;              // 15     elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
-  unsigned short cbs[8];         // 16..19 first column block of partition q = 1..7 at [q - 1]; 0xffff beyond the last
-  unsigned short tst[8];         // 20..23 first tile of partition q = 1..8 at [q - 1] (== all tiles beyond the last)
-  unsigned short szt[8];         // 24..27 first scale/zero tile of partition q = 1..7 at [q - 1]
-  const unsigned short* residual;  // 28..29 [rows][N] added to the output, or null (FUSED)
-  int N;                         // 30
-  float eps;                     // 31     RMSNorm epsilon (FUSED)
+  int cbs[7];                    // 16..22 first column block of partition q = 1..7 at [q - 1]; INT_MAX beyond the last
+  unsigned ent[9];               // 23..31 partition q = 0..8: first tile | first scale/zero tile << 16 (q = nparts: the totals)
 };
 static_assert(sizeof(GemvHot) == 128, "the hot argument block is two s_load_dwordx16");
 
 struct GemvArgs {
   GemvHot hot;                   // must stay first: the kernel reads it at kernarg offset 0
   // ---- cold: first used once the first global loads are in flight
+  const unsigned short* residual;  // [rows][N] added to the output, or null (FUSED)
+  int N;
+  float eps;                     // RMSNorm epsilon (FUSED)
   const unsigned short* bias;
   unsigned short* y;
   unsigned long long* slabs;     // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]
@@ -87,11 +88,8 @@ inline bool pack_hot(GemvHot& h, const PartTable& pt, int rows, int krot, int ks
            ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28);
   h.gps_tsz = (unsigned)gps | ((unsigned)pt.tsz << 16);
   h.xstride = (unsigned)xstride;
-  for (int q = 1; q <= 8; ++q) {
-    h.cbs[q - 1] = (unsigned short)((q < pt.nparts) ? pt.cb_start[q] : 0xffff);
-    h.tst[q - 1] = (unsigned short)pt.tile_start[q];
-    h.szt[q - 1] = (unsigned short)pt.szt_start[q];
-  }
+  for (int q = 1; q < PARO_MAX_PARTS; ++q) h.cbs[q - 1] = (q < pt.nparts) ? pt.cb_start[q] : 0x7fffffff;
+  for (int q = 0; q <= PARO_MAX_PARTS; ++q) h.ent[q] = (unsigned)pt.tile_start[q] | ((unsigned)pt.szt_start[q] << 16);
   return true;
 }
 
@@ -145,16 +143,43 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x, ks = blockIdx.y;
-  // The hot argument block (kernarg bytes 0..127) with two back-to-back scalar loads and ONE wait, by hand: left to
-  // the compiler the argument fetch was three to four dependent scalar-load round trips before the first global load.
+  // The hot argument block (kernarg bytes 0..127) with two back-to-back scalar loads and ONE wait, and the partition
+  // lookup of this column block, in one hand-written sequence:  p = #{q in 1..7 : cb >= cbs[q]} (seven compare +
+  // add-with-carry pairs), then three indexed scalar reads (s_movrels) of cbs[p], ent[p], ent[p + 1].  The table half
+  // of the block lands in fixed registers s[84:99] so that the indexed reads can name them.
   typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-  u32x16 k0, k1;
+  u32x16 k0;
+  int p;
+  unsigned p_cb0_u, ent0, ent1;
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(k0), "=&s"(k1)
-                 : "s"(kp)
-                 : "memory");
+    unsigned m0_save;
+    asm volatile(
+        "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
+        "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
+        "s_mov_b32 %[m0s], m0\n\t"
+        "s_mov_b32 %[p], 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_cmp_ge_i32 %[cb], s84\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s85\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s86\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s87\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s88\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s89\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_cmp_ge_i32 %[cb], s90\n\ts_addc_u32 %[p], %[p], 0\n\t"
+        "s_mov_b32 m0, %[p]\n\t"
+        "s_nop 0\n\t"                       // hazard: a scalar write of m0 needs one wait state before s_movrel (no compiler in here to insert it)
+        "s_movrels_b32 %[cb0], s83\n\t"     // cbs[p - 1] = first column block of partition p (p = 0: junk, fixed below)
+        "s_movrels_b32 %[e0], s91\n\t"      // ent[p]
+        "s_movrels_b32 %[e1], s92\n\t"      // ent[p + 1]
+        "s_cmp_eq_u32 %[p], 0\n\t"
+        "s_cselect_b32 %[cb0], 0, %[cb0]\n\t"
+        "s_mov_b32 m0, %[m0s]\n\t"
+        "s_nop 0"
+        : [k0] "=&s"(k0), [p] "=&s"(p), [cb0] "=&s"(p_cb0_u), [e0] "=&s"(ent0), [e1] "=&s"(ent1), [m0s] "=&s"(m0_save)
+        : [kp] "s"(kp), [cb] "s"(cb)
+        : "memory", "scc", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+          "s98", "s99");
   }
   // pointers rebuilt from argument dwords carry no address space: name it (global), or every access through them
   // becomes a flat load that also counts against lgkmcnt
@@ -164,10 +189,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     GP<unsigned> rot;
     GP<unsigned short> cs;
     GP<unsigned short> x;
-    GP<unsigned short> residual;
-    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
+    int K, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
     long long xstride;
-    float eps;
   } h;
   {
     auto ptr = [](unsigned lo, unsigned hi) { return ((unsigned long long)hi << 32) | (unsigned long long)lo; };
@@ -191,19 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.tstride = (int)k0[13];
     h.gstride = (int)k0[14];
     h.xstride = (long long)k0[15];
-    h.residual = (GP<unsigned short>)ptr(k1[12], k1[13]);
-    h.N = (int)k1[14];
-    // the element is taken as an INTEGER and pinned before the cast: a float bit_cast of an element of an
-    // asm-defined SGPR vector is folded to element 0 by this compiler (hipcc 7.2, reproduced stand-alone)
-    unsigned eps_bits = k1[15];
-    asm volatile("" : "+s"(eps_bits));
-    h.eps = __builtin_bit_cast(float, eps_bits);
   }
-  // 16-bit table entry i of the four dwords starting at k1[base]
-  auto half = [&](int base, int i) -> int {
-    const unsigned w = k1[base + (i >> 1)];
-    return (int)((i & 1) ? (w >> 16) : (w & 0xffffu));
-  };
   GP<u32x4> wq_p = h.wq;
   GP<unsigned> sz_p = h.sz;
   GP<unsigned short> x_p = h.x;
@@ -219,7 +230,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   }
   // DIAG 3: phase stamps (s_memtime, shader clock) into a.slabs
   unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if constexpr (DIAG == 3) ts[0] = __builtin_amdgcn_s_memtime();
+  unsigned long long rt0 = 0;   // DIAG 3: chip-wide real-time counter (100 MHz) at workgroup entry
+  if constexpr (DIAG == 3) { ts[0] = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   // a stamp that cannot be scheduled before `dep` exists (s_memtime alone has no data dependencies and
   // floats above the s_waitcnt it is meant to follow)
   auto stamp_after = [](float dep) -> unsigned long long {
@@ -235,9 +247,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // only the partition index and the wave's first group, so those are computed -- and the requests issued -- before
   // the tile bookkeeping below (the scalar prologues of the waves that share a SIMD run one after the other: every
   // scalar instruction in front of the first request delays the later waves' requests several times over).
-  int p = 0;
-#pragma unroll
-  for (int q = 1; q < PARO_MAX_PARTS; ++q) p = (cb >= half(0, q - 1)) ? q : p;   // entries beyond the last partition hold 0xffff
   const int g_begin = ks * h.gps;
   const int g_end = min(h.G, g_begin + h.gps);
   const int n_local = g_end - g_begin;
@@ -274,7 +283,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     unsigned szw[TPW];
   };
 
-  GP<unsigned short> xrot_p = x_p + (PREROT ? (int64_t)p * h.rows * h.K : 0);
+  // element / chunk offsets are 32-bit (host-checked ranges): 64-bit scalar index arithmetic is several instructions
+  // per term, in a prologue every wave of the CU executes on the one shared scalar unit
+  GP<unsigned short> xrot_p = x_p + (PREROT ? (unsigned)(p * h.rows * h.K) : 0u);
 
   auto load_p = [&](PBuf& b, int g) {
     if constexpr (PREROT) {
@@ -285,23 +296,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           const int row = rt * 16 + brow;
           b.xa[rt * 4 + i] = (u32x4){0u, 0u, 0u, 0u};
           if (((mrow & 3) < MR) && row < h.rows)
-            b.xa[rt * 4 + i] = *(GP<u32x4>)(xrot_p + (int64_t)row * h.K + g * 128 + 32 * i + 8 * mq);
+            b.xa[rt * 4 + i] = *(GP<u32x4>)(xrot_p + (unsigned)(row * h.K + g * 128 + 32 * i + 8 * mq));
         }
     } else {
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
-      GP<u32x4> rp = (GP<u32x4>)h.rot + ((int64_t)p * h.G + g) * 192 + lane;
+      GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
 #pragma unroll
       for (int q = 0; q < 3; ++q) b.rc[q] = rp[q * 64];
-      b.csv = *(GP<unsigned>)(h.cs + (int64_t)p * h.K + g * 128 + 2 * lane);
+      b.csv = *(GP<unsigned>)(h.cs + (unsigned)(p * h.K + g * 128 + 2 * lane));
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         const int rr = r < h.rows ? r : 0;  // clamp instead of branching: keeps the load count static
         if constexpr (FUSED) {
-          GP<unsigned short> xr = x_p + (int64_t)rr * h.xstride + g * 128 + 2 * lane;
+          GP<unsigned short> xr = x_p + ((unsigned)rr * (unsigned)h.xstride + (unsigned)(g * 128 + 2 * lane));
           b.xv[r] = *(GP<unsigned>)xr;
           if constexpr (FUSED == 2) b.xu[r] = *(GP<unsigned>)(xr + h.K);
         } else {
-          b.xv[r] = *(GP<unsigned>)(x_p + (int64_t)rr * h.K + g * 128 + 2 * lane);
+          b.xv[r] = *(GP<unsigned>)(x_p + (unsigned)(rr * h.K + g * 128 + 2 * lane));
         }
       }
     }
@@ -314,20 +325,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   if (h.prio) __builtin_amdgcn_s_setprio(0);
 
   // ---- tile bookkeeping of this column block (after the coefficient requests are out)
-  int p_cb0 = 0, p_t0 = 0, p_t1 = half(4, 0), p_sz0 = 0;
-#pragma unroll
-  for (int q = 1; q < PARO_MAX_PARTS; ++q) {
-    const bool in = cb >= half(0, q - 1);
-    p_cb0 = in ? half(0, q - 1) : p_cb0;
-    p_t0 = in ? half(4, q - 1) : p_t0;
-    p_t1 = in ? half(4, q) : p_t1;
-    p_sz0 = in ? half(8, q - 1) : p_sz0;
-  }
+  const int p_cb0 = (int)p_cb0_u, p_t0 = (int)(ent0 & 0xffffu), p_t1 = (int)(ent1 & 0xffffu), p_sz0 = (int)(ent0 >> 16);
   const int ltile0 = (cb - p_cb0) * TPW;
   const int tile0 = p_t0 + ltile0;
   const int nt = min(TPW, p_t1 - tile0);
   const int ts0 = p_sz0 + ltile0;
-  const int64_t szrow = (int64_t)(h.tsz >> 2) * 64;  // words per group row of the scale/zero array
+  const unsigned szrow = (unsigned)(h.tsz >> 2) * 64u;  // words per group row of the scale/zero array
 
   // Every load is unconditional (ragged column blocks re-read their last tile and mask it later; waves
   // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
@@ -336,10 +339,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int jj = j < nt ? j : nt - 1;
-      b.q[j] = __builtin_nontemporal_load(wq_p + ((int64_t)(tile0 + jj) * h.tstride + (int64_t)g * h.gstride) * 64 + lane);
+      b.q[j] = __builtin_nontemporal_load(wq_p + ((unsigned)((tile0 + jj) * h.tstride + g * h.gstride) * 64u + (unsigned)lane));
     }
     if constexpr (SZ_VEC) {
-      GP<unsigned> sp = sz_p + (int64_t)g * szrow + ((int64_t)(ts0 >> 2) * 16 + n) * 4 + (ts0 & 3);
+      GP<unsigned> sp = sz_p + ((unsigned)g * szrow + (unsigned)(((ts0 >> 2) * 16 + n) * 4 + (ts0 & 3)));
 #pragma unroll
       for (int v = 0; v < NSZ; ++v) {
         const SZV q = *(GP<SZV>)(sp + v * 64);
@@ -350,10 +353,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int ts = ts0 + (j < nt ? j : nt - 1);
-        b.szw[j] = sz_p[(int64_t)g * szrow + ((int64_t)(ts >> 2) * 16 + n) * 4 + (ts & 3)];
+        b.szw[j] = sz_p[(unsigned)g * szrow + (unsigned)(((ts >> 2) * 16 + n) * 4 + (ts & 3))];
       }
     }
   };
+
+  // the first unit's tiles are requested HERE, straight after the bookkeeping they need (the unit/skew logic of the
+  // driver loop below is not needed for them: unit 0 of a wave is always group gf_first)
+  TBuf tc_first;
+  load_t(tc_first, gf_first);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
 
   // ---- rotation pieces (state in REGISTERS: lane l holds both members (A, B) of one pair of the stage)
   // The packed coefficients are 16-bit integers in units of 2^-14.  They are used AS integers (two
@@ -365,10 +375,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // as a dependent load after the reduction (a global access at the tail is ~1 us of pure latency)
   float res_first = 0.f;
   if constexpr (FUSED) {
-    if (h.residual && tid < TPW * MRT * 64 && ks == h.ksplit - 1) {   // only the workgroup that writes y
+    if (a.residual && tid < TPW * MRT * 64 && ks == h.ksplit - 1) {   // only the workgroup that writes y
       const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
       const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
-      if (j < nt && b < h.rows) res_first = A::to_f32(h.residual[(int64_t)b * h.N + (tile0 + j) * 16 + (el & 15)]);
+      if (j < nt && b < h.rows) res_first = A::to_f32(a.residual[(int64_t)b * a.N + (tile0 + j) * 16 + (el & 15)]);
     }
   }
   float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
@@ -586,8 +596,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // the later waves come back behind the earlier waves' HBM tile loads.  Every wave therefore ran at priority 3
     // until its first coefficient requests were out and dropped to 0 before its tile requests (h.prio).
     pc = pc_first;
-    load_t(tc, gf);
-    if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
+    tc = tc_first;
     for (int i = 0; i + 1 < my_count; ++i) {
       const int gn = unit_group(i + 1);
       step(yes, yes, gn, gn);
@@ -645,25 +654,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           float ss = 0.f;
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) ss += ssl[w * MB + b];
-          v *= __builtin_amdgcn_rsqf(ss / (float)h.K + h.eps);
+          v *= __builtin_amdgcn_rsqf(ss / (float)h.K + a.eps);
         }
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (h.residual) v += (e == tid) ? res_first : A::to_f32(h.residual[(int64_t)b * h.N + col]);
+        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
-      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
     } else if (ks != h.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
       const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
-      __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * h.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * a.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
       // partial in registers, poll the other splits' granules until their tags appear (bounded),
       // re-arm them to zero for the next launch, write y once.
       for (int s = 0; s < h.ksplit - 1; ++s) {
-        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
+        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * a.N + col;
         unsigned long long gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
           __builtin_amdgcn_s_sleep(2);
@@ -684,9 +693,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (h.residual) v += (e == tid) ? res_first : A::to_f32(h.residual[(int64_t)b * h.N + col]);
+        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
       }
-      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
     }
   }
   if constexpr (DIAG == 3) {
@@ -699,6 +708,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) dbg[k] = ts[k];
         dbg[10] = ts[9];
+        dbg[11] = rt0;                                  // chip-wide clock at entry / exit: dispatch ramp and tail
+        dbg[12] = __builtin_amdgcn_s_memrealtime();
         dbg[9] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
                  ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
       }
@@ -781,7 +792,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || a.hot.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || a.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

@@ -45,6 +45,11 @@ print(f"{a.model} {name} tpw={a.tpw} waves={a.waves} workgroups={ncb}  kernel {e
 for k in order:
     col = d[:, k]
     print(f"  {names[k]:16s} mean {col.mean():8.0f}  p5 {np.percentile(col,5):8.0f}  p95 {np.percentile(col,95):8.0f}  max {col.max():8.0f}")
+# chip-wide real-time counter (100 MHz): when each workgroup entered / left, relative to the first entry
+rt = raw[:, 11:13].astype(np.float64) * 10.0   # ns
+rt -= rt[:, 0].min()
+print(f"  chip-wide clock, ns since the first workgroup's entry:  entry mean {rt[:,0].mean():6.0f} p95 {np.percentile(rt[:,0],95):6.0f} max {rt[:,0].max():6.0f}"
+      f"   exit min {rt[:,1].min():6.0f} mean {rt[:,1].mean():6.0f} p95 {np.percentile(rt[:,1],95):6.0f} max {rt[:,1].max():6.0f}")
 wv = raw[:, 16:16 + 4 * a.waves].astype(np.float64).reshape(ncb, a.waves, 4) - t[:, :1, None]
 print("  by wave index, mean cycles since workgroup start:  start / first coefficients arrived / first unit done / all units done")
 for w in range(a.waves):
