@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 6
+#define PARO_ABI_VERSION 7
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -83,22 +83,25 @@ int paro_rotate(const void* x, void* out, const int16_t* idx_ij, const void* the
  *
  * Inputs (checkpoint format, cli/convert.py:149-155,194-203,264-277):
  *   qweight int32 [K, N/8]      nibble p of word c = column 8c + (0,2,4,6,1,3,5,7)[p]
- *   qzeros  int32 [K/128, N/8]  same packing
- *   scales  fp16  [K/128, N]
+ *   qzeros  int32 [K/gs, N/8]   same packing; gs = group_size of the QUANTISATION, 128 or 64 (the rotation always
+ *                               works on 128-channel groups at inference: RotateQuantizedLinear.forward calls
+ *                               rotate() without a group size, transformers/modules.py:59, and forwards group_size
+ *                               only to the AWQ matmul, :60-69)
+ *   scales  fp16  [K/gs, N]
  *   part_cols[n_parts]          columns of each merged partition (multiples of 16, sum = N)
  * Outputs:
  *   out_wq  uint32 [N/16][K/128][64][4] (wq_order 0) or [K/128][N/16][64][4] (wq_order 1); tile (t,g) = 1 KiB; lane l = (kb = l>>4, n = l&15), word i holds
  *           k = 128g + 32i + 8kb + e (e = 0..7) of column 16t+n; element e sits in nibble (e>>1) + 4*(e&1)
  *           -- the v_mfma_f32_16x16x32 B-fragment order, the two k-adjacent nibbles 16 bits apart.
- *   out_sz  uint32 [K/128][Tsz/4][16][4]  one word per (group, column): lo16 = scale (fp16 bits),
+ *   out_sz  uint32 [K/gs][Tsz/4][16][4]  one word per (quantisation group, column): lo16 = scale (fp16 bits),
  *           hi16 = fp16(zero_point).  Column tiles are indexed in a padded tile space: partition p
  *           starts at the sum of its predecessors' tile counts rounded up to 8 (Tsz = that sum over all
  *           partitions); word ((g*Tsz/4 + ts/4)*16 + n)*4 + ts%4 belongs to padded tile ts, column n.
  *           Padding words are zero.
  */
 int64_t paro_packed_qweight_bytes(int64_t K, int64_t N);
-int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols);
-int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
+int64_t paro_packed_sz_bytes(int64_t K, int group_size, int n_parts, const int32_t* part_cols);
+int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N, int group_size,
                     int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz, void* stream);
 
 /* Rotation parameters -> the register EXCHANGE SCHEDULE of every (partition, group), 3072 bytes each:
@@ -152,6 +155,8 @@ typedef struct paro_linear {
   const void* rmat;                   /* optional: dense per-group rotation matrices, act_dtype
                                          [n_parts][K/128][128 n][128 k] = (diag(cs) G_1..G_krot)^T, used by
                                          the prefill pre-pass on the matrix cores; NULL = stage kernel */
+  int32_t group_size;                 /* quantisation group: 128 (0 is read as 128) or 64 channels per (scale, zero) */
+  int32_t reserved0;
 } paro_linear_t;
 
 /* Bytes of caller-provided scratch the fused ops may need for `rows` rows

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 6
+PARO_ABI_VERSION = 7
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
@@ -71,6 +71,8 @@ class ParoLinearDesc(Structure):
         ("channel_scales", c_void_p),
         ("bias", c_void_p),
         ("rmat", c_void_p),
+        ("group_size", c_int32),
+        ("reserved0", c_int32),
     ]
 
 
@@ -118,11 +120,11 @@ def load() -> ctypes.CDLL:
     lib.paro_packed_qweight_bytes.restype = c_int64
     lib.paro_packed_qweight_bytes.argtypes = [c_int64, c_int64]
     lib.paro_packed_sz_bytes.restype = c_int64
-    lib.paro_packed_sz_bytes.argtypes = [c_int64, c_int, POINTER(c_int32)]
+    lib.paro_packed_sz_bytes.argtypes = [c_int64, c_int, c_int, POINTER(c_int32)]
     lib.paro_packed_rot_bytes.restype = c_int64
     lib.paro_packed_rot_bytes.argtypes = [c_int64, c_int]
     lib.paro_repack_awq.restype = c_int
-    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_int32), c_int,
+    lib.paro_repack_awq.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, POINTER(c_int32), c_int,
                                     c_void_p, c_void_p, c_void_p]
     lib.paro_pack_rotation.restype = c_int
     lib.paro_pack_rotation.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]

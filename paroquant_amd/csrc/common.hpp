@@ -49,6 +49,9 @@ struct PartTable {
   }
 };
 
+// quantisation group of a layer: 128 (also for 0 = unset) or 64; -1 = unsupported
+inline int quant_group(int group_size) { return (group_size == 0 || group_size == 128) ? 128 : (group_size == 64 ? 64 : -1); }
+
 inline bool fill_part_table(PartTable& pt, int nparts, const int32_t* part_cols, int tiles_per_cb) {
   if (nparts < 1 || nparts > PARO_MAX_PARTS || !part_cols || tiles_per_cb < 1) return false;
   pt.nparts = nparts;

@@ -29,7 +29,7 @@ int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows,
 constexpr int BM = 128;
 constexpr int BN_TILES = 8;  // 128 columns per workgroup
 
-template <typename AT>
+template <typename AT, int QS = 1>   // QS: quantisation groups per 128-channel span (2 = group_size 64)
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 
   u32x4 stg[8];
   u32x4 qv[4];
-  u32x4 szv;
+  u32x4 szv[QS];
+  constexpr int SPH = 4 / QS;   // MFMA k-steps per quantisation group
 
   auto issue_loads = [&](int g) {
 #pragma unroll
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < nt) qv[j] = *(a.wq + ((int64_t)(tile0 + j) * a.tstride + (int64_t)g * a.gstride) * 64 + lane);
-    if (nt > 0) szv = *(const u32x4*)(szp + (int64_t)g * szrow);
+    if (nt > 0) {
+#pragma unroll
+      for (int hq = 0; hq < QS; ++hq) szv[hq] = *(const u32x4*)(szp + (int64_t)(g * QS + hq) * szrow);
+    }
   };
 
   issue_loads(0);
@@ -90,7 +94,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     u32x4 qc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) qc[j] = qv[j];
-    const u32x4 szc = szv;
+    u32x4 szc[QS];
+#pragma unroll
+    for (int hq = 0; hq < QS; ++hq) szc[hq] = szv[hq];
     __syncthreads();
     if (g + 1 < a.G) issue_loads(g + 1);  // next group's A rows + INT4 tiles fly under this group's MFMAs
 
@@ -101,23 +107,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[rt][i] = *(const vec8*)(lds + row * 256 + (((4 * i + mq) ^ (row & 15)) << 4));
     }
-    f32x4 sx[4];
+    f32x4 sx[4][QS];
     {
       const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
       const vec8 ob = __builtin_bit_cast(vec8, ones);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        sx[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sx[rt] = A::mfma(af[rt][i], ob, sx[rt]);
+        for (int hq = 0; hq < QS; ++hq) sx[rt][hq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sx[rt][i / SPH] = A::mfma(af[rt][i], ob, sx[rt][i / SPH]);
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < nt) {
-        f32x4 d[4];
+        f32x4 d[4][QS];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) d[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int hq = 0; hq < QS; ++hq) d[rt][hq] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           unsigned w4[4];
@@ -125,15 +134,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
           const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
           const vec8 bf = __builtin_bit_cast(vec8, wv);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) d[rt] = A::mfma(af[rt][i], bf, d[rt]);
+          for (int rt = 0; rt < 4; ++rt) d[rt][i / SPH] = A::mfma(af[rt][i], bf, d[rt][i / SPH]);
         }
-        const float s = f16_bits_to_f32(szc[j] & 0xffffu);
-        const float zf = f16_bits_to_f32(szc[j] >> 16) + 16.f;  // unpack() yields 16 + q
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int hq = 0; hq < QS; ++hq) {
+          const float s = f16_bits_to_f32(szc[hq][j] & 0xffffu);
+          const float zf = f16_bits_to_f32(szc[hq][j] >> 16) + 16.f;  // unpack() yields 16 + q
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[rt][j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][r], d[rt][r]), acc[rt][j][r]);
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[rt][j][r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][hq][r], d[rt][hq][r]), acc[rt][j][r]);
+        }
       }
     }
   }
@@ -400,7 +412,7 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
 }  // namespace paro
 
 namespace paro {
-int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag);   // gemm3.hip
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs);   // gemm3.hip
 }
 
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
@@ -424,10 +436,13 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   // and enough 256 x 256 tiles to cover the CUs; fp16 below that -> 256 x 128 tile with a K-split at small M;
   // bf16 below that -> the 128 x 128 kernel.
   const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
+  const int qs = 128 / quant_group(L->group_size);
+  if (qs == 2 && (variant == 2 || variant == 3))
+    return fail(PARO_ERR_UNSUPPORTED, "group_size 64 runs GEMM variant 1 or 4 (variants 2 and 3 are built for group_size 128)");
   int v = variant;
   if (v == PARO_GEMM_AUTO) {
     if (rows >= 256 && wide_wgs >= 192) v = 4;
-    else if (f16in && rows > 16) v = 2;
+    else if (f16in && rows > 16 && qs == 1) v = 2;
     else v = 1;
   }
   const int ksplit_req = v == 2 ? gemm_ksplit(L, rows) : 1;
@@ -470,7 +485,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)rb, (unsigned)a.ksplit);
   if (v == 4) {
-    rc = launch_gemm3(a, L->act_dtype, grid, st, diag);
+    rc = launch_gemm3(a, L->act_dtype, grid, st, diag, qs);
     if (rc != PARO_OK) return rc;
   } else if (v == 3) {
     hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);
@@ -481,6 +496,11 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
       hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a.partial,
                          (const unsigned short*)L->bias, (unsigned short*)y, rows, (int)L->N, a.ksplit);
     }
+  } else if (qs == 2) {
+    if (f16in)
+      hipLaunchKernelGGL((gemm_kernel<f16, 2>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((gemm_kernel<bf16, 2>), grid, dim3(256), 0, st, a);
   } else if (f16in) {
     hipLaunchKernelGGL(gemm_kernel<f16>, grid, dim3(256), 0, st, a);
   } else {

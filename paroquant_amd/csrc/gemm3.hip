@@ -144,7 +144,9 @@ constexpr int BM3 = 256;
 // DIAG (energy / issue ablation on the power-limited chip, tools/bench_gemm.py --variants 41,42,43; wrong results):
 // 1 = no dequant (raw INT4 words as the weight operand), 2 = no fragment re-reads inside a group (the first
 // k-step's fragments are reused), 3 = both.  0 = the shipping kernel.
-template <typename AT, int DIAG = 0>
+// QS: quantisation groups per 128-channel slab (1: group_size 128; 2: group_size 64 -- k-steps 0..3 and 4..7 of a
+// slab are dequantised with different (scale, zero) words).
+template <typename AT, int DIAG = 0, int QS = 1>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -200,12 +202,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   };
 
   u32x4 qn0, qn1;
-  unsigned szn;
+  unsigned szn[QS];
   auto load_b = [&](int g) {
     const u32x4* q = wq0 + (int64_t)g * wq_gstride;
     qn0 = q[0];
     qn1 = q[32];     // lane' (2 + kh, n): k-steps 1, 3, 5, 7
-    szn = szp[(int64_t)g * szrow];
+#pragma unroll
+    for (int hq = 0; hq < QS; ++hq) szn[hq] = szp[(int64_t)(g * QS + hq) * szrow];
   };
 
   f32x16 acc[8];
@@ -231,7 +234,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   auto group = [&](int g, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
     const u32x4 qc0 = qn0, qc1 = qn1;
-    d.set_group(szn);
+    unsigned szc[QS];
+#pragma unroll
+    for (int hq = 0; hq < QS; ++hq) szc[hq] = szn[hq];
+    d.set_group(szc[0]);
     auto word = [&](int s) -> unsigned { return (s & 1) ? qc1[(s >> 1) & 3] : qc0[(s >> 1) & 3]; };
     // the first k-step's weights are dequantised before the barrier (they need nothing from LDS)
     if constexpr (DIAG == 1 || DIAG == 3) {
@@ -260,6 +266,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
           if constexpr (DIAG == 1 || DIAG == 3) {
             if (rt == 0) d.out = (u32x4){word(s + 1), qc0[s & 3], qc1[s & 3], qc0[(s + 1) & 3]};
           } else {
+            // group_size 64: k-step 4 opens the slab's second quantisation group (its weights are dequantised
+            // during k-step 3, all eight parts of a word with the same scale / zero)
+            if constexpr (QS == 2) {
+              if (s == 3 && rt == 0) d.set_group(szc[1]);
+            }
             d.part(rt, word(s + 1));
           }
           if constexpr (DIAG != 2 && DIAG != 3)
@@ -302,7 +313,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   }
 }
 
-int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag) {
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs) {
+  if (qs == 2) {
+    if (diag != 0) return fail(PARO_ERR_UNSUPPORTED, "the ablation builds of GEMM variant 4 exist for group_size 128 only");
+    if (act_dtype == PARO_DTYPE_F16)
+      hipLaunchKernelGGL((gemm3_kernel<f16, 0, 2>), grid, dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((gemm3_kernel<bf16, 0, 2>), grid, dim3(512), 0, st, a);
+    return PARO_OK;
+  }
   if (diag == 1 && act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL((gemm3_kernel<f16, 1>), grid, dim3(512), 0, st, a);
   else if (diag == 2 && act_dtype == PARO_DTYPE_F16)

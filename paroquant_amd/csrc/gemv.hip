@@ -29,6 +29,8 @@ int validate_linear(const paro_linear_t* L) {
   if (!L->wq || !L->sz || !L->pairs || !L->theta || !L->channel_scales)
     return fail(PARO_ERR_INVALID, "null parameter pointer");
   if (L->krot <= 8 && !L->rot) return fail(PARO_ERR_INVALID, "packed rotation words missing (paro_pack_rotation)");
+  if (quant_group(L->group_size) < 0)
+    return fail(PARO_ERR_UNSUPPORTED, "Unsupported group_size: %d; expected 64 or 128", L->group_size);
   return PARO_OK;
 }
 
@@ -125,6 +127,11 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves_in <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
   if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
+  if (quant_group(L->group_size) == 64) {   // group_size 64 instantiations: 1 / 2 / 4 / 8 tiles, 4 or 8 waves
+    if (tpw == 3) tpw = 2;
+    if (tpw == 5 || tpw == 6 || tpw == 7) tpw = 4;
+    if (wv == 16) wv = 8;
+  }
   const int G = (int)(L->K / 128);
   const int gps = (G + ksp - 1) / ksp;
   ksp = (G + gps - 1) / gps;           // empty splits are dropped
@@ -227,6 +234,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.bias = (const unsigned short*)L->bias;
   a.y = (unsigned short*)y;
   a.rows = (int)rows;
+  a.qs = 128 / quant_group(L->group_size);
   int gps = (G + ksp - 1) / ksp;
   a.ksplit = (G + gps - 1) / gps;  // drop empty splits
   a.slabs = nullptr;

@@ -76,6 +76,7 @@ struct GemvArgs {
   int x_div;
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
+  int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
 static_assert(offsetof(GemvArgs, hot) == 0, "hot block at kernarg offset 0");
@@ -113,7 +114,9 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 //                      gate_up projection's output [rows][2 K] (the MLX MoE path rotates the activation output the
 //                      same way before down_proj, mlx/modules.py:204-207).
 //   epilogue residual  y += residual[row][col] (the decoder's residual stream), in the final write.
-template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0>
+// QS: quantisation groups per 128-channel rotation span (1: group_size 128, 2: group_size 64 -- two (scale, zero)
+// words per tile and column, the tile's first two / last two MFMA k-steps accumulated separately).
+template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0, int QS = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -280,8 +283,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   };
   struct TBuf {
     u32x4 q[TPW];
-    unsigned szw[TPW];
+    unsigned szw[QS][TPW];
   };
+  static_assert(QS == 1 || QS == 2, "one or two quantisation groups per 128-channel span");
+  constexpr int SPH = 4 / QS;   // MFMA k-steps (32 channels each) per quantisation group
 
   // element / chunk offsets are 32-bit (host-checked ranges): 64-bit scalar index arithmetic is several instructions
   // per term, in a prologue every wave of the CU executes on the one shared scalar unit
@@ -341,19 +346,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       const int jj = j < nt ? j : nt - 1;
       b.q[j] = __builtin_nontemporal_load(wq_p + ((unsigned)((tile0 + jj) * h.tstride + g * h.gstride) * 64u + (unsigned)lane));
     }
-    if constexpr (SZ_VEC) {
-      GP<unsigned> sp = sz_p + ((unsigned)g * szrow + (unsigned)(((ts0 >> 2) * 16 + n) * 4 + (ts0 & 3)));
 #pragma unroll
-      for (int v = 0; v < NSZ; ++v) {
-        const SZV q = *(GP<SZV>)(sp + v * 64);
+    for (int hq = 0; hq < QS; ++hq) {
+      const unsigned grow = (unsigned)(g * QS + hq) * szrow;   // row of the scale/zero array = quantisation group
+      if constexpr (SZ_VEC) {
+        GP<unsigned> sp = sz_p + (grow + (unsigned)(((ts0 >> 2) * 16 + n) * 4 + (ts0 & 3)));
 #pragma unroll
-        for (int e = 0; e < SZW; ++e) b.szw[v * 4 + e] = q[e];
-      }
-    } else {
+        for (int v = 0; v < NSZ; ++v) {
+          const SZV q = *(GP<SZV>)(sp + v * 64);
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int ts = ts0 + (j < nt ? j : nt - 1);
-        b.szw[j] = sz_p[(unsigned)g * szrow + (unsigned)(((ts >> 2) * 16 + n) * 4 + (ts & 3))];
+          for (int e = 0; e < SZW; ++e) b.szw[hq][v * 4 + e] = q[e];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int ts = ts0 + (j < nt ? j : nt - 1);
+          b.szw[hq][j] = sz_p[grow + (unsigned)(((ts >> 2) * 16 + n) * 4 + (ts & 3))];
+        }
       }
     }
   };
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const typename A::Unpack upk = A::unpack_consts();
   auto consume = [&](const vec8 (&af)[4 * RT], const TBuf& t) {
     // sx = sum_k x_k and so = sum_k x_k off_k (off_k = the per-element offset unpack_fast leaves in), per row tile
-    f32x4 sx[RT], so[RT];
+    f32x4 sx[RT][QS], so[RT][QS];
     {
       const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
       const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
@@ -471,22 +480,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       const vec8 fb = __builtin_bit_cast(vec8, offs);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        sx[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        so[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hq = 0; hq < QS; ++hq) {
+          sx[rt][hq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          so[rt][hq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          sx[rt] = A::mfma(af[rt * 4 + i], ob, sx[rt]);
-          so[rt] = A::mfma(af[rt * 4 + i], fb, so[rt]);
+          sx[rt][i / SPH] = A::mfma(af[rt * 4 + i], ob, sx[rt][i / SPH]);
+          so[rt][i / SPH] = A::mfma(af[rt * 4 + i], fb, so[rt][i / SPH]);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      f32x4 d[RT];
+      f32x4 d[RT][QS];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) d[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int hq = 0; hq < QS; ++hq) d[rt][hq] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if constexpr (DIAG == 2) {
-        d[0][0] = __builtin_bit_cast(float, (t.q[j][0] ^ t.q[j][1] ^ t.q[j][2] ^ t.q[j][3]) & 0x3fffffffu);
+        d[0][0][0] = __builtin_bit_cast(float, (t.q[j][0] ^ t.q[j][1] ^ t.q[j][2] ^ t.q[j][3]) & 0x3fffffffu);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -495,17 +509,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
           const vec8 bfrag = __builtin_bit_cast(vec8, wv);
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) d[rt] = A::mfma(af[rt * 4 + i], bfrag, d[rt]);
+          for (int rt = 0; rt < RT; ++rt) d[rt][i / SPH] = A::mfma(af[rt * 4 + i], bfrag, d[rt][i / SPH]);
         }
       }
-      const unsigned szw = t.szw[j];
-      const float s = f16_bits_to_f32(szw & 0xffffu);
-      const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int hq = 0; hq < QS; ++hq) {
+        const unsigned szw = t.szw[hq][j];
+        const float s = f16_bits_to_f32(szw & 0xffffu);
+        const float zf = f16_bits_to_f32(szw >> 16);
 #pragma unroll
-        for (int r = 0; r < MR; ++r)
-          acc[j][rt * MR + r] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][r], d[rt][r] - so[rt][r]), acc[j][rt * MR + r]);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < MR; ++r)
+            acc[j][rt * MR + r] =
+                __builtin_fmaf(s, __builtin_fmaf(-zf, sx[rt][hq][r], d[rt][hq][r] - so[rt][hq][r]), acc[j][rt * MR + r]);
+      }
     }
   };
   auto frags_from_lds = [&](const unsigned short* xs, vec8 (&af)[4 * RT]) {
@@ -752,6 +770,11 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
 template <typename AT, int TPW, int MB, bool PREROT, int FUSED>
 int launch_waves_fused_mode(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if constexpr (!PREROT && MB <= 4 && tpw_is_pow2(TPW)) {
+    if (a.qs == 2) {   // group_size 64: 8- and 4-wave workgroups
+      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, FUSED, 2>, 512>(a, grid, st);
+      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, FUSED, 2>, 256>(a, grid, st);
+      return fail(PARO_ERR_UNSUPPORTED, "group_size 64: fused prologue / epilogue is built for 4 or 8 waves per workgroup (got %d)", waves);
+    }
     if constexpr (TPW < 8) {
       if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, FUSED>, 1024>(a, grid, st);
     }
@@ -769,6 +792,13 @@ int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) 
 
 template <typename AT, int TPW, int MB, bool PREROT, int PD>
 int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (a.qs == 2) {   // group_size 64: power-of-two tiles per wave, 8- and 4-wave workgroups, shipping build only
+    if constexpr (tpw_is_pow2(TPW) && PD == 1) {
+      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, PREROT, 1, 0, 2>, 512>(a, grid, st);
+      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, PREROT, 1, 0, 2>, 256>(a, grid, st);
+    }
+    return fail(PARO_ERR_UNSUPPORTED, "group_size 64 is built for 1 / 2 / 4 / 8 tiles per wave and 4 or 8 waves per workgroup (got %d x %d)", TPW, waves);
+  }
   if constexpr (tpw_is_pow2(TPW) && TPW < 8 && MB <= 4) {   // 8 tiles x 16 waves does not fit 128 VGPRs
     if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, PREROT, PD>, 1024>(a, grid, st);
   }

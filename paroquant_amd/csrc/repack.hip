@@ -226,12 +226,13 @@ template <typename AT>
 __global__ __launch_bounds__(256) void dequant_packed_kernel(const unsigned* __restrict__ wq,
                                                             const unsigned* __restrict__ sz,
                                                             unsigned short* __restrict__ out, int K, int N,
-                                                            PartTable pt, int order) {
+                                                            PartTable pt, int order, int gs) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)K * N) return;
   const int k = (int)(gid / N), n = (int)(gid % N);
   const int G = K / 128;
   const int g = k >> 7, kk = k & 127;
+  const int gq = k / gs;   // quantisation group (row of the scale/zero array)
   const int i = kk >> 5, kb = (kk >> 3) & 3, e = kk & 7;
   const int t = n >> 4, lane = (kb << 4) | (n & 15);
   const int64_t chunk = order ? (int64_t)g * (N / 16) + t : (int64_t)t * G + g;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void dequant_packed_kernel(const unsigned* __r
   const int q = (int)((w >> (4 * ((e >> 1) + 4 * (e & 1)))) & 0xF);
   const int p = pt.part_of_tile(t);
   const int ts = pt.szt_start[p] + (t - pt.tile_start[p]);
-  const unsigned word = sz[(((int64_t)g * (pt.tsz / 4) + (ts >> 2)) * 16 + (n & 15)) * 4 + (ts & 3)];
+  const unsigned word = sz[(((int64_t)gq * (pt.tsz / 4) + (ts >> 2)) * 16 + (n & 15)) * 4 + (ts & 3)];
   const float s = f16_bits_to_f32(word & 0xffffu);
   const float zf = f16_bits_to_f32(word >> 16);  // zero point
   out[gid] = Act<AT>::from_f32(((float)q - zf) * s);
@@ -252,10 +253,11 @@ extern "C" int64_t paro_packed_qweight_bytes(int64_t K, int64_t N) {
   return K * N / 2;
 }
 
-extern "C" int64_t paro_packed_sz_bytes(int64_t K, int n_parts, const int32_t* part_cols) {
+extern "C" int64_t paro_packed_sz_bytes(int64_t K, int group_size, int n_parts, const int32_t* part_cols) {
   paro::PartTable pt;
-  if (K <= 0 || K % 128 != 0 || !paro::fill_part_table(pt, n_parts, part_cols, 1)) return -1;
-  return (K / 128) * (int64_t)pt.tsz * 16 * 4;
+  const int gs = paro::quant_group(group_size);
+  if (K <= 0 || K % 128 != 0 || gs < 0 || !paro::fill_part_table(pt, n_parts, part_cols, 1)) return -1;
+  return (K / gs) * (int64_t)pt.tsz * 16 * 4;
 }
 
 extern "C" int64_t paro_packed_rot_bytes(int64_t K, int n_parts) {
@@ -264,7 +266,7 @@ extern "C" int64_t paro_packed_rot_bytes(int64_t K, int n_parts) {
 }
 
 extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t K, int64_t N,
-                               int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz,
+                               int group_size, int n_parts, const int32_t* part_cols, int wq_order, void* out_wq, void* out_sz,
                                void* stream) {
   using namespace paro;
   if (K <= 0 || N <= 0 || K % 128 != 0)
@@ -272,6 +274,8 @@ extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, co
   if (N % 16 != 0) return fail(PARO_ERR_INVALID, "out_features must be a multiple of 16 (got %lld)", (long long)N);
   if (K > (1 << 24) || N > (1 << 24)) return fail(PARO_ERR_INVALID, "shape out of range");
   if (!qweight || !qzeros || !scales || !out_wq || !out_sz) return fail(PARO_ERR_INVALID, "null pointer");
+  const int gs = quant_group(group_size);
+  if (gs < 0) return fail(PARO_ERR_UNSUPPORTED, "Unsupported group_size: %d; expected 64 or 128", group_size);
   PartTable pt;
   if (!fill_part_table(pt, n_parts, part_cols, 1) || (int64_t)pt.tiles * 16 != N)
     return fail(PARO_ERR_INVALID, "partition sizes must be positive multiples of 16 summing to out_features");
@@ -279,7 +283,7 @@ extern "C" int paro_repack_awq(const int32_t* qweight, const int32_t* qzeros, co
   const int64_t words = K * N / 8;
   hipLaunchKernelGGL(repack_qweight_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                      (const unsigned*)qweight, (unsigned*)out_wq, (int)K, (int)N, wq_order ? 1 : 0);
-  const int G = (int)(K / 128);
+  const int G = (int)(K / gs);   // rows of the scale/zero array: quantisation groups
   (void)hipMemsetAsync(out_sz, 0, (size_t)G * pt.tsz * 64, st);
   const int64_t cols = (int64_t)G * N;
   hipLaunchKernelGGL(pack_sz_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, (const unsigned*)qzeros,
@@ -308,17 +312,18 @@ extern "C" int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* st
   using namespace paro;
   if (!L || !out_w || !L->wq || !L->sz) return fail(PARO_ERR_INVALID, "null pointer");
   PartTable pt;
-  if (L->K % 128 != 0 || !fill_part_table(pt, L->n_parts, L->part_cols, 1) || (int64_t)pt.tiles * 16 != L->N)
+  const int gs = quant_group(L->group_size);
+  if (L->K % 128 != 0 || gs < 0 || !fill_part_table(pt, L->n_parts, L->part_cols, 1) || (int64_t)pt.tiles * 16 != L->N)
     return fail(PARO_ERR_INVALID, "bad shape");
   const int64_t total = L->K * L->N;
   dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
   if (L->act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(dequant_packed_kernel<f16>, grid, dim3(256), 0, st, (const unsigned*)L->wq,
-                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order);
+                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order, gs);
   else if (L->act_dtype == PARO_DTYPE_BF16)
     hipLaunchKernelGGL(dequant_packed_kernel<bf16>, grid, dim3(256), 0, st, (const unsigned*)L->wq,
-                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order);
+                       (const unsigned*)L->sz, (unsigned short*)out_w, (int)L->K, (int)L->N, pt, L->wq_order, gs);
   else
     return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
   return check_launch("paro_dequant_packed");

@@ -40,23 +40,29 @@ class PackedParoWeights:
     """Kernel-ready parameters of one (possibly merged) ParoQuant linear.
 
     Built once from checkpoint-format tensors (``cli/convert.py:268-277``):
-      qweight int32 [K, N/8], qzeros int32 [K/128, N/8], scales f16 [K/128, N],
+      qweight int32 [K, N/8], qzeros int32 [K/gs, N/8], scales f16 [K/gs, N]  (gs = group_size, 128 or 64),
       theta f16 [P, krot, K/2], pairs int16 [P, krot, K], channel_scales f16 [P, 1, K].
     Takes the place of the Marlin-repacked tensors the reference stashes on the layer in
     ``process_weights_after_loading`` (vllm/plugin.py:251-279).
     """
 
     def __init__(self, qweight, qzeros, scales, theta, pairs, channel_scales, partition_sizes: Sequence[int],
-                 bias: Optional[torch.Tensor] = None, group_size: int = 128, bits: int = 4,
+                 bias: Optional[torch.Tensor] = None, group_size: Optional[int] = None, bits: int = 4,
                  wq_order: Optional[int] = None):
         if bits != 4:
             raise ValueError(f"Unsupported bits={bits}. Supported: [4]")          # plugin.py:84-85
-        if group_size != 128:
-            raise ValueError(f"Unsupported group_size={group_size}; the fused kernels need 128 "
-                             "(rotation group is fixed at 128 at inference, modules.py:60)")
+        if group_size is None:    # what the checkpoint tensors say: rows of qzeros = K / group_size
+            group_size = qweight.shape[0] // qzeros.shape[0] if qzeros.dim() == 2 and qzeros.shape[0] else 0
+        if group_size not in (64, 128):
+            raise ValueError(f"Unsupported group_size={group_size}; the fused kernels take a quantisation group of 64 or "
+                             "128 (the rotation group is 128 at inference either way, modules.py:59-60)")
         self.partition_sizes = [int(s) for s in partition_sizes]
+        self.group_size = int(group_size)
         K = qweight.shape[0]
         N = qweight.shape[1] * 8
+        if tuple(qzeros.shape) != (K // group_size, N // 8) or tuple(scales.shape) != (K // group_size, N):
+            raise ValueError(f"qzeros {tuple(qzeros.shape)} / scales {tuple(scales.shape)} do not match group_size {group_size} "
+                             f"for a [{K}, {N}] layer")
         if sum(self.partition_sizes) != N:
             raise ValueError(f"partition sizes {self.partition_sizes} do not sum to out_features {N}")
         if any(s % 16 for s in self.partition_sizes):
@@ -93,6 +99,10 @@ class PackedParoWeights:
         self.channel_scales = channel_scales.reshape(P, self.K).to(torch.float16).contiguous()
         self.wq_order = int(wq_order)
         self.wq, self.sz, self.rot = wq.contiguous(), sz.contiguous(), rot.contiguous()
+        tsz = sum((n // 16 + 7) // 8 * 8 for n in self.partition_sizes)
+        self.group_size = self.K // (self.sz.numel() // (tsz * 16))   # rows of the packed scale/zero array = K / group_size
+        if self.group_size not in (64, 128):
+            raise ValueError(f"packed scale/zero tensor of {self.sz.numel()} words does not belong to a [{self.K}, {self.N}] layer")
         self.bias = bias
         self._rmat = {}
         self.workspace = ops.get_workspace(wq.device, ops.decode_workspace_bytes(self.K, self.N, P))

@@ -63,7 +63,7 @@ class ParoMoEExperts:
                idx: torch.Tensor, x_div: int, prologue: int) -> None:
         lib = nat.load()
         d = ops.make_desc(pk0.K, pk0.partition_sizes, int(pk0.pairs.size(1)), x.dtype, wq, sz, pk0.rot, pk0.pairs, pk0.theta,
-                          pk0.channel_scales, None, 0)
+                          pk0.channel_scales, None, 0, group_size=pk0.group_size)
         f = nat.ParoFusion()
         f.prologue, f.eps, f.x_stride, f.residual = int(prologue), 0.0, 0, None
         e = nat.ParoExperts()

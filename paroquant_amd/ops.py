@@ -96,14 +96,18 @@ def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
         raise ValueError(f"in_features must be a multiple of 128, got {K}")
     if any(s <= 0 or s % 16 for s in sizes) or sum(sizes) != N:
         raise ValueError(f"partition sizes {sizes} must be positive multiples of 16 summing to out_features {N}")
-    if tuple(qzeros.shape) != (K // 128, NW) or tuple(scales.shape) != (K // 128, N):
+    # the quantisation group is what the checkpoint tensors say it is: K / rows(qzeros); 128 or 64 (the rotation
+    # always works on 128-channel groups at inference, transformers/modules.py:59)
+    rows_q = int(qzeros.shape[0]) if qzeros.dim() == 2 else 0
+    gs = K // rows_q if rows_q and K % rows_q == 0 else 0
+    if gs not in (64, 128) or tuple(qzeros.shape) != (K // gs, NW) or tuple(scales.shape) != (K // gs, N):
         raise ValueError(f"qzeros {tuple(qzeros.shape)} / scales {tuple(scales.shape)} do not match "
-                         f"[{K // 128}, {NW}] / [{K // 128}, {N}] (group_size must be 128)")
+                         f"[K/gs, {NW}] / [K/gs, {N}] for a group_size gs of 64 or 128 (K = {K})")
     qweight, qzeros, scales = qweight.contiguous(), qzeros.contiguous(), scales.contiguous()
     wq = torch.empty(lib.paro_packed_qweight_bytes(K, N) // 4, dtype=torch.int32, device=qweight.device)
-    sz = torch.empty(lib.paro_packed_sz_bytes(K, len(sizes), arr) // 4, dtype=torch.int32, device=qweight.device)
+    sz = torch.empty(lib.paro_packed_sz_bytes(K, gs, len(sizes), arr) // 4, dtype=torch.int32, device=qweight.device)
     with torch.cuda.device(qweight.device):
-        nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, len(sizes), arr,
+        nat.check(lib.paro_repack_awq(qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(), K, N, gs, len(sizes), arr,
                                       int(wq_order), wq.data_ptr(), sz.data_ptr(), nat.current_stream_ptr(qweight.device)))
     return wq, sz
 
@@ -111,7 +115,7 @@ def _repack_impl(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tens
 def _repack_fake(qweight, qzeros, scales, partition_sizes, wq_order=0):
     K, NW = qweight.shape
     tsz = sum((int(s) // 16 + 7) // 8 * 8 for s in partition_sizes)
-    return qweight.new_empty(K * NW), qweight.new_empty((K // 128) * tsz * 16)
+    return qweight.new_empty(K * NW), qweight.new_empty(int(qzeros.shape[0]) * tsz * 16)
 
 
 def _pack_rotation_impl(pairs: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
@@ -148,8 +152,17 @@ def _pack_rotation_fake(pairs, theta):
 
 
 def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, sz, rot, pairs,
-              theta, channel_scales, bias, wq_order: int = 0, rmat=None) -> nat.ParoLinearDesc:
+              theta, channel_scales, bias, wq_order: int = 0, rmat=None, group_size: int = 0) -> nat.ParoLinearDesc:
+    """``group_size`` 0: read it off the packed scale/zero tensor (rows = K / group_size); stacked expert tensors
+    (moe.py) pass it explicitly."""
     d = nat.ParoLinearDesc()
+    if group_size == 0:
+        tsz = sum((int(n) // 16 + 7) // 8 * 8 for n in partition_sizes)
+        rows_q = sz.numel() // (tsz * 16) if tsz else 0
+        group_size = K // rows_q if rows_q and K % rows_q == 0 else -1
+    if group_size not in (64, 128):
+        raise ValueError(f"Unsupported group_size: {group_size}; expected 64 or 128")
+    d.group_size = int(group_size)
     d.K = K
     d.N = int(sum(partition_sizes))
     d.n_parts = len(partition_sizes)
@@ -279,6 +292,8 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
     d.act_dtype = nat.dtype_code(dtype)
     d.wq_order = int(wq_order)
     d.wq, d.sz = wq.data_ptr(), sz.data_ptr()
+    tsz = sum((int(n) // 16 + 7) // 8 * 8 for n in partition_sizes)
+    d.group_size = K // (sz.numel() // (tsz * 16))   # rows of the packed scale/zero array = K / group_size
     with torch.cuda.device(wq.device):
         nat.check(lib.paro_dequant_packed(ctypes.byref(d), out.data_ptr(), nat.current_stream_ptr(wq.device)))
     return out

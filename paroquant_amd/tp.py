@@ -49,8 +49,10 @@ def shard_row_parallel(layer: Dict[str, torch.Tensor], rank: int, world: int, gr
     """Shard K (rows of qweight, group-rows of scales/qzeros) and narrow the rotation params
     (``loaded_weight.narrow(-1, tp_rank * shard, shard)``, plugin.py:47-50)."""
     K = layer["qweight"].shape[0]
-    if K % (world * group_size) != 0:
-        raise ValueError(f"in_features {K} cannot be split {world}-way in multiples of {group_size}")
+    group_size = K // layer["qzeros"].shape[0] if layer["qzeros"].shape[0] else group_size   # what the tensors say
+    # a shard must hold whole ROTATION groups (128 channels at inference whatever the quantisation group is)
+    if K % (world * max(group_size, 128)) != 0:
+        raise ValueError(f"in_features {K} cannot be split {world}-way in multiples of {max(group_size, 128)}")
     Kp = K // world
     g0, g1 = rank * Kp // group_size, (rank + 1) * Kp // group_size
     out = dict(layer)

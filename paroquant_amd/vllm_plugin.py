@@ -193,8 +193,8 @@ class ParoQuantConfig(QuantizationConfig):
             return None
         if is_layer_skipped(prefix, self.modules_to_not_convert, self.packed_modules_mapping, skip_with_substr=True):
             return UnquantizedLinearMethod()
-        if self.group_size != 128:
-            raise ValueError(f"Unsupported group_size={self.group_size}: the MI355X kernels need 128")
+        if self.group_size not in (64, 128):
+            raise ValueError(f"Unsupported group_size={self.group_size}: the MI355X kernels take 64 or 128")
         return ParoQuantLinearMethod(self)
 
 

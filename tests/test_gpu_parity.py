@@ -840,6 +840,130 @@ def test_hf_from_pretrained_end_to_end(dev, tmp_path):
     assert gen.shape == (1, 13)
 
 
+# ---------------------------------------------------------------- quantisation group_size 64 (rotation group stays 128)
+
+GS64_SHAPES = [(256, [48, 16]), (1024, [3072, 3072]), (2560, [4096, 1024, 1024]), (4096, [2560])]
+
+
+def _ideal(L, x, sizes, gs, bias=None):
+    return po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"], sizes,
+                                 bias, group_size=gs, ideal=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sizes", [(128, [16]), (512, [208, 48, 16]), (4096, [1024])])
+def test_repack_dequant_bit_exact_group64(dev, K, sizes):
+    """group_size 64 (reference: the AWQ matmul gets group_size, the rotation does not -- transformers/modules.py:59-69):
+    twice the scale/zero rows, same INT4 tiles; (q - z) * s bit-exact against the oracle."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + 64, K, sizes, group_size=64)
+    assert L["qzeros"].shape[0] == K // 64
+    wq, sz = torch.ops.paro.repack_awq(_t(L["qweight"], dev), _t(L["qzeros"], dev), _t(L["scales"], dev), sizes)
+    tsz = sum((s // 16 + 7) // 8 * 8 for s in sizes)
+    assert sz.numel() == (K // 64) * tsz * 16
+    w = ops.dequant_packed(wq, sz, K, sizes, torch.float16).cpu().numpy()
+    ref = po.dequant_awq(L["qweight"], L["qzeros"], L["scales"], 64, np.float16)
+    assert np.array_equal(w.view(np.uint16), ref.view(np.uint16))
+    wq128, _ = torch.ops.paro.repack_awq(_t(L["qweight"], dev), _t(L["qzeros"][::2].copy(), dev), _t(L["scales"][::2].copy(), dev), sizes)
+    assert torch.equal(wq, wq128)   # the INT4 tiles do not depend on the quantisation group
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sizes", GS64_SHAPES)
+@pytest.mark.parametrize("rows", [1, 3, 8, 16, 40])
+def test_gemv_group64_matches_oracle(dev, K, sizes, rows):
+    """Decode / small-batch path at group_size 64 (rows 40: the pre-rotated skinny path), f16 and bf16."""
+    L = po.make_layer(K + rows + 64, K, sizes, group_size=64, bias=(rows == 3))
+    x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+    pk = _packed(L, dev, L.get("bias"))
+    assert pk.group_size == 64
+    y = pk.apply(_t(x, dev))
+    ideal = _ideal(L, x, sizes, 64, L.get("bias"))
+    assert np.isfinite(_np(y)).all()
+    assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    yb = pk.apply(_t(x, dev).to(torch.bfloat16))
+    assert po.rel_err(_np(yb), ideal) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tpw,ksplit,waves,mode", [(1, 1, 8, 0), (2, 2, 4, 0), (4, 4, 8, 0), (8, 1, 8, 0), (0, 0, 0, 0), (3, 1, 0, 0),
+                                                   (1, 1, 16, 0), (2, 1, 0, 1), (4, 2, 4, 1)])
+def test_gemv_group64_launch_shapes(dev, tpw, ksplit, waves, mode):
+    """Launch-shape knobs at group_size 64: unsupported combinations (3 / 5 / 6 / 7 tiles, 16 waves) are resolved to a
+    built one, never to a wrong answer."""
+    from paroquant_amd import ops
+    K, sizes = 1536, [400, 112]
+    L = po.make_layer(164, K, sizes, group_size=64, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    rng = np.random.default_rng(7)
+    for rows in (1, 4, 7, 13):
+        if rows > 8 and tpw == 8:
+            continue
+        x = rng.standard_normal((rows, K)).astype(np.float16)
+        y = ops.w4a16_gemv_tuned(_t(x, dev), pk, tpw, ksplit, waves, mode, pk.bias)
+        assert po.rel_err(_np(y), _ideal(L, x, sizes, 64, L["bias"])) < TIGHT_F16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("K,sizes,rows", [(512, [256], 300), (1024, [272, 48], 700), (384, [512, 256, 256], 256), (256, [4096], 512)])
+def test_gemm_group64(dev, variant, K, sizes, rows):
+    """Prefill kernels at group_size 64: variant 1 (128 x 128) and variant 4 (256 x 256, k-steps 0..3 / 4..7 of a slab
+    dequantised with different scale / zero words); variants 2 and 3 refuse."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + rows + 64, K, sizes, group_size=64, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+    y = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=variant) if variant else pk.apply(_t(x, dev))
+    ideal = _ideal(L, x, sizes, 64, L["bias"])
+    assert np.isfinite(_np(y)).all()
+    assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    if variant == 4:
+        yb = ops.w4a16_gemm_forced(_t(x, dev).to(torch.bfloat16), pk, pk.bias.to(torch.bfloat16), variant=4)
+        assert po.rel_err(_np(yb), ideal) < 2e-2
+        with pytest.raises(RuntimeError, match="group_size 64"):
+            ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 4])
+def test_fused_prologues_group64(dev, rows):
+    """RMSNorm / SiLU*mul prologues and the residual epilogue at group_size 64."""
+    from paroquant_amd import ops, _native as nat
+    K, sizes = 1024, [3072, 3072]
+    L = po.make_layer(K + rows, K, sizes, group_size=64)
+    rng = np.random.default_rng(rows)
+    w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    x = (rng.standard_normal((rows, K)) * 3.0).astype(np.float16)
+    res = rng.standard_normal((rows, sum(sizes))).astype(np.float16)
+    pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+    y = ops.w4a16_gemv_fused(_t(x, dev), pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=_t(res, dev))
+    assert po.rel_err(_np(y), _ideal(L, po.rmsnorm(x, w, 1e-6), sizes, 64) + res.astype(np.float64)) < TIGHT_F16
+    Ld = po.make_layer(K + rows + 1, 3072, [1024], group_size=64)
+    gu = rng.standard_normal((rows, 2 * 3072)).astype(np.float16)
+    yd = ops.w4a16_gemv_fused(_t(gu, dev), _packed(Ld, dev), nat.PROLOGUE_SILU_MUL)
+    assert po.rel_err(_np(yd), _ideal(Ld, po.silu_mul(gu, 3072), [1024], 64)) < TIGHT_F16
+
+
+@pytest.mark.gpu
+def test_rotate_quantized_linear_module_group64(dev):
+    """The HF-style module with group_size=64 buffers (n_groups = K / 64, transformers/modules.py:40): state-dict load,
+    decode and prefill rows."""
+    from paroquant_amd import RotateQuantizedLinear
+    K, N = 512, 384
+    L = po.make_layer(64, K, [N], group_size=64, bias=True)
+    m = RotateQuantizedLinear(K, N, bias=True, group_size=64, bits=4, krot=8)
+    assert tuple(m.qzeros.shape) == (K // 64, N // 8) and tuple(m.scales.shape) == (K // 64, N)
+    m.load_state_dict({"theta": torch.from_numpy(L["theta"][0]), "pairs": torch.from_numpy(L["pairs"][0]),
+                       "channel_scales": torch.from_numpy(L["channel_scales"][0].reshape(1, K)), "qweight": torch.from_numpy(L["qweight"]),
+                       "qzeros": torch.from_numpy(L["qzeros"]), "scales": torch.from_numpy(L["scales"]), "bias": torch.from_numpy(L["bias"])})
+    m = m.to(dev)
+    for rows in (1, 5, 300):
+        x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+        y = m(_t(x, dev))
+        assert po.rel_err(_np(y), _ideal(L, x, [N], 64, L["bias"])) < TIGHT_F16
+
+
 # ---------------------------------------------------------------- f3: fused prologue / epilogue of the decode GEMV
 
 @pytest.mark.parametrize("K,sizes", [(2560, [4096, 1024, 1024]), (2560, [9728, 9728]), (1024, [3072, 3072]), (256, [48, 16])])

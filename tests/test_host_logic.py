@@ -42,9 +42,12 @@ def test_abi_validation_without_gpu(lib):
     assert lib.paro_packed_qweight_bytes(4096, 4096) == 4096 * 4096 // 2
     assert lib.paro_packed_qweight_bytes(100, 64) == -1
     sizes = (ctypes.c_int32 * 3)(4096, 1024, 1024)
-    assert lib.paro_packed_sz_bytes(4096, 3, sizes) == 32 * (256 + 64 + 64) * 16 * 4
+    assert lib.paro_packed_sz_bytes(4096, 128, 3, sizes) == 32 * (256 + 64 + 64) * 16 * 4
+    assert lib.paro_packed_sz_bytes(4096, 0, 3, sizes) == 32 * (256 + 64 + 64) * 16 * 4      # 0 = unset = 128
+    assert lib.paro_packed_sz_bytes(4096, 64, 3, sizes) == 64 * (256 + 64 + 64) * 16 * 4     # group_size 64: twice the rows
+    assert lib.paro_packed_sz_bytes(4096, 32, 3, sizes) == -1                                 # 64 or 128 only
     sizes2 = (ctypes.c_int32 * 2)(48, 16)      # 3 + 1 tiles -> padded to 8 + 8
-    assert lib.paro_packed_sz_bytes(256, 2, sizes2) == 2 * 16 * 16 * 4
+    assert lib.paro_packed_sz_bytes(256, 128, 2, sizes2) == 2 * 16 * 16 * 4
     assert lib.paro_packed_rot_bytes(4096, 3) == 3 * 32 * 3072
 
 
@@ -85,6 +88,32 @@ def test_rotate_quantized_linear_api_matches_reference():
     assert RotateQuantizedLinear(512, 256).bias is None
     with pytest.raises(RuntimeError, match="GPU"):
         m(torch.zeros(1, 512, dtype=torch.float16))
+    # group_size is the QUANTISATION group (n_groups = in_features // group_size, modules.py:40); rotation buffers do not change
+    m64 = RotateQuantizedLinear(512, 256, group_size=64)
+    assert tuple(m64.qzeros.shape) == (8, 32) and tuple(m64.scales.shape) == (8, 256) and tuple(m64.pairs.shape) == (8, 512)
+
+
+def test_group_size_host_checks():
+    """64 and 128 are accepted everywhere a group size enters, anything else is refused with the reference's wording
+    (rotation.cu:123 "Unsupported group_size")."""
+    from paroquant_amd.vllm_plugin import ParoQuantConfig
+    from paroquant_amd.linear import PackedParoWeights
+    from paroquant_amd.tp import shard_row_parallel
+    assert ParoQuantConfig(bits=4, group_size=64, krot=8, zero_point=True).group_size == 64
+    z = torch.zeros
+    with pytest.raises(ValueError, match="group_size"):
+        PackedParoWeights(z(256, 8, dtype=torch.int32), z(8, 8, dtype=torch.int32), z(8, 64, dtype=torch.float16), z(8, 128), z(8, 256),
+                          z(1, 256), [64])                      # 256 / 8 rows = group_size 32
+    with pytest.raises(ValueError, match="do not match group_size"):
+        PackedParoWeights(z(256, 8, dtype=torch.int32), z(4, 8, dtype=torch.int32), z(4, 64, dtype=torch.float16), z(8, 128), z(8, 256),
+                          z(1, 256), [64], group_size=128)      # the tensors say 64
+    # a row-parallel shard holds whole ROTATION groups (128) even when the quantisation group is 64
+    layer = {"qweight": z(256, 8, dtype=torch.int32), "qzeros": z(4, 8, dtype=torch.int32), "scales": z(4, 64, dtype=torch.float16),
+             "theta": z(8, 128), "pairs": z(8, 256, dtype=torch.int16), "channel_scales": z(1, 256)}
+    sh = shard_row_parallel(layer, 1, 2)
+    assert tuple(sh["qzeros"].shape) == (2, 8) and tuple(sh["qweight"].shape) == (128, 8)
+    with pytest.raises(ValueError, match="multiples of 128"):
+        shard_row_parallel(layer, 0, 4)
 
 
 def test_vllm_config_and_loaders():
