@@ -119,6 +119,41 @@ def test_g6_quantize_layer_end_to_end(golden_dir):
     assert po.rel_err(y, y_ref) < 2e-3    # only fp16 storage of scales / channel_scales / theta separates the two
 
 
+# ---- G10: the layer export at group_size 64 (the other group size the reference's operators accept) -----------------
+
+def test_g10_quantize_layer_group64(golden_dir):
+    """`_quantize_layer` run by the reference with group_size 64: [K/64]-row scale / zero tensors, same packing; and the
+    inference convention on top of it -- the AWQ matmul honours group_size, the rotation runs on 128-channel groups
+    (transformers/modules.py:59-69), which is the function the HIP kernels are tested against at group_size 64."""
+    g = _load(golden_dir, "quantize_layer_g64.npz")
+    w = g["weight"].astype(np.float32)
+    K = w.shape[1]
+    assert int(g["group_size"]) == 64 and g["out_qzeros"].shape[0] == K // 64 and g["out_scales"].shape[0] == K // 64
+    q, s2d, z2d = po.quantize_rotated_weight(w, g["pairs_in"], g["theta_in"].astype(np.float32), g["channel_scales_opt"],
+                                             g["scale"], g["zero_point_float"], 4, 64, "f32")
+    b = po.to_awq_buffers(q, s2d, z2d)
+    assert np.array_equal(b["qweight"], g["out_qweight"])
+    assert np.array_equal(b["qzeros"], g["out_qzeros"])
+    assert np.array_equal(b["scales"].view(np.uint16), g["out_scales"].view(np.uint16))
+    # dequant with the group size of the tensors
+    wd = po.dequant_awq(g["out_qweight"], g["out_qzeros"], g["out_scales"], 64, np.float32)
+    zz = po.unpack_awq(g["out_qzeros"]).astype(np.float32)
+    k, n = 200, 17
+    assert wd[k, n] == (po.unpack_awq(g["out_qweight"])[k, n] - zz[k // 64, n]) * np.float32(g["out_scales"][k // 64, n])
+    # The exported pairs live inside 64-channel groups (the optimiser's group size) while inference rotates 128-channel
+    # groups (modules.py:59): read that way they are NOT a perfect matching -- the reference's CUDA kernel would have
+    # two threads write the same shared-memory slots.  paro_pack_rotation refuses them ("illegal pair"); the inference
+    # convention at group_size 64 is therefore tested with pairs that are valid for 128 (tests/test_gpu_parity.py,
+    # `*group64*`), on exactly these [K/64]-row quantisation tensors.
+    assert po.is_valid_pairing(g["out_pairs"], 64) and not po.is_valid_pairing(g["out_pairs"], 128)
+    pairs128 = po.random_pairs(np.random.default_rng(11), 8, K, 128)
+    x = np.random.default_rng(10).standard_normal((3, K))
+    y = po.paro_linear(x, g["out_qweight"], g["out_qzeros"], g["out_scales"], g["out_theta"], pairs128, g["out_channel_scales"],
+                       None, 64, ideal=True)
+    xr = po.rotate(x, pairs128, g["out_theta"].astype(np.float64), g["out_channel_scales"].astype(np.float64), 128, mode="ideal")
+    assert np.allclose(y, xr @ wd.astype(np.float64), rtol=1e-10, atol=1e-12)
+
+
 # ---- G9: MoE expert export (cli/convert.py:280-379) --------------------------------------------------------
 
 def test_g9_quantize_moe(golden_dir):
