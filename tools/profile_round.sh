@@ -58,5 +58,17 @@ S=$(find $OUT/e2e_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$S" ] && python tools/pmc_summary.py stats $S $P/${R}_e2e_qwen3-4b_kernel_stats.csv
 timeout 200 python tools/bench_fused.py --model qwen3-4b > $P/${R}_fused_vs_plain.jsonl 2>> $OUT/e2e.err
 timeout 200 python tools/bench_attn.py > $P/${R}_attn_decode.jsonl 2>> $OUT/e2e.err
+# ---- context probes: the vendor's dense kernels on the same shapes, grid-barrier cost, kernarg fetch latency, per-wave timeline
+timeout 300 python tools/bench_vendor.py --model llama3-8b > $P/${R}_vendor_llama3-8b.jsonl 2>> $OUT/vendor.err
+timeout 200 python tools/bench_vendor.py --model qwen3-4b --rows 1,8192 > $P/${R}_vendor_qwen3-4b.jsonl 2>> $OUT/vendor.err
+[ -x tools/probes/barrier_probe ] && timeout 100 tools/probes/barrier_probe > $P/${R}_grid_barrier_probe.jsonl 2>> $OUT/vendor.err
+[ -x tools/probes/kernarg_probe_sload ] && { timeout 60 tools/probes/kernarg_probe_sload; timeout 60 tools/probes/kernarg_probe_preload; } > $P/${R}_kernarg_probe.jsonl 2>> $OUT/vendor.err
+if [ -f paroquant_amd/_lib_diag/libparo_mi355x.so ]; then
+  rm -f $P/${R}_gemv_timeline.txt
+  for spec in "qkv_proj 2 16" "gate_up_proj 8 8" "o_proj 1 16" "down_proj 1 16"; do
+    set -- $spec
+    PARO_LIB_DIR=_lib_diag PARO_GEMV_PD=31 timeout 100 python tools/timeline_gemv.py --model qwen3-4b --linear $1 --tpw $2 --waves $3 2>> $OUT/vendor.err | grep -v amdgpu.ids >> $P/${R}_gemv_timeline.txt
+  done
+fi
 mkdir -p $ROOT/gpurun_out/$R/profiles_copy && cp $P/${R}_* $ROOT/gpurun_out/$R/profiles_copy/
 tail -1 $P/${R}_bench_qwen3-4b.jsonl | cut -c1-400; head -1 $P/${R}_bench_qwen3-4b.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['roofline'], d.get('end_to_end'), d.get('cpu_baseline'))"
