@@ -225,11 +225,11 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.hot.rot = (const unsigned*)L->rot;
   a.hot.cs = (const unsigned short*)L->channel_scales;
   a.hot.x = (const unsigned short*)x;
-  a.hot.G = (unsigned)G;
-  a.hot.tstride = L->wq_order ? 1 : G;
-  a.hot.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  a.residual = fused ? (const unsigned short*)F->residual : nullptr;
-  a.N = (int)L->N;
+  {
+    const unsigned long long rp = fused ? (unsigned long long)(uintptr_t)F->residual : 0ull;
+    a.hot.residual_lo = (unsigned)rp;
+    a.hot.residual_hi = (unsigned)(rp >> 32);
+  }
   a.eps = fused ? F->eps : 0.f;
   a.bias = (const unsigned short*)L->bias;
   a.y = (unsigned short*)y;
@@ -249,7 +249,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.x_div = E ? E->x_slot_div : 1;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
   auto repack_hot = [&]() {
-    return pack_hot(a.hot, pt, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride);
+    return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride);
   };
   if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 

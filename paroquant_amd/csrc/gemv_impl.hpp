@@ -48,10 +48,10 @@ struct alignas(16) GemvHot {
   const unsigned* rot;           // 4..5
   const unsigned short* cs;      // 6..7
   const unsigned short* x;       // 8..9   [rows][K], or pre-rotated [nparts][rows][K] when PREROT
-  unsigned G;                    // 10     K / 128
-  unsigned meta;                 // 11     rows | krot << 8 | ksplit << 16 | skew << 24 | prio << 25 | prologue << 26 | experts << 28
+  unsigned g_t;                  // 10     G = K / 128 | T = N / 16 << 16   (tile (t, g) = chunk t * G + g, or g * T + t when order)
+  unsigned meta;                 // 11     rows | krot << 8 | ksplit << 16 | skew << 24 | prio << 25 | prologue << 26 | experts << 28 | order << 29
   unsigned gps_tsz;              // 12     groups per K-split | scale/zero tiles per group row << 16
-  int tstride, gstride;          // 13, 14 1-KiB chunk index of tile (t, g) = t * tstride + g * gstride
+  unsigned residual_lo, residual_hi;  // 13, 14 pointer to [rows][N] added to the output, or null (FUSED); two dwords: offset 52 is not pointer-aligned
   unsigned xstride;              // 15     elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
   int cbs[7];                    // 16..22 first column block of partition q = 1..7 at [q - 1]; INT_MAX beyond the last
   unsigned ent[9];               // 23..31 partition q = 0..8: first tile | first scale/zero tile << 16 (q = nparts: the totals)
@@ -61,8 +61,6 @@ static_assert(sizeof(GemvHot) == 128, "the hot argument block is two s_load_dwor
 struct GemvArgs {
   GemvHot hot;                   // must stay first: the kernel reads it at kernarg offset 0
   // ---- cold: first used once the first global loads are in flight
-  const unsigned short* residual;  // [rows][N] added to the output, or null (FUSED)
-  int N;
   float eps;                     // RMSNorm epsilon (FUSED)
   const unsigned short* bias;
   unsigned short* y;
@@ -82,11 +80,12 @@ struct GemvArgs {
 static_assert(offsetof(GemvArgs, hot) == 0, "hot block at kernarg offset 0");
 
 // host: pack the hot block; false when a table entry does not fit 16 bits
-inline bool pack_hot(GemvHot& h, const PartTable& pt, int rows, int krot, int ksplit, int gps, int skew, int prio, int prologue,
-                     bool experts, long long xstride) {
-  if (pt.tiles >= 0xffff || pt.tsz >= 0xffff || gps > 0xffff || xstride < 0 || xstride > 0xffffffffll) return false;
+inline bool pack_hot(GemvHot& h, const PartTable& pt, int G, int order, int rows, int krot, int ksplit, int gps, int skew, int prio,
+                     int prologue, bool experts, long long xstride) {
+  if (pt.tiles >= 0xffff || pt.tsz >= 0xffff || gps > 0xffff || G > 0xffff || xstride < 0 || xstride > 0xffffffffll) return false;
+  h.g_t = (unsigned)G | ((unsigned)pt.tiles << 16);
   h.meta = (unsigned)rows | ((unsigned)krot << 8) | ((unsigned)ksplit << 16) | ((unsigned)(skew != 0) << 24) |
-           ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28);
+           ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28) | ((unsigned)(order != 0) << 29);
   h.gps_tsz = (unsigned)gps | ((unsigned)pt.tsz << 16);
   h.xstride = (unsigned)xstride;
   for (int q = 1; q < PARO_MAX_PARTS; ++q) h.cbs[q - 1] = (q < pt.nparts) ? pt.cb_start[q] : 0x7fffffff;
@@ -192,7 +191,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     GP<unsigned> rot;
     GP<unsigned short> cs;
     GP<unsigned short> x;
-    int K, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
+    GP<unsigned short> residual;
+    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
     long long xstride;
   } h;
   {
@@ -202,8 +202,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.rot = (GP<unsigned>)ptr(k0[4], k0[5]);
     h.cs = (GP<unsigned short>)ptr(k0[6], k0[7]);
     h.x = (GP<unsigned short>)ptr(k0[8], k0[9]);
-    h.G = (int)k0[10];
+    h.G = (int)(k0[10] & 0xffffu);
     h.K = h.G * 128;
+    const int T = (int)(k0[10] >> 16);
+    h.N = T * 16;
     const unsigned meta = k0[11];
     h.rows = (int)(meta & 0xffu);
     h.krot = (int)((meta >> 8) & 0xffu);
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.experts = (int)((meta >> 28) & 1u);
     h.gps = (int)(k0[12] & 0xffffu);
     h.tsz = (int)(k0[12] >> 16);
-    h.tstride = (int)k0[13];
-    h.gstride = (int)k0[14];
+    const bool order = (meta >> 29) & 1u;
+    h.tstride = order ? 1 : h.G;
+    h.gstride = order ? T : 1;
+    h.residual = (GP<unsigned short>)ptr(k0[13], k0[14]);
     h.xstride = (long long)k0[15];
   }
   GP<u32x4> wq_p = h.wq;
@@ -225,7 +229,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   if constexpr (FUSED != 0) {
     if (h.experts) {
       slot = blockIdx.z;
-      const long long ex = a.expert_idx[slot];
+      // the id is the same for the whole workgroup: pulled back into a scalar register so that the pointers derived
+      // from it stay scalar (otherwise EVERY fused instantiation addresses its loads through 64-bit vector registers)
+      const long long ex = __builtin_amdgcn_readfirstlane(a.expert_idx[slot]);
       wq_p = (GP<u32x4>)((GP<unsigned char>)h.wq + ex * a.wq_estride);
       sz_p = (GP<unsigned>)((GP<unsigned char>)h.sz + ex * a.sz_estride);
       x_p = h.x + (long long)(slot / a.x_div) * a.x_sstride;
@@ -367,6 +373,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   };
 
+  // residual epilogue: the value this thread adds to its FIRST output is requested here, at kernel entry -- not as a
+  // dependent load after the reduction (~1 us of pure latency at the tail) -- and UNCONDITIONALLY (clamped address,
+  // validity applied at the use): a load inside a branch makes the compiler's vmcnt bookkeeping give up, and the wait
+  // for the first coefficients then becomes a wait for the HBM tiles as well (measured: +0.6 us per fused launch).
+  unsigned short res_raw = 0;
+  bool res_valid = false;
+  if constexpr (FUSED) {
+    const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
+    const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
+    const bool has_res = h.residual != nullptr;
+    res_valid = has_res && tid < TPW * MRT * 64 && ks == h.ksplit - 1 && j < nt && b < h.rows;   // only the workgroup that writes y
+    GP<unsigned short> rbase = has_res ? h.residual : h.cs;                                     // any readable address when there is none
+    res_raw = rbase[res_valid ? (unsigned)(b * h.N + (tile0 + j) * 16 + (el & 15)) : 0u];
+  }
   // the first unit's tiles are requested HERE, straight after the bookkeeping they need (the unit/skew logic of the
   // driver loop below is not needed for them: unit 0 of a wave is always group gf_first)
   TBuf tc_first;
@@ -382,14 +402,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // start: channels 2l, 2l+1 of the group (one coalesced load), times their channel scales
   // residual epilogue: the value this thread will add to its FIRST output is requested here, at kernel entry, not
   // as a dependent load after the reduction (a global access at the tail is ~1 us of pure latency)
-  float res_first = 0.f;
-  if constexpr (FUSED) {
-    if (a.residual && tid < TPW * MRT * 64 && ks == h.ksplit - 1) {   // only the workgroup that writes y
-      const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
-      const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
-      if (j < nt && b < h.rows) res_first = A::to_f32(a.residual[(int64_t)b * a.N + (tile0 + j) * 16 + (el & 15)]);
-    }
-  }
+  // (the residual value of this thread's first output was requested above, unconditionally: res_raw / res_valid)
   float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
 #pragma unroll
   for (int r = 0; r < (FUSED ? MB : 1); ++r) ssq[r] = 0.f;
@@ -643,10 +656,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     if (h.prologue == PARO_PROLOGUE_RMSNORM) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
+        // wave-wide sum on the VALU's DPP paths (six dependent adds, ~50 cycles; the total ends up in lane 63) -- six
+        // __shfl_xor steps are six dependent ds_bpermute round trips (~600 cycles at the tail of every fused launch)
         float v = has_work_any ? ssq[r] : 0.f;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) ssl[wave * MB + r] = v;
+        auto dpp_add = [](float a, auto ctrl_tag, auto mask_tag) {
+          constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+          return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, MASK, 0xf, false));
+        };
+        v = dpp_add(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+        v = dpp_add(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+        v = dpp_add(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+        v = dpp_add(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror: every lane = its row's sum
+        v = dpp_add(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+        v = dpp_add(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+        if (lane == 63) ssl[wave * MB + r] = v;
       }
     }
   }
@@ -677,20 +700,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
-      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
     } else if (ks != h.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
       const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
-      __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * a.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * h.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
       // partial in registers, poll the other splits' granules until their tags appear (bounded),
       // re-arm them to zero for the next launch, write y once.
       for (int s = 0; s < h.ksplit - 1; ++s) {
-        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * a.N + col;
+        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
         unsigned long long gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
           __builtin_amdgcn_s_sleep(2);
@@ -711,9 +734,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
       if constexpr (FUSED) {
-        if (a.residual) v += (e == tid) ? res_first : A::to_f32(a.residual[(int64_t)b * a.N + col]);
+        if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
-      y_p[(int64_t)b * a.N + col] = A::from_f32(v);
+      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
     }
   }
   if constexpr (DIAG == 3) {
@@ -822,7 +845,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || a.residual || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 
