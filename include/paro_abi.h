@@ -252,7 +252,9 @@ int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t ro
  * attention to HF generate() / vLLM, transformers/generator.py:37-67): optional per-head q / k RMSNorm (Qwen3),
  * rotary embedding (rotate_half convention), KV-cache append at *pos, grouped-query attention over 0..*pos.
  *   qkv     act_dtype [(n_heads + 2 n_kv_heads) * head_dim]   (output of the merged qkv projection)
- *   kcache, vcache  act_dtype [n_kv_heads][max_positions][head_dim]
+ *   kcache          act_dtype [n_kv_heads][max_positions][head_dim]
+ *   vcache          act_dtype [n_kv_heads][head_dim][max_positions]  (position-contiguous: the P V product reads it as
+ *                   MFMA fragments); max_positions a multiple of 8
  *   out     act_dtype [n_heads * head_dim]
  *   pos     int32 in DEVICE memory (a captured graph replays for every token)
  *   rope    fp32 [max_positions][head_dim]: cos then sin (head_dim / 2 each) of every position

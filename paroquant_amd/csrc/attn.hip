@@ -5,10 +5,10 @@
 // down GEMV) inside one HIP graph, and the end-to-end tokens/s of north_star can be measured.
 //
 // Grid = (KV heads, position chunks of 256).  A workgroup handles one chunk of one KV head for all of that head's
-// n_rep = Hq / Hkv query heads (they share every K / V byte): every global load of the chunk -- one K row per thread,
-// one channel pair of 64 V rows per thread -- is requested before anything else, scores one position per thread,
-// soft-max statistics through LDS, P V from the registers -- a CU ingests ~10 B / clock, so long contexts are spread over many CUs rather than one
-// workgroup per head.  With more than one active chunk the partial (max, sum, unnormalised output) triples go to
+// n_rep = Hq / Hkv query heads (they share every K / V byte): every global load of the chunk -- K and V as MFMA B
+// fragments, 16 bytes per lane and load -- is requested before anything else; scores and P V run on the matrix cores,
+// the soft-max of a wave's 64 positions in registers -- a CU ingests ~10 B / clock, so long contexts are spread over
+// many CUs rather than one workgroup per head.  The V cache is kept position-contiguous ([head][dim][position]) for that.  With more than one active chunk the partial (max, sum, unnormalised output) triples go to
 // a workspace and the LAST workgroup of a KV head to arrive (agent-scope release -> ticket -> acquire; no spinning,
 // so no dependence on dispatch order) merges them.  The position comes from DEVICE memory, so one captured graph
 // replays for every token: the grid always covers max_positions, chunks beyond `pos` exit at once.
@@ -25,7 +25,7 @@ constexpr int kChunk = 256;
 struct AttnArgs {
   const unsigned short* qkv;   // [(Hq + 2 Hkv) * hd]: q heads, k heads, v heads of this token
   unsigned short* kcache;      // [Hkv][T_max][hd]
-  unsigned short* vcache;
+  unsigned short* vcache;      // [Hkv][hd][T_max]  (position-contiguous: the P V product's MFMA B fragments are 16-byte loads)
   unsigned short* out;         // [Hq * hd]
   const int* pos;              // device scalar: 0-based position of this token
   const float* rope;           // [T_max][hd]: cos[0 .. hd/2) then sin[0 .. hd/2) of every position
@@ -38,202 +38,298 @@ struct AttnArgs {
   int dbg;                     // PARO_ATTN_DBG: stop after phase N (timing ablation; wrong results)
 };
 
-// NREP = query heads per KV head rounded up to a power of two: a COMPILE-TIME bound, so that the score and P V
-// loops unroll without a branch per iteration (with a run-time bound every iteration became its own basic block and
-// paid the LDS latency of its probability reads: the P V phase alone took 18 us for 256 positions).  Padding heads
-// have zero queries and are never stored.
+// Cross-lane reductions on the VALU's DPP paths (a dependent step costs ~8 cycles; a __shfl_xor step is a ds_bpermute
+// round trip of ~100): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror leave the reduction of
+// every 16-lane row in all of its lanes; row_bcast:15 / row_bcast:31 carry on to the whole wave (total in lane 63).
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_f(float a) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, RMASK, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1, 0xf>(v);
+  v += dpp_f<0x4E, 0xf>(v);
+  v += dpp_f<0x141, 0xf>(v);
+  v += dpp_f<0x140, 0xf>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {   // the same value in every lane
+  v = row16_sum(v);
+  v += dpp_f<0x142, 0xa>(v);
+  v += dpp_f<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// NREP = query heads per KV head rounded up to a power of two: a COMPILE-TIME bound, so that every loop over heads
+// unrolls without a branch per iteration.  Padding heads have zero queries and are never stored.
+//
+// Latency chain of a workgroup (what the kernel is bound by at short contexts: 8 workgroups, ~10 us of dependent
+// steps): [K / V of the chunk + this token's q / k / v requested] -> q / k norm, RoPE, KV append -> ONE barrier ->
+// scores on the matrix cores (the new key patched into the K fragments) -> soft-max of each wave's 64 positions in
+// registers (DPP row reductions, no LDS, no barrier) -> P V of the wave's own rows -> ONE barrier -> the four waves'
+// (max, sum, partial output) triples merged like chunks are.
 template <typename AT, int HD, int NREP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   typedef Act<AT> A;
+  typedef typename A::vec8 vec8;
   constexpr int hd = HD, half = HD / 2;
-  constexpr int GROUPS = 256 / half;           // thread = (group, channel pair) in the P V phase: 4 (hd 128) / 8 (hd 64)
-  constexpr int VN = kChunk / GROUPS;          // cache rows per thread in the P V phase
-  __shared__ __attribute__((aligned(16))) float qs[NREP * HD];        // [NREP][hd] roped queries * scale
-  __shared__ __attribute__((aligned(16))) float sc[NREP * kChunk];    // [NREP][chunk] scores -> probabilities (0 past the chunk)
-  __shared__ __attribute__((aligned(16))) float accs[GROUPS * NREP * HD];  // [groups][NREP][hd] partial outputs
-  __shared__ float knew[HD], red[8 * 8];
-  __shared__ __attribute__((aligned(16))) unsigned short q16[16 * HD];   // [16 MFMA rows][hd] roped queries (activation dtype), rows >= n_rep zero
+  constexpr int DT = HD / 16;                  // 16-column output tiles of the P V product
+  constexpr float kLog2e = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) float pw[4 * NREP * 64];        // [wave][head][64] unnormalised probabilities of the wave's positions
+  __shared__ __attribute__((aligned(16))) float accs[4 * NREP * HD];      // [wave][head][hd] partial outputs
+  __shared__ float st[4 * NREP * 2];                                       // [wave][head] (max, sum) of the wave's positions
+  __shared__ __attribute__((aligned(16))) unsigned short q16[16 * HD];     // [16 MFMA rows][hd] roped queries (activation dtype), rows >= n_rep zero
+  __shared__ __attribute__((aligned(16))) unsigned short k16[HD];          // the new token's roped key (activation dtype)
+  __shared__ __attribute__((aligned(16))) unsigned short v16[HD];          // the new token's value
   __shared__ unsigned last_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, s = blockIdx.y;
   const int n_rep = a.Hq / a.Hkv;
   const int p0 = s * kChunk;
-  // ---- every global load of the chunk is requested up front (a dependent global access costs ~1-2 us at this
-  // occupancy).  K in v_mfma_f32_16x16x32 B-fragment order: wave w owns positions 64 w .. 64 w + 63 of the chunk as four
-  // tiles of 16; lane (kb = l >> 4, n = l & 15) holds dims 32 i + 8 kb .. + 7 of position 16 t + n for k-step i: kw[t][i].
-  // V: this thread's channel pair of VN cache rows.  Chunk 0 always takes part, so ITS loads do not wait for the
-  // position to arrive from device memory (rows clamped to the cache, masked once `pos` is known); later chunks first
-  // learn from `pos` whether they run at all.
-  constexpr int KS = HD / 32;
-  u32x4 kw[4][KS];
-  const int dq = tid % half, grp = tid / half;
-  unsigned vv[VN];
-  const unsigned vtok = *((const unsigned*)(a.qkv + (int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd) + dq);   // this token's v
-  // the loads themselves are unconditional and clamped to the cache (a load inside a select becomes a branch per row:
-  // 64 serialised round trips); rows past the chunk and the new token's row are masked where they are consumed
-  auto issue_loads = [&]() {
-    const int kb = lane >> 4, nn = lane & 15;
+  const int kb = lane >> 4, mm = lane & 15;
+  // The position first, through the scalar cache (one ~300-cycle round trip, nothing queued in front of it): chunks
+  // beyond it leave at once, and the rotary row -- the only load that depends on it -- goes out ahead of the K / V stream.
+  constexpr int KS = HD / 32;                  // MFMA k-steps of a score (32 head dims each)
+  // this token's query heads and key (vector v < n_rep: query head, v == n_rep: the key; wave w takes v = w, w + 4, ..),
+  // the norm weights, this token's value: none of it depends on the position, so it is in flight while the position
+  // makes its round trip
+  constexpr int ITER = (NREP + 1 + 3) / 4;
+  const bool act = lane < half;
+  const int li = act ? lane : 0;
+  float x0[ITER], x1[ITER], w0[ITER], w1[ITER];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = min(p0 + wave * 64 + t * 16 + nn, a.T_max - 1);
-      const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + row) * hd) + kb;
-#pragma unroll
-      for (int i = 0; i < KS; ++i) kw[t][i] = kr[4 * i];
-    }
-    const unsigned* vbase = (const unsigned*)(a.vcache + (int64_t)h * a.T_max * hd) + dq;
-#pragma unroll
-    for (int u = 0; u < VN; ++u) vv[u] = vbase[(int64_t)min(p0 + grp + u * GROUPS, a.T_max - 1) * half];
-  };
-  if (s == 0) issue_loads();
-  const int pos = *a.pos;
+  for (int it = 0; it < ITER; ++it) {
+    const int v = min(wave + 4 * it, n_rep);
+    const bool isk = v == n_rep;
+    const unsigned short* src = isk ? a.qkv + (int64_t)a.Hq * hd + (int64_t)h * hd : a.qkv + ((int64_t)h * n_rep + v) * hd;
+    x0[it] = A::to_f32(src[li]);
+    x1[it] = A::to_f32(src[li + half]);
+    const unsigned short* nw = isk ? a.knw : a.qnw;
+    w0[it] = nw ? A::to_f32(nw[li]) : 1.f;
+    w1[it] = nw ? A::to_f32(nw[li + half]) : 1.f;
+  }
+  const unsigned short vnew = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + (tid < hd ? tid : 0)];   // this token's v[tid]
+  // The position, through the scalar cache (one ~300-cycle round trip): chunks beyond it leave at once; nothing past
+  // the chunk's last position is requested below (a CU ingests ~13 B / clock: the 128 KiB of a full chunk are ~4.5 us,
+  // the floor of this kernel).
+  int pos;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
   if (p0 > pos || pos >= a.T_max || pos < 0) return;  // chunk beyond the current position; a position outside the cache writes nothing
   const int n_act = pos / kChunk + 1;                 // chunks that take part
   const int cn = min(kChunk, pos + 1 - p0);           // positions of this chunk
   const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position
-  if (s != 0) issue_loads();
-
-  // padding query heads are zero, scores past the chunk are zero: the loops below need no bounds
-  for (int e = tid; e < NREP * HD; e += 256) qs[e] = 0.f;
-  for (int e = tid; e < 16 * HD / 2; e += 256) ((unsigned*)q16)[e] = 0u;
-  for (int e = tid; e < NREP * kChunk; e += 256) sc[e] = 0.f;
-  __syncthreads();
-
-  // ---- step 1: per-head RMSNorm (optional) + rotary embedding of the n_rep query heads (and of the new key)
   const float* rp = a.rope + (int64_t)pos * hd;
-  for (int v = wave; v <= n_rep; v += 4) {          // vector v < n_rep: query head, v == n_rep: the key
-    const bool isk = v == n_rep;
-    if (isk && !own_new) continue;
-    const unsigned short* src = isk ? a.qkv + (int64_t)a.Hq * hd + (int64_t)h * hd : a.qkv + ((int64_t)h * n_rep + v) * hd;
-    const unsigned short* nw = isk ? a.knw : a.qnw;
-    const bool act = lane < half;
-    float x0 = act ? A::to_f32(src[lane]) : 0.f, x1 = act ? A::to_f32(src[lane + half]) : 0.f;
-    if (nw) {
-      float ss = x0 * x0 + x1 * x1;
+  const float rope_c = rp[li], rope_s = rp[half + li];
+  // ---- the chunk's K and V, all requested here (a dependent global access costs ~1-2 us at this occupancy), as MFMA B
+  // fragments: wave w owns positions 64 w .. 64 w + 63 of the chunk.
+  //   K [pos][dim]: tile t = positions 16 t .. + 15; lane (kb, mm) holds dims 32 i + 8 kb .. + 7 of position 16 t + mm: kw[t][i]
+  //   V [dim][pos]: tile t = dims 16 t .. + 15; lane (kb, mm) holds positions 32 i + 8 kb .. + 7 of dim 16 t + mm: vf[t][i]
+  // Every load is issued unconditionally -- a load inside a branch makes the compiler's vmcnt bookkeeping give up and the
+  // first use of K then waits for V as well -- but tiles past the chunk's end all read ONE address (the chunk's first
+  // row: a single cache line for the whole wave), so they cost no bandwidth.  Rows past the end and the new token's row
+  // (not in the cache yet) are masked / patched where they are consumed.
+  u32x4 kw[4][KS];
+  u32x4 vf[DT][2];
+  {
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-      const float r = __builtin_amdgcn_rsqf(ss / (float)hd + a.eps);
-      // HF: normalise in fp32, round to the activation dtype, then multiply by the weight
-      if (act) {
-        x0 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(x0 * r)) * A::to_f32(nw[lane])));
-        x1 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(x1 * r)) * A::to_f32(nw[lane + half])));
-      }
+    for (int t = 0; t < 4; ++t) {
+      const bool need = wave * 64 + t * 16 < cn;
+      const int row = need ? min(p0 + wave * 64 + t * 16 + mm, a.T_max - 1) : p0;
+      const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + row) * hd) + (need ? kb : 0);
+#pragma unroll
+      for (int i = 0; i < KS; ++i) kw[t][i] = kr[need ? 4 * i : 0];
     }
-    if (act) {
-      // rotate_half convention, cos / sin rounded to the activation dtype like HF's rotary embedding does
-      const float c = A::to_f32(A::from_f32(rp[lane])), sn = A::to_f32(A::from_f32(rp[half + lane]));
-      const float y0 = A::to_f32(A::from_f32(x0 * c - x1 * sn)), y1 = A::to_f32(A::from_f32(x1 * c + x0 * sn));
-      if (isk) {
-        knew[lane] = y0;
-        knew[lane + half] = y1;
-        unsigned short* kc = a.kcache + ((int64_t)h * a.T_max + pos) * hd;
-        kc[lane] = A::from_f32(y0);
-        kc[lane + half] = A::from_f32(y1);
-      } else {
-        qs[v * hd + lane] = y0 * a.scale;
-        qs[v * hd + lane + half] = y1 * a.scale;
-        q16[v * hd + lane] = A::from_f32(y0);            // exact: y0 / y1 are already rounded to the activation dtype
-        q16[v * hd + lane + half] = A::from_f32(y1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool need = wave * 64 + 32 * i < cn;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const unsigned short* vr = a.vcache + ((int64_t)h * hd + (need ? 16 * t + mm : 0)) * a.T_max;
+        vf[t][i] = *(const u32x4*)(vr + (need ? min(p0 + wave * 64 + 32 * i + 8 * kb, a.T_max - 8) : p0));
       }
     }
   }
-  if (own_new && tid < hd)
-    a.vcache[((int64_t)h * a.T_max + pos) * hd + tid] = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + tid];
-  __syncthreads();
-  if (a.dbg == 1) return;
+  // padding query heads are zero (rows >= n_rep of the MFMA A operand)
+  for (int e = tid; e < 16 * HD / 2; e += 256) ((unsigned*)q16)[e] = 0u;
+  if (tid < hd) v16[tid] = vnew;
+  __syncthreads();                                    // q16 is zero before the query heads are written into it
 
-  // ---- step 2: scores s[j][p] = q_j . K[p] on the matrix cores: A = queries (row m = head, zero rows past n_rep),
-  // B = the K fragments requested at the top; D[row 4 (l >> 4) + r][col l & 15] = (head, position)
+  // ---- step 1: per-head RMSNorm (optional) + rotary embedding of the n_rep query heads (and of the new key)
   {
-    typedef typename A::vec8 vec8;
-    vec8 qa[KS];
-    const int kb = lane >> 4, mm = lane & 15;
+    // rotate_half convention, cos / sin rounded to the activation dtype like HF's rotary embedding does
+    const float c = A::to_f32(A::from_f32(rope_c)), sn = A::to_f32(A::from_f32(rope_s));
 #pragma unroll
-    for (int i = 0; i < KS; ++i) qa[i] = *(const vec8*)(q16 + mm * hd + 32 * i + 8 * kb);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < KS; ++i) dacc = A::mfma(qa[i], __builtin_bit_cast(vec8, kw[t][i]), dacc);
-      const int pp = wave * 64 + t * 16 + mm;
-      if (pp < cn) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 4 * kb + r;
-          if (j < NREP) sc[j * kChunk + pp] = dacc[r] * a.scale;
+    for (int it = 0; it < ITER; ++it) {
+      const int v = wave + 4 * it;
+      const bool isk = v == n_rep;
+      float a0 = act ? x0[it] : 0.f, a1 = act ? x1[it] : 0.f;
+      if (a.qnw) {
+        const float ss = wave_sum(a0 * a0 + a1 * a1);
+        const float r = __builtin_amdgcn_rsqf(ss / (float)hd + a.eps);
+        // HF: normalise in fp32, round to the activation dtype, then multiply by the weight
+        a0 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(a0 * r)) * w0[it]));
+        a1 = A::to_f32(A::from_f32(A::to_f32(A::from_f32(a1 * r)) * w1[it]));
+      }
+      const unsigned short y0 = A::from_f32(a0 * c - a1 * sn), y1 = A::from_f32(a1 * c + a0 * sn);
+      if (act && v <= n_rep) {
+        if (isk) {
+          if (own_new) {
+            k16[lane] = y0;
+            k16[lane + half] = y1;
+            unsigned short* kc = a.kcache + ((int64_t)h * a.T_max + pos) * hd;
+            kc[lane] = y0;
+            kc[lane + half] = y1;
+          }
+        } else {
+          q16[v * hd + lane] = y0;
+          q16[v * hd + lane + half] = y1;
         }
       }
     }
   }
+  if (own_new && tid < hd) a.vcache[((int64_t)h * hd + tid) * a.T_max + pos] = vnew;
   __syncthreads();
-  // the new token's key is not in the cache yet (it was written above by this workgroup): its column is recomputed
-  // from the LDS copy, one wave per query head
-  if (own_new) {
-    for (int j = wave; j < n_rep; j += 4) {
-      float d = 0.f;
-      for (int e = lane; e < hd; e += 64) d = __builtin_fmaf(qs[j * hd + e], knew[e], d);
+  if (a.dbg == 1) return;
+
+  // ---- step 2: scores s[j][p] = q_j . K[p] on the matrix cores: A = queries (row m = head, zero rows past n_rep),
+  // B = the K fragments requested at the top, the new token's key (not in the cache when they were requested)
+  // patched into the fragment rows of its position; D[row 4 kb + r][col mm] = (head, position 16 t + mm of the wave)
+  float sc[4][4];   // [t][r]
+  {
+    vec8 qa[KS];
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-      if (lane == 0) sc[j * kChunk + (pos - p0)] = d;
+    for (int i = 0; i < KS; ++i) qa[i] = *(const vec8*)(q16 + mm * hd + 32 * i + 8 * kb);
+    const int lp = pos - p0;                          // local position of the new token (when own_new)
+    const bool patch = own_new && wave == (lp >> 6) && mm == (lp & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (patch && t == ((lp >> 4) & 3)) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) kw[t][i] = *(const u32x4*)(k16 + 32 * i + 8 * kb);
+      }
+      f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) dacc = A::mfma(qa[i], __builtin_bit_cast(vec8, kw[t][i]), dacc);
+      const bool inb = wave * 64 + t * 16 + mm < cn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[t][r] = inb ? dacc[r] * a.scale : -3.0e38f;
     }
   }
-  __syncthreads();
   if (a.dbg == 2) return;
 
-  // ---- step 3: chunk-local soft-max statistics: m_j = max_p s, e = exp(s - m), l_j = sum e
-  for (int j = wave; j < n_rep; j += 4) {             // one wave per query head
-    float m = -3.0e38f;
-    for (int p = lane; p < cn; p += 64) m = fmaxf(m, sc[j * kChunk + p]);
+  // ---- step 3: soft-max of THIS WAVE's 64 positions, in registers: head j = 4 kb + r lives in lane row kb, its 64
+  // positions in 16 lanes x 4 tiles: m = max, e = exp(s - m), l = sum e.  (max, sum) and the unnormalised
+  // probabilities go to the wave's own LDS block; the four waves are merged at the end like chunks are.
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  for (int r = 0; r < 4; ++r) {
+    const float m = row16_max(fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r])));
     float l = 0.f;
-    for (int p = lane; p < cn; p += 64) {
-      const float e = __builtin_amdgcn_exp2f((sc[j * kChunk + p] - m) * 1.4426950408889634f);
-      sc[j * kChunk + p] = e;
-      l += e;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool inb = wave * 64 + t * 16 + mm < cn;
+      sc[t][r] = inb ? __builtin_amdgcn_exp2f((sc[t][r] - m) * kLog2e) : 0.f;
+      l += sc[t][r];
     }
+    l = row16_sum(l);
+    const int j = 4 * kb + r;
+    if (j < NREP) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) l += __shfl_xor(l, off, 64);
-    if (lane == 0) {
-      red[j * 8] = m;
-      red[j * 8 + 1] = l;
-    }
-  }
-  __syncthreads();
-  if (a.dbg == 3) return;
-
-  // ---- step 4: o_j[d] = sum_p e_j[p] V[p][d] from the rows requested at the top (probabilities past the chunk are 0)
-  {
-    float o0[NREP], o1[NREP];
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) o0[j] = o1[j] = 0.f;
-    const float* scg = sc + grp;
-#pragma unroll
-    for (int u = 0; u < VN; ++u) {
-      const int p = grp + u * GROUPS;                 // rows past the chunk -> 0, the new row -> this token's v
-      const unsigned vw = (p < cn) ? ((p0 + p) != pos ? vv[u] : vtok) : 0u;
-      const float v0 = A::to_f32(vw & 0xffffu), v1 = A::to_f32(vw >> 16);
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const float e = scg[j * kChunk + u * GROUPS];
-        o0[j] = __builtin_fmaf(e, v0, o0[j]);
-        o1[j] = __builtin_fmaf(e, v1, o1[j]);
+      for (int t = 0; t < 4; ++t) pw[(wave * NREP + j) * 64 + t * 16 + mm] = sc[t][r];
+      if (mm == 0) {
+        st[(wave * NREP + j) * 2] = m;
+        st[(wave * NREP + j) * 2 + 1] = l;
       }
     }
+  }
+  __builtin_amdgcn_wave_barrier();   // the wave reads back what its own lanes wrote (LDS is in order within a wave)
+  if (a.dbg == 3) return;
+
+  // ---- step 4: O[j][d] = sum_p e_j[p] V[p][d] over the wave's 64 positions on the matrix cores: A = probabilities
+  // (row = head, rounded to the activation dtype as HF's attn_weights.to(dtype) does), B = the V fragments requested at
+  // the top with positions past the chunk zeroed (stale cache memory times zero must not make a NaN) and the new
+  // token's value patched into its position
+  {
+    const int lp = pos - p0;
+    const bool vpatch = own_new && wave == (lp >> 6) && kb == ((lp >> 3) & 3);
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      accs[(grp * NREP + j) * hd + 2 * dq] = o0[j];
-      accs[(grp * NREP + j) * hd + 2 * dq + 1] = o1[j];
+    for (int i = 0; i < 2; ++i) {
+      // only the 32 positions that hold the chunk's end or the new token need any of this (wave-uniform test)
+      const bool pi32 = own_new && wave == (lp >> 6) && i == ((lp >> 5) & 1);
+      if (wave * 64 + 32 * i + 32 <= cn && !pi32) continue;
+      const int nv = cn - (wave * 64 + 32 * i + 8 * kb);          // valid positions among this lane's eight
+      unsigned mk[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mk[c] = nv >= 2 * c + 2 ? 0xffffffffu : (nv == 2 * c + 1 ? 0x0000ffffu : 0u);
+      const bool pi = vpatch && i == ((lp >> 5) & 1);
+      // the new token's value replaces one 16-bit slot of one word: keep-mask / insert-shift per word, computed once
+      unsigned keep[4], sh[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool hit = pi && c == ((lp >> 1) & 3);
+        keep[c] = hit ? ((lp & 1) ? 0x0000ffffu : 0xffff0000u) : 0xffffffffu;
+        sh[c] = hit ? ((lp & 1) ? 16u : 0u) : 32u;            // 32: nothing inserted
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const unsigned nv16 = v16[16 * t + mm];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vf[t][i][c] = (vf[t][i][c] & mk[c] & keep[c]) | (sh[c] < 32u ? nv16 << sh[c] : 0u);
+      }
+    }
+    vec8 pa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (mm < NREP) {
+        const f32x4 e0 = *(const f32x4*)(pw + (wave * NREP + mm) * 64 + 32 * i + 8 * kb);
+        const f32x4 e1 = *(const f32x4*)(pw + (wave * NREP + mm) * 64 + 32 * i + 8 * kb + 4);
+        w[0] = (unsigned)A::from_f32(e0[0]) | ((unsigned)A::from_f32(e0[1]) << 16);
+        w[1] = (unsigned)A::from_f32(e0[2]) | ((unsigned)A::from_f32(e0[3]) << 16);
+        w[2] = (unsigned)A::from_f32(e1[0]) | ((unsigned)A::from_f32(e1[1]) << 16);
+        w[3] = (unsigned)A::from_f32(e1[2]) | ((unsigned)A::from_f32(e1[3]) << 16);
+      }
+      pa[i] = __builtin_bit_cast(vec8, w);
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) o = A::mfma(pa[i], __builtin_bit_cast(vec8, vf[t][i]), o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * kb + r;
+        if (j < NREP) accs[(wave * NREP + j) * hd + 16 * t + mm] = o[r];
+      }
     }
   }
+  if (a.dbg == 4) return;
   __syncthreads();
+  // ---- the four waves' (max, sum, partial output) -> the chunk's: M = max m_w, num = sum 2^(m_w - M) o_w, den likewise
+  auto chunk_value = [&](int j, int d, float& M, float& den) {
+    M = fmaxf(fmaxf(st[(0 * NREP + j) * 2], st[(1 * NREP + j) * 2]), fmaxf(st[(2 * NREP + j) * 2], st[(3 * NREP + j) * 2]));
+    float num = 0.f;
+    den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __builtin_amdgcn_exp2f((st[(w * NREP + j) * 2] - M) * kLog2e);
+      den = __builtin_fmaf(f, st[(w * NREP + j) * 2 + 1], den);
+      num = __builtin_fmaf(f, accs[(w * NREP + j) * hd + d], num);
+    }
+    return num;
+  };
   if (n_act == 1) {
     // the only chunk: normalise and write the output
     for (int e = tid; e < n_rep * hd; e += 256) {
       const int j = e / hd, d = e % hd;
-      float v = 0.f;
-#pragma unroll
-      for (int g = 0; g < GROUPS; ++g) v += accs[(g * NREP + j) * hd + d];
-      a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(v / red[j * 8 + 1]);
+      float M, den;
+      const float num = chunk_value(j, d, M, den);
+      a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(num / den);
     }
     return;
   }
@@ -241,14 +337,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   float* mine = a.part + (((int64_t)h * a.chunks + s) * n_rep) * (hd + 2);
   for (int e = tid; e < n_rep * hd; e += 256) {
     const int j = e / hd, d = e % hd;
-    float v = 0.f;
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) v += accs[(g * NREP + j) * hd + d];
-    mine[j * (hd + 2) + d] = v;
-  }
-  if (tid < n_rep) {
-    mine[tid * (hd + 2) + hd] = red[tid * 8];
-    mine[tid * (hd + 2) + hd + 1] = red[tid * 8 + 1];
+    float M, den;
+    mine[j * (hd + 2) + d] = chunk_value(j, d, M, den);
+    if (d == 0) {
+      mine[j * (hd + 2) + hd] = M;
+      mine[j * (hd + 2) + hd + 1] = den;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -300,7 +394,8 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
   if (head_dim != 64 && head_dim != 128) return fail(PARO_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
   if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return fail(PARO_ERR_INVALID, "q / k norm weights come together");
   const int64_t need = paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions);
-  if (max_positions < 1 || max_positions > 65535 * kChunk) return fail(PARO_ERR_INVALID, "max_positions out of range");
+  if (max_positions < 8 || max_positions % 8 != 0 || max_positions > 65535 * kChunk)
+    return fail(PARO_ERR_INVALID, "max_positions must be a multiple of 8 in 8..%d (got %d)", 65535 * kChunk, max_positions);
   if (!workspace || workspace_bytes < need)
     return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;

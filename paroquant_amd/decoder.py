@@ -99,7 +99,8 @@ class ParoDecoderLM:
     def _alloc_cache(self, layer: _Layer):
         c = self.cfg
         layer.kcache = torch.zeros(c.n_kv_heads, c.max_positions, c.head_dim, dtype=self.dtype, device=self.device)
-        layer.vcache = torch.zeros_like(layer.kcache)
+        # V is kept position-contiguous ([head][dim][position]): the attention kernel's P V product reads it as MFMA fragments
+        layer.vcache = torch.zeros(c.n_kv_heads, c.head_dim, c.max_positions, dtype=self.dtype, device=self.device)
 
     @classmethod
     def random(cls, name_or_cfg, device, n_layers: Optional[int] = None, max_positions: int = 1024, seed: int = 0,
@@ -283,7 +284,7 @@ class ParoDecoderLM:
             k = rope(headnorm(k.view(T, c.n_kv_heads, c.head_dim), L.k_norm))
             v = v.view(T, c.n_kv_heads, c.head_dim)
             L.kcache[:, :T] = k.transpose(0, 1)
-            L.vcache[:, :T] = v.transpose(0, 1)
+            L.vcache[:, :, :T] = v.permute(1, 2, 0)
             att = torch.nn.functional.scaled_dot_product_attention(
                 q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None], is_causal=True,
                 enable_gqa=c.n_heads != c.n_kv_heads)[0].transpose(0, 1).reshape(T, -1)

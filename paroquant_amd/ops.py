@@ -356,7 +356,9 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
                 n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
                 out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decoder layer's batch-1 attention in one launch (``paro_attn_decode``): q/k norm + RoPE + KV-cache append at
-    ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache`` / ``vcache``: [n_kv_heads, T_max, head_dim]."""
+    ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache``: [n_kv_heads, T_max, head_dim];
+    ``vcache``: [n_kv_heads, head_dim, T_max] (position-contiguous); T_max a multiple of 8; both must hold finite values
+    (allocate them zero-filled)."""
     lib = nat.load()
     T_max = kcache.size(1)
     y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)

@@ -1031,14 +1031,16 @@ def test_attn_decode_matches_oracle(dev, hd, Hq, Hkv, qk_norm, pos):
     kw = (1 + 0.2 * rng.standard_normal(hd)).astype(np.float16) if qk_norm else None
     cos, sin = po.rope_tables(hd, T, 1e4)
     rope = torch.from_numpy(np.concatenate([cos, sin], axis=-1).astype(np.float32)).to(dev)
-    kct, vct = _t(kc, dev), _t(vc, dev)
+    kct, vct = _t(kc, dev), _t(np.ascontiguousarray(vc.transpose(0, 2, 1)), dev)     # V cache: [head][dim][position]
     out = ops.attn_decode(_t(qkv, dev), kct, vct, torch.tensor([pos], dtype=torch.int32, device=dev), rope, Hq, Hkv, hd,
                           None if qw is None else _t(qw, dev), None if kw is None else _t(kw, dev), 1e-6)
     ref, k_new, v_new = po.attention_decode(qkv, kc, vc, pos, Hq, Hkv, hd, cos, sin, qw, kw, 1e-6)
     assert po.rel_err(_np(out), ref) < 4e-3
-    assert po.rel_err(_np(kct[:, pos]), k_new) < 2e-3 and po.rel_err(_np(vct[:, pos]), v_new) < 1e-6
+    assert po.rel_err(_np(kct[:, pos]), k_new) < 2e-3 and po.rel_err(_np(vct[:, :, pos]), v_new) < 1e-6
     if pos > 0:   # the rest of the cache is untouched
-        assert torch.equal(kct[:, :pos], _t(kc, dev)[:, :pos]) and torch.equal(vct[:, pos + 1:], _t(vc, dev)[:, pos + 1:])
+        vt = _t(np.ascontiguousarray(vc.transpose(0, 2, 1)), dev)
+        assert torch.equal(kct[:, :pos], _t(kc, dev)[:, :pos]) and torch.equal(vct[:, :, pos + 1:], vt[:, :, pos + 1:]) \
+            and torch.equal(vct[:, :, :pos], vt[:, :, :pos])
 
 
 # ---------------------------------------------------------------- f2: the decode harness against HF on the same checkpoint

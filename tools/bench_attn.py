@@ -14,7 +14,7 @@ ap.add_argument("--layers", type=int, default=36)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 H, KV, hd, T = a.heads, a.kv, a.hd, a.tmax
-caches = [(torch.randn(KV, T, hd, device=dev).half(), torch.randn(KV, T, hd, device=dev).half()) for _ in range(a.layers)]
+caches = [(torch.randn(KV, T, hd, device=dev).half(), torch.randn(KV, hd, T, device=dev).half()) for _ in range(a.layers)]
 qkv = torch.randn((H + 2 * KV) * hd, device=dev).half()
 half = hd // 2
 inv = 1.0 / (1e6 ** (torch.arange(half, device=dev).float() * 2 / hd))
