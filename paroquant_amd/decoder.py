@@ -48,6 +48,10 @@ class DecoderConfig:
     qk_norm: bool = False          # Qwen3: per-head RMSNorm on q and k before RoPE
     max_positions: int = 2048
 
+    def __post_init__(self):
+        # the attention kernel reads the position-contiguous V cache 8 positions (16 bytes) at a time
+        self.max_positions = (int(self.max_positions) + 7) // 8 * 8
+
     @classmethod
     def from_hf(cls, c: dict, max_positions: int = 2048) -> "DecoderConfig":
         c = c.get("text_config", c)
