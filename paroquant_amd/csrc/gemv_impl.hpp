@@ -712,24 +712,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
       // partial in registers, poll the other splits' granules until their tags appear (bounded),
       // re-arm them to zero for the next launch, write y once.
-      for (int s = 0; s < h.ksplit - 1; ++s) {
-        unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
-        unsigned long long gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
-          __builtin_amdgcn_s_sleep(2);
-          gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // The first poll of EVERY split is issued before any of them is looked at (up to 4 per batch): a poll is a
+      // ~0.6 us round trip to the coherence point, and one after the other they were most of the hand-off's cost.
+      const int nsp = h.ksplit - 1;
+      for (int s0 = 0; s0 < nsp; s0 += 4) {
+        unsigned long long gq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int s = min(s0 + q, nsp - 1);   // clamped duplicate beyond the last split (never consumed)
+          gq[q] = __hip_atomic_load(a.slabs + ((int64_t)s * h.rows + b) * h.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if ((gv >> 32) != 1ull) {
-          // give-up: never a silent wrong sum -- the output becomes NaN and the sticky status word of the
-          // workspace is set (paro_workspace_status / ops.check_workspace); the granule is NOT re-armed, so
-          // a producer that arrives late cannot be mistaken for the next launch's partial without the
-          // status word already saying so.  Unreachable while every workgroup of the launch is resident
-          // (checked on the host before a K-split launch).
-          a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
-          v = __builtin_nanf("");
-        } else {
-          v += __builtin_bit_cast(float, (unsigned)gv);
-          __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int s = s0 + q;
+          if (s >= nsp) break;
+          unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
+          unsigned long long gv = gq[q];
+          for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
+            __builtin_amdgcn_s_sleep(2);
+            gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if ((gv >> 32) != 1ull) {
+            // give-up: never a silent wrong sum -- the output becomes NaN and the sticky status word of the
+            // workspace is set (paro_workspace_status / ops.check_workspace); the granule is NOT re-armed, so
+            // a producer that arrives late cannot be mistaken for the next launch's partial without the
+            // status word already saying so.  Unreachable while every workgroup of the launch is resident
+            // (checked on the host before a K-split launch).
+            a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
+            v = __builtin_nanf("");
+          } else {
+            v += __builtin_bit_cast(float, (unsigned)gv);
+            __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       if (a.bias) v += A::to_f32(a.bias[col]);
