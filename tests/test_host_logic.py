@@ -226,7 +226,7 @@ def test_gemv_launch_shape_heuristics():
     by_model = {m: {n: (K, s) for n, K, s, _ in bench.layer_shapes(m)} for m in ("llama3-8b", "qwen3-4b", "llama3-70b")}
     l8, q4, l70 = by_model["llama3-8b"], by_model["qwen3-4b"], by_model["llama3-70b"]
     # batch 1: (tiles per wave, K-split, waves per workgroup, mode 0 = fused rotation)
-    assert shape(*l8["qkv_proj"], 1) == (2, 1, 16, 0)
+    assert shape(*l8["qkv_proj"], 1) == (4, 2, 8, 0)      # mid-width, K = 4096: 96 column blocks x 2 K-splits
     assert shape(*l8["o_proj"], 1) == (4, 4, 4, 0)
     assert shape(*l8["gate_up_proj"], 1) == (8, 1, 8, 0)
     assert shape(*l8["down_proj"], 1) == (4, 4, 8, 0)
