@@ -30,6 +30,19 @@ int main() {
       for (int i = 0; i < 20; ++i) k<<<256, 1024, 0, st>>>(d, d + 1, d + 2, d + 3, 1, 2, 3, 4, 5, 6, out);
       hipStreamEndCapture(st, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
       hipGraphLaunch(ge, st); hipGraphLaunch(ge, st);
+      // the dependent-launch boundary with / without preload: 200 back-to-back (tiny) kernels per replay
+      hipGraph_t g2; hipGraphExec_t ge2;
+      hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+      for (int i = 0; i < 200; ++i) k<<<256, 1024, 0, st>>>(d, d + 1, d + 2, d + 3, 1, 2, 3, 4, 5, 6, out);
+      hipStreamEndCapture(st, &g2); hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
+      hipGraphLaunch(ge2, st); hipStreamSynchronize(st);
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e9f;
+      for (int r = 0; r < 5; ++r) {
+        hipEventRecord(e0, st); hipGraphLaunch(ge2, st); hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+      }
+      printf("{\"probe\": \"launch_spacing\", \"build\": \"%s\", \"us_per_launch\": %.3f}\n", PRELOAD ? "preload" : "s_load", best * 1000.f / 200.f);
     }
     hipStreamSynchronize(st);
     std::vector<unsigned long long> h(256 * 16 * 2);
