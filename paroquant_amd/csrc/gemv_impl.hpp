@@ -26,8 +26,12 @@
 //     reduce through LDS; by default one workgroup covers ALL of K, so no cross-workgroup
 //     reduction exists.  An optional K-split (grid.y) is combined in-launch with data-tagged
 //     granules: the first ksplit-1 splits write {tag, partial} 8-byte granules with ONE
-//     write-through (sc1) store per output and exit; the last split polls them (sc1 loads, bounded
-//     spin), re-arms them, and writes y exactly once -- no fences, no tickets, one round trip.
+//     write-through (sc1) store per output and exit; the last split polls them (sc1 loads, the first poll of
+//     every split issued before any is examined; bounded spin), re-arms them, and writes y exactly once --
+//     no fences, no tickets, one round trip.
+//   * kernel start: the arguments a wave needs before its first loads are a hand-packed 128-byte block at kernarg
+//     offset 0 (GemvHot) fetched with two s_load_dwordx16 + one wait, the partition lookup is a dozen scalar
+//     instructions (s_addc chain + s_movrels); see the note at GemvHot.
 #pragma once
 #include <cstddef>
 #include <type_traits>
@@ -249,13 +253,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     return t;
   };
 
-  // Partition lookup with compile-time kernarg offsets only (select chain, no data-dependent s_load):
-  // the whole argument block is then fetched in ONE batch of scalar loads instead of six dependent
-  // round trips (measured: 2300 cycles from workgroup start to the first global load before this).
   // The FIRST thing a wave requests is its first unit's coefficients (exchange schedule, channel scales, x): they need
-  // only the partition index and the wave's first group, so those are computed -- and the requests issued -- before
-  // the tile bookkeeping below (the scalar prologues of the waves that share a SIMD run one after the other: every
-  // scalar instruction in front of the first request delays the later waves' requests several times over).
+  // only the partition index (from the lookup above) and the wave's first group, so the requests are issued before the
+  // tile bookkeeping below (all waves of a CU share ONE scalar unit: every scalar instruction in front of the first
+  // request delays the later waves' requests several times over).
   const int g_begin = ks * h.gps;
   const int g_end = min(h.G, g_begin + h.gps);
   const int n_local = g_end - g_begin;
