@@ -237,9 +237,27 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
         if len(times) >= 3 and (time.perf_counter() - t_start > budget_s or len(times) >= 20):
             break
     t_layer = float(np.median(times))
-    return {"value": round(1.0 / (t_layer * L), 4), "unit": "tokens/s", "cores": pc.threads(), "kind": "port",
-            "sample": f"1 of {L} decoder layers (4 fused linears, M=1) x {len(times)} runs, median {t_layer * 1e3:.1f} ms/layer; "
-                      f"tokens/s = 1 / (ms_per_layer * {L})"}
+    out = {"value": round(1.0 / (t_layer * L), 4), "unit": "tokens/s", "cores": pc.threads(), "kind": "port",
+           "sample": f"1 of {L} decoder layers (4 fused linears, M=1) x {len(times)} runs, median {t_layer * 1e3:.1f} ms/layer; "
+                     f"tokens/s = 1 / (ms_per_layer * {L})"}
+    # BASELINE config 0 ("single ParoLinear layer 4096 x 4096, group 128, CPU dequant + matmul path"): the same one
+    # layer as torch-CPU dequant -> fp32 matmul (what AutoAWQ's WQLinearMMFunction does off-GPU), M = 1, for context
+    try:
+        K = N = 4096
+        qw = torch.from_numpy(rng.integers(0, 16, size=(K, N), dtype=np.int64).astype(np.float32))
+        qz = torch.from_numpy(rng.integers(0, 16, size=(K // 128, N), dtype=np.int64).astype(np.float32))
+        sc = torch.from_numpy(rng.uniform(0.002, 0.02, size=(K // 128, N)).astype(np.float32))
+        xr = torch.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            w = (qw - qz.repeat_interleave(128, 0)) * sc.repeat_interleave(128, 0)
+            (xr @ w).sum().item()
+            ts.append(time.perf_counter() - t0)
+        out["torch_cpu_dequant_matmul_4096x4096_ms"] = round(float(np.median(ts)) * 1e3, 2)
+    except Exception as e:   # context only: never fail the bench line over it
+        out["torch_cpu_dequant_matmul_4096x4096_ms"] = f"failed: {e}"
+    return out
 
 
 def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5, warmup: int = 2):
