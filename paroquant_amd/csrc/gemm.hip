@@ -397,12 +397,13 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
 namespace paro {
 // K-split of the v2 GEMM for small M: with one 256-row block the grid is only N / 128 workgroups (32 for
 // N = 4096), each looping over all of K (o_proj, M = 32..128: 70 us); splitting K over grid.z and summing
-// fp32 partial tiles in a second small kernel fills the chip.  Used for 17 <= rows < 512 when the grid is
-// below half of the CUs; at most 8 splits of at least 2 groups.
+// fp32 partial tiles in a second small kernel fills the chip.  Used for 17 <= rows < 4096 when the grid is at most
+// half of the CUs (narrow outputs at M = 512 / 1024 ran 64 / 128 workgroups over all of K: down_proj 230 us); at most
+// 8 splits of at least 2 groups.
 int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
-  if (L->act_dtype != PARO_DTYPE_F16 || rows <= 16 || rows >= 512) return 1;
+  if (L->act_dtype != PARO_DTYPE_F16 || rows <= 16 || rows >= 4096) return 1;
   const int64_t wgs = ((L->N + 127) / 128) * ((rows + 255) / 256);
-  if (wgs >= 128) return 1;
+  if (wgs > 128) return 1;
   const int G = (int)(L->K / 128);
   int ks = (int)(256 / wgs);
   if (ks > 8) ks = 8;
