@@ -46,13 +46,12 @@ extern "C" const char* paro_last_error(void) { return paro::error_buffer(); }
 extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   if (rows <= 16) return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, -1, stream);
-  // 17..64 rows: the GEMV kernel on pre-rotated activations with 2 / 4 MFMA row tiles per weight fragment
-  // (measured, Llama-3-8B shapes, us GEMV / K-split MFMA GEMM: M=32 qkv 20 / 32, o 19 / 27, gate_up 37 / 74,
-  // down 28 / 45; M=64 qkv 30 / 35, o 22 / 30, down 45 / 47, but gate_up 85 / 76: with four row tiles only
-  // two column tiles fit a wave, and every workgroup re-reads all of x_rot -- wide outputs above 32 rows stay
-  // on the GEMM).  PARO_SKINNY=0 routes everything above 16 rows to the GEMM (A/B runs).
+  // 17..32 rows: the GEMV kernel on pre-rotated activations with 2 MFMA row tiles per weight fragment (measured,
+  // Llama-3-8B shapes at 24 rows, us GEMV / MFMA GEMM: qkv 25 / 30, o 24 / 26, gate_up 31 / 68, down 24 / 45); from 33
+  // rows on the GEMM's 64- / 128-row blocks with a K-split are ahead on every shape (48 rows: gate_up 33 vs 70, down 29
+  // vs 36, qkv 27 vs 27).  PARO_SKINNY=0 routes everything above 16 rows to the GEMM (A/B runs).
   static const int skinny = getenv("PARO_SKINNY") ? atoi(getenv("PARO_SKINNY")) : 1;
-  if (skinny && rows <= 64 && L && !(rows > 32 && L->N / 16 >= 1024))   // fp16 and bf16 alike
+  if (skinny && rows <= 32 && L)   // fp16 and bf16 alike
     return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 1, stream);
   return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, PARO_GEMM_AUTO, stream);
 }

@@ -139,24 +139,27 @@ struct Dequant<bf16> {
   }
 };
 
-constexpr int BM3 = 256;
 
 // DIAG (energy / issue ablation on the power-limited chip, tools/bench_gemm.py --variants 41,42,43; wrong results):
 // 1 = no dequant (raw INT4 words as the weight operand), 2 = no fragment re-reads inside a group (the first
 // k-step's fragments are reused), 3 = both.  0 = the shipping kernel.
 // QS: quantisation groups per 128-channel slab (1: group_size 128; 2: group_size 64 -- k-steps 0..3 and 4..7 of a
 // slab are dequantised with different (scale, zero) words).
-template <typename AT, int DIAG = 0, int QS = 1>
+// RT: 32-row tiles of the workgroup's row block (8 = 256 rows, the prefill shape; 1 / 2 / 4 = 32 / 64 / 128 rows for
+// batched decode and short prefill, where a 256-row block would stage and multiply mostly padding).  With a K-split
+// (grid.z) the fp32 tile goes to `partial` and gemm_reduce_kernel sums the splits.
+template <typename AT, int DIAG = 0, int QS = 1, int RT = 8>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM3 * 256];
+  constexpr int BMR = RT * 32;                 // rows of the workgroup's block
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BMR * 256];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x;
-  const int row0 = blockIdx.y * BM3;
+  const int row0 = blockIdx.y * BMR;
 
   const int p = a.pt.part_of_cb(cb);
   const int ltile0 = (cb - a.pt.cb_start[p]) * 16 + wave * 2;   // the wave's two 16-column tiles
@@ -177,10 +180,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   // --- activation staging: wave w fills LDS rows 32 w .. 32 w + 31 (8 LDS-DMA pieces of 4 rows).  Lane l lands on
   // (row = 4 c + l / 16, physical slot l % 16) and therefore FETCHES logical slot phys ^ (row & 15).
   const int srow_in = lane >> 4, sphys = lane & 15;
-  const unsigned short* asrc[8];
+  const unsigned short* asrc[RT];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int row = (wave * 8 + c) * 4 + srow_in;
+  for (int c = 0; c < RT; ++c) {
+    const int row = (wave * RT + c) * 4 + srow_in;
     const int grow = min(row0 + row, a.rows - 1);   // tail rows re-read the last valid row (never stored)
     asrc[c] = xp + (int64_t)grow * a.K + ((sphys ^ (row & 15)) << 3);
   }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) unsigned char*)lds);
   auto issue_a_piece = [&](int c, int g, int buf) {
     const unsigned short* src = asrc[c] + g * 128;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * (BM3 * 256) + (wave * 8 + c) * 1024));
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * (BMR * 256) + (wave * RT + c) * 1024));
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     for (int hq = 0; hq < QS; ++hq) szn[hq] = szp[(int64_t)(g * QS + hq) * szrow];
   };
 
-  f32x16 acc[8];
+  f32x16 acc[RT];
 #pragma unroll
-  for (int rt = 0; rt < 8; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int ks = blockIdx.z;
   const int g0 = ks * a.gps, g1 = min(a.G, g0 + a.gps);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) issue_a_piece(c, g0, 0);
+  for (int c = 0; c < RT; ++c) issue_a_piece(c, g0, 0);
   load_b(g0);
   // one quantisation group; MORE = another group follows (its slab and weights are requested here).  The last
   // group is a second instantiation of the body, so that nothing in the loop is conditional.
@@ -251,17 +254,23 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     __syncthreads();                                   // ... and so have everyone else's; all have left the other buffer
     const int nbuf = (g + 1 - g0) & 1;
     if constexpr (MORE) load_b(g + 1);
-    const unsigned char* abuf = lds + ((g - g0) & 1) * (BM3 * 256);
-    vec8 af[8];
+    const unsigned char* abuf = lds + ((g - g0) & 1) * (BMR * 256);
+    vec8 af[RT];
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) af[rt] = *(const vec8*)(abuf + a0 + rt * 8192);
+    for (int rt = 0; rt < RT; ++rt) af[rt] = *(const vec8*)(abuf + a0 + rt * 8192);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const vec8 wf = __builtin_bit_cast(vec8, bcur);
+      // eight slots per k-step: slot k carries the MFMA of row tile k (when there is one) and part k of the NEXT
+      // k-step's dequant (always: the word has eight parts whatever the number of row tiles)
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
-        acc[rt] = Mma32<AT>::run(wf, af[rt], acc[rt]);
+        if constexpr (RT == 8) {
+          acc[rt] = Mma32<AT>::run(wf, af[rt], acc[rt]);
+        } else {
+          if (rt < RT) acc[rt] = Mma32<AT>::run(wf, af[rt < RT ? rt : 0], acc[rt < RT ? rt : 0]);
+        }
         if (s < 7) {
           if constexpr (DIAG == 1 || DIAG == 3) {
             if (rt == 0) d.out = (u32x4){word(s + 1), qc0[s & 3], qc1[s & 3], qc0[(s + 1) & 3]};
@@ -273,14 +282,20 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
             }
             d.part(rt, word(s + 1));
           }
-          if constexpr (DIAG != 2 && DIAG != 3)
-            af[rt] = *(const vec8*)(abuf + (a0 ^ (unsigned)((s + 1) << 5)) + rt * 8192);
+          if constexpr (DIAG != 2 && DIAG != 3) {
+            if (rt < RT) af[rt < RT ? rt : 0] = *(const vec8*)(abuf + (a0 ^ (unsigned)((s + 1) << 5)) + (rt < RT ? rt : 0) * 8192);
+          }
         }
-        // the next slab's eight DMA pieces go out during the first four k-steps (two per step), so that the
-        // vmcnt drain in front of the next group's first weight use finds them long landed
+        // the next slab's DMA pieces go out early in the group (RT = 8: two per k-step over the first four k-steps;
+        // fewer row tiles: one per k-step), so that the vmcnt drain in front of the next group's first weight use
+        // finds them long landed
         if constexpr (MORE) {
-          if (s < 4 && rt == 1) issue_a_piece(2 * s, g + 1, nbuf);
-          if (s < 4 && rt == 5) issue_a_piece(2 * s + 1, g + 1, nbuf);
+          if constexpr (RT == 8) {
+            if (s < 4 && rt == 1) issue_a_piece(2 * s, g + 1, nbuf);
+            if (s < 4 && rt == 5) issue_a_piece(2 * s + 1, g + 1, nbuf);
+          } else {
+            if (s < RT && rt == 1) issue_a_piece(s < RT ? s : 0, g + 1, nbuf);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -302,9 +317,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       for (int e = 0; e < 4; ++e) bv[e] = A::to_f32(a.bias[col + e]);
     }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = row0 + rt * 32 + n32;
       if (row >= a.rows) continue;
+      if (a.ksplit > 1) {   // K-split: the fp32 tile of this split, summed (+ bias) by gemm_reduce_kernel
+        const f32x4 pv = {acc[rt][4 * q + 0], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]};
+        *(f32x4*)(a.partial + ((int64_t)ks * a.rows + row) * a.N + col) = pv;
+        continue;
+      }
       u32x2 o;
       o[0] = (unsigned)A::from_f32(acc[rt][4 * q + 0] + bv[0]) | ((unsigned)A::from_f32(acc[rt][4 * q + 1] + bv[1]) << 16);
       o[1] = (unsigned)A::from_f32(acc[rt][4 * q + 2] + bv[2]) | ((unsigned)A::from_f32(acc[rt][4 * q + 3] + bv[3]) << 16);
@@ -313,25 +333,35 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   }
 }
 
-int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs) {
-  if (qs == 2) {
-    if (diag != 0) return fail(PARO_ERR_UNSUPPORTED, "the ablation builds of GEMM variant 4 exist for group_size 128 only");
-    if (act_dtype == PARO_DTYPE_F16)
-      hipLaunchKernelGGL((gemm3_kernel<f16, 0, 2>), grid, dim3(512), 0, st, a);
+template <typename AT, int QS>
+static void launch_gemm3_rt(const GemmArgs& a, dim3 grid, hipStream_t st, int rt) {
+  if (rt == 2)
+    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 2>), grid, dim3(512), 0, st, a);
+  else if (rt == 4)
+    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 4>), grid, dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 8>), grid, dim3(512), 0, st, a);
+}
+
+// rt: 32-row tiles per row block (2 / 4 / 8 -- grid.y counts blocks of 32 rt rows)
+int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs, int rt) {
+  if (rt != 2 && rt != 4 && rt != 8) return fail(PARO_ERR_INVALID, "GEMM variant 4 is built for 2 / 4 / 8 row tiles (got %d)", rt);
+  if (diag != 0) {
+    if (qs == 2 || rt != 8 || act_dtype != PARO_DTYPE_F16 || a.ksplit > 1)
+      return fail(PARO_ERR_UNSUPPORTED, "the ablation builds of GEMM variant 4 exist for fp16, group_size 128, 256-row blocks, no K-split only");
+    if (diag == 1)
+      hipLaunchKernelGGL((gemm3_kernel<f16, 1>), grid, dim3(512), 0, st, a);
+    else if (diag == 2)
+      hipLaunchKernelGGL((gemm3_kernel<f16, 2>), grid, dim3(512), 0, st, a);
     else
-      hipLaunchKernelGGL((gemm3_kernel<bf16, 0, 2>), grid, dim3(512), 0, st, a);
+      hipLaunchKernelGGL((gemm3_kernel<f16, 3>), grid, dim3(512), 0, st, a);
     return PARO_OK;
   }
-  if (diag == 1 && act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL((gemm3_kernel<f16, 1>), grid, dim3(512), 0, st, a);
-  else if (diag == 2 && act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL((gemm3_kernel<f16, 2>), grid, dim3(512), 0, st, a);
-  else if (diag == 3 && act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL((gemm3_kernel<f16, 3>), grid, dim3(512), 0, st, a);
-  else if (act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL((gemm3_kernel<f16, 0>), grid, dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((gemm3_kernel<bf16, 0>), grid, dim3(512), 0, st, a);
+  if (act_dtype == PARO_DTYPE_F16) {
+    if (qs == 2) launch_gemm3_rt<f16, 2>(a, grid, st, rt); else launch_gemm3_rt<f16, 1>(a, grid, st, rt);
+  } else {
+    if (qs == 2) launch_gemm3_rt<bf16, 2>(a, grid, st, rt); else launch_gemm3_rt<bf16, 1>(a, grid, st, rt);
+  }
   return PARO_OK;
 }
 

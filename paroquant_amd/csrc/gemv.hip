@@ -6,6 +6,7 @@
 namespace paro {
 
 int gemm_ksplit(const paro_linear_t* L, int64_t rows);   // gemm.hip
+int gemm4_ksplit(const paro_linear_t* L, int64_t rows);  // gemm.hip
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
                   int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 
@@ -171,7 +172,8 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
     slabs = (int64_t)(ks > 1 ? ks : 1) * r * L->N * 8;
     if (slabs < (int64_t)kMaxKsplit * 16 * L->N * 8) slabs = (int64_t)kMaxKsplit * 16 * L->N * 8;   // two 16-row passes
   }
-  const int gks = gemm_ksplit(L, r);                                      // fp32 partial tiles of the small-M GEMM
+  int gks = gemm_ksplit(L, r);                                            // fp32 partial tiles of the small-M GEMM
+  if (gemm4_ksplit(L, r) > gks) gks = gemm4_ksplit(L, r);                  // (either kernel may be the one that runs)
   const int64_t partial = gks > 1 ? 256 + (int64_t)gks * r * L->N * 4 : 0;
   return PARO_WS_COUNTER_BYTES + slabs + xrot + partial;
 }

@@ -511,6 +511,33 @@ def test_gemm_variants_forced(dev, variant, K, sizes, rows):
     assert po.rel_err(_np(y), ref) < REL_TOL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gs", [128, 64])
+@pytest.mark.parametrize("K,sizes,rows", [
+    (2048, [512, 272], 33), (2048, [512, 272], 64),       # 64-row blocks, K-split 8 (ragged last column block)
+    (1024, [1024, 256, 256], 65), (1024, [1024, 256, 256], 128), (4096, [768], 100),   # 128-row blocks, K-split
+    (512, [8192, 8192], 48),                              # wide output: no K-split (64 column blocks already)
+    (4096, [48], 40),                                     # a single partial column block
+])
+def test_gemm_row_tile_blocks(dev, gs, K, sizes, rows):
+    """33..128 rows run GEMM variant 4 with 64- / 128-row blocks and (narrow outputs) an fp32 K-split summed by a second
+    kernel: the automatic route and the forced variant agree with the oracle, fp16 and bf16, group_size 128 and 64."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + rows + gs, K, sizes, group_size=gs, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+    ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"], sizes,
+                                  L["bias"], group_size=gs, ideal=True)
+    y_auto = pk.apply(_t(x, dev))
+    y_v4 = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=4)
+    assert np.isfinite(_np(y_auto)).all() and torch.equal(y_auto, y_v4)          # the automatic route IS variant 4 here
+    assert po.rel_err(_np(y_auto), ideal) < TIGHT_F16
+    yb = pk.apply(_t(x, dev).to(torch.bfloat16), pk.bias.to(torch.bfloat16))
+    assert po.rel_err(_np(yb), ideal) < 2e-2
+    y1 = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=1)              # an independent kernel on the same inputs
+    assert po.rel_err(_np(y_auto), _np(y1).astype(np.float64)) < TIGHT_F16
+
+
 @pytest.mark.parametrize("variant", [1, 4])
 @pytest.mark.parametrize("K,sizes,rows", [(1024, [512, 272], 300), (256, [4096], 512)])
 def test_gemm_bf16_native(dev, variant, K, sizes, rows):
