@@ -413,7 +413,7 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
 }
 // Variant 4 below 256 rows (batched decode / short prefill): row tiles of the block, and a K-split that brings the grid
 // of 256-column blocks up to about one workgroup per CU.
-int gemm4_row_tiles(int64_t rows) { return rows <= 64 ? 2 : (rows <= 128 ? 4 : 8); }
+int gemm4_row_tiles(int64_t rows) { return rows <= 64 ? 2 : (rows >= 225 ? 8 : (int)((rows + 31) / 32)); }
 int gemm4_ksplit(const paro_linear_t* L, int64_t rows) {
   if (rows <= 16 || rows >= 4096) return 1;
   const int rt = gemm4_row_tiles(rows);
@@ -448,7 +448,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   const bool f16in = L->act_dtype == PARO_DTYPE_F16;
   if ((variant == 2 || variant == 3) && !f16in)
     return fail(PARO_ERR_UNSUPPORTED, "GEMM variants 2 and 3 are fp16-only; bf16 runs variant 1 or 4");
-  // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) for 33..128 rows (64- / 128-row
+  // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) for 33..192 rows (64- .. 192-row
   // blocks) and when there are >= 256 rows and enough 256 x 256 tiles to cover the CUs; fp16 below that -> 256 x 128 tile with a K-split at small M;
   // bf16 below that -> the 128 x 128 kernel.
   const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
@@ -457,10 +457,10 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     return fail(PARO_ERR_UNSUPPORTED, "group_size 64 runs GEMM variant 1 or 4 (variants 2 and 3 are built for group_size 128)");
   int v = variant;
   if (v == PARO_GEMM_AUTO) {
-    // 33..128 rows (batched decode, short prefill): variant 4 with 64- / 128-row blocks and a K-split -- 256-column
+    // 33..192 rows (batched decode, short prefill): variant 4 with 64- .. 192-row blocks (32-row steps) and a K-split -- 256-column
     // blocks halve the re-reads of the activation tile, no padding rows are staged or multiplied (Llama-3-8B gate_up
     // 64 rows: 67 -> 34 us, down 42 -> 30, qkv 128 rows: 42 -> 31)
-    if (rows >= 33 && rows <= 128) v = 4;
+    if (rows >= 33 && rows <= 192) v = 4;
     else if (rows >= 256 && wide_wgs >= 192) v = 4;
     else if (f16in && rows > 16 && qs == 1) v = 2;
     else v = 1;

@@ -335,17 +335,20 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
 
 template <typename AT, int QS>
 static void launch_gemm3_rt(const GemmArgs& a, dim3 grid, hipStream_t st, int rt) {
-  if (rt == 2)
-    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 2>), grid, dim3(512), 0, st, a);
-  else if (rt == 4)
-    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 4>), grid, dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 8>), grid, dim3(512), 0, st, a);
+  switch (rt) {
+    case 2: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 2>), grid, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 3>), grid, dim3(512), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 4>), grid, dim3(512), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 5>), grid, dim3(512), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 6>), grid, dim3(512), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 7>), grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm3_kernel<AT, 0, QS, 8>), grid, dim3(512), 0, st, a); break;
+  }
 }
 
-// rt: 32-row tiles per row block (2 / 4 / 8 -- grid.y counts blocks of 32 rt rows)
+// rt: 32-row tiles per row block (2..8 -- grid.y counts blocks of 32 rt rows)
 int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs, int rt) {
-  if (rt != 2 && rt != 4 && rt != 8) return fail(PARO_ERR_INVALID, "GEMM variant 4 is built for 2 / 4 / 8 row tiles (got %d)", rt);
+  if (rt < 2 || rt > 8) return fail(PARO_ERR_INVALID, "GEMM variant 4 is built for 2..8 row tiles (got %d)", rt);
   if (diag != 0) {
     if (qs == 2 || rt != 8 || act_dtype != PARO_DTYPE_F16 || a.ksplit > 1)
       return fail(PARO_ERR_UNSUPPORTED, "the ablation builds of GEMM variant 4 exist for fp16, group_size 128, 256-row blocks, no K-split only");

@@ -515,12 +515,13 @@ def test_gemm_variants_forced(dev, variant, K, sizes, rows):
 @pytest.mark.parametrize("gs", [128, 64])
 @pytest.mark.parametrize("K,sizes,rows", [
     (2048, [512, 272], 33), (2048, [512, 272], 64),       # 64-row blocks, K-split 8 (ragged last column block)
-    (1024, [1024, 256, 256], 65), (1024, [1024, 256, 256], 128), (4096, [768], 100),   # 128-row blocks, K-split
+    (1024, [1024, 256, 256], 65), (1024, [1024, 256, 256], 128), (4096, [768], 100),   # 96- / 128-row blocks, K-split
+    (1024, [1024, 256, 256], 150), (2048, [512, 272], 192),                            # 160- / 192-row blocks
     (512, [8192, 8192], 48),                              # wide output: no K-split (64 column blocks already)
     (4096, [48], 40),                                     # a single partial column block
 ])
 def test_gemm_row_tile_blocks(dev, gs, K, sizes, rows):
-    """33..128 rows run GEMM variant 4 with 64- / 128-row blocks and (narrow outputs) an fp32 K-split summed by a second
+    """33..192 rows run GEMM variant 4 with 64- .. 192-row blocks and (narrow outputs) an fp32 K-split summed by a second
     kernel: the automatic route and the forced variant agree with the oracle, fp16 and bf16, group_size 128 and 64."""
     from paroquant_amd import ops
     L = po.make_layer(K + rows + gs, K, sizes, group_size=gs, bias=True)
