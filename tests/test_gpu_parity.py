@@ -1071,6 +1071,49 @@ def test_attn_decode_matches_oracle(dev, hd, Hq, Hkv, qk_norm, pos):
             and torch.equal(vct[:, :, :pos], vt[:, :, :pos])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 3])
+def test_fused_prologues_and_attention_bf16(dev, rows):
+    """bf16 activations through the decode-layer fusions (RMSNorm prologue + residual, SiLU*mul prologue) and the decode
+    attention kernel (bf16 K / V caches, probabilities rounded to bf16 for the P V product as HF does)."""
+    from paroquant_amd import ops, _native as nat
+    bf = torch.bfloat16
+    K, sizes = 1024, [3072, 3072]
+    L = po.make_layer(K + rows + 7, K, sizes)
+    rng = np.random.default_rng(rows + 70)
+    w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    x = _t((rng.standard_normal((rows, K)) * 3.0).astype(np.float32), dev).to(bf)
+    res = _t(rng.standard_normal((rows, sum(sizes))).astype(np.float32), dev).to(bf)
+    pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+    y = ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=res)
+    assert y.dtype == bf
+    xn = po.rmsnorm(x.float().cpu().numpy(), w, 1e-6)
+    ideal = po.paro_linear_merged(xn, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"], sizes,
+                                  None, ideal=True) + res.float().cpu().numpy().astype(np.float64)
+    assert po.rel_err(y.float().cpu().numpy(), ideal) < 2e-2
+    Ld = po.make_layer(K + rows + 8, 3072, [1024])
+    gu = _t(rng.standard_normal((rows, 2 * 3072)).astype(np.float32), dev).to(bf)
+    yd = ops.w4a16_gemv_fused(gu, _packed(Ld, dev), nat.PROLOGUE_SILU_MUL)
+    ideal_d = po.paro_linear_merged(po.silu_mul(gu.float().cpu().numpy(), 3072), Ld["qweight"], Ld["qzeros"], Ld["scales"], Ld["theta"],
+                                    Ld["pairs"], Ld["channel_scales"], [1024], None, ideal=True)
+    assert po.rel_err(yd.float().cpu().numpy(), ideal_d) < 2e-2
+    # attention, bf16
+    hd, Hq, Hkv, T, pos = 128, 8, 2, 512, 300 + rows
+    qkv = _t(rng.standard_normal((Hq + 2 * Hkv) * hd).astype(np.float32), dev).to(bf)
+    kc = _t(rng.standard_normal((Hkv, T, hd)).astype(np.float32), dev).to(bf)
+    vc = _t(rng.standard_normal((Hkv, T, hd)).astype(np.float32), dev).to(bf)
+    qw = _t((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32), dev).to(bf)
+    kw = _t((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32), dev).to(bf)
+    cos, sin = po.rope_tables(hd, T, 1e4)
+    rope = torch.from_numpy(np.concatenate([cos, sin], axis=-1).astype(np.float32)).to(dev)
+    kct, vct = kc.clone(), vc.transpose(1, 2).contiguous()
+    out = ops.attn_decode(qkv, kct, vct, torch.tensor([pos], dtype=torch.int32, device=dev), rope, Hq, Hkv, hd, qw, kw, 1e-6)
+    f = lambda t: t.float().cpu().numpy()
+    ref, k_new, v_new = po.attention_decode(f(qkv), f(kc), f(vc), pos, Hq, Hkv, hd, cos, sin, f(qw), f(kw), 1e-6)
+    assert out.dtype == bf and po.rel_err(f(out), ref) < 3e-2
+    assert po.rel_err(f(kct[:, pos]), k_new) < 2e-2 and po.rel_err(f(vct[:, :, pos]), v_new) < 1e-6
+
+
 # ---------------------------------------------------------------- f2: the decode harness against HF on the same checkpoint
 
 @pytest.mark.parametrize("model_type,head_dim", [("llama", 64), ("qwen3", 128)])
