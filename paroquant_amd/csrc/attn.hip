@@ -20,7 +20,9 @@
 
 namespace paro {
 
-constexpr int kChunk = 256;
+// positions per workgroup: 256 for short caches (one chunk = no merge up to 256 positions), 128 above that (a CU
+// ingests ~13 B / clock: smaller chunks spread a context over more CUs; each extra chunk costs the in-launch merge)
+constexpr int attn_chunk(int max_positions) { return max_positions <= 512 ? 256 : 128; }
 
 struct AttnArgs {
   const unsigned short* qkv;   // [(Hq + 2 Hkv) * hd]: q heads, k heads, v heads of this token
@@ -74,14 +76,18 @@ __device__ __forceinline__ float wave_sum(float v) {   // the same value in ever
 // scores on the matrix cores (the new key patched into the K fragments) -> soft-max of each wave's 64 positions in
 // registers (DPP row reductions, no LDS, no barrier) -> P V of the wave's own rows -> ONE barrier -> the four waves'
 // (max, sum, partial output) triples merged like chunks are.
-template <typename AT, int HD, int NREP>
+template <typename AT, int HD, int NREP, int CH>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+  constexpr int kChunk = CH;                   // positions of a workgroup
+  constexpr int WP = CH / 4;                   // positions of a wave (64 / 32)
+  constexpr int KT = WP / 16;                  // K tiles (16 positions) of a wave
+  constexpr int VS = WP / 32;                  // V k-steps (32 positions) of a wave
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int hd = HD, half = HD / 2;
   constexpr int DT = HD / 16;                  // 16-column output tiles of the P V product
   constexpr float kLog2e = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) float pw[4 * NREP * 64];        // [wave][head][64] unnormalised probabilities of the wave's positions
+  __shared__ __attribute__((aligned(16))) float pw[4 * NREP * WP];        // [wave][head][WP] unnormalised probabilities of the wave's positions
   __shared__ __attribute__((aligned(16))) float accs[4 * NREP * HD];      // [wave][head][hd] partial outputs
   __shared__ float st[4 * NREP * 2];                                       // [wave][head] (max, sum) of the wave's positions
   __shared__ __attribute__((aligned(16))) unsigned short q16[16 * HD];     // [16 MFMA rows][hd] roped queries (activation dtype), rows >= n_rep zero
@@ -134,24 +140,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // first use of K then waits for V as well -- but tiles past the chunk's end all read ONE address (the chunk's first
   // row: a single cache line for the whole wave), so they cost no bandwidth.  Rows past the end and the new token's row
   // (not in the cache yet) are masked / patched where they are consumed.
-  u32x4 kw[4][KS];
-  u32x4 vf[DT][2];
+  u32x4 kw[KT][KS];
+  u32x4 vf[DT][VS];
   {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool need = wave * 64 + t * 16 < cn;
-      const int row = need ? min(p0 + wave * 64 + t * 16 + mm, a.T_max - 1) : p0;
+    for (int t = 0; t < KT; ++t) {
+      const bool need = wave * WP + t * 16 < cn;
+      const int row = need ? min(p0 + wave * WP + t * 16 + mm, a.T_max - 1) : p0;
       const u32x4* kr = (const u32x4*)(a.kcache + ((int64_t)h * a.T_max + row) * hd) + (need ? kb : 0);
 #pragma unroll
       for (int i = 0; i < KS; ++i) kw[t][i] = kr[need ? 4 * i : 0];
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool need = wave * 64 + 32 * i < cn;
+    for (int i = 0; i < VS; ++i) {
+      const bool need = wave * WP + 32 * i < cn;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const unsigned short* vr = a.vcache + ((int64_t)h * hd + (need ? 16 * t + mm : 0)) * a.T_max;
-        vf[t][i] = *(const u32x4*)(vr + (need ? min(p0 + wave * 64 + 32 * i + 8 * kb, a.T_max - 8) : p0));
+        vf[t][i] = *(const u32x4*)(vr + (need ? min(p0 + wave * WP + 32 * i + 8 * kb, a.T_max - 8) : p0));
       }
     }
   }
@@ -200,23 +206,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // ---- step 2: scores s[j][p] = q_j . K[p] on the matrix cores: A = queries (row m = head, zero rows past n_rep),
   // B = the K fragments requested at the top, the new token's key (not in the cache when they were requested)
   // patched into the fragment rows of its position; D[row 4 kb + r][col mm] = (head, position 16 t + mm of the wave)
-  float sc[4][4];   // [t][r]
+  float sc[KT][4];   // [t][r]
   {
     vec8 qa[KS];
 #pragma unroll
     for (int i = 0; i < KS; ++i) qa[i] = *(const vec8*)(q16 + mm * hd + 32 * i + 8 * kb);
     const int lp = pos - p0;                          // local position of the new token (when own_new)
-    const bool patch = own_new && wave == (lp >> 6) && mm == (lp & 15);
+    const bool patch = own_new && wave == lp / WP && mm == (lp & 15);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (patch && t == ((lp >> 4) & 3)) {
+    for (int t = 0; t < KT; ++t) {
+      if (patch && t == ((lp % WP) >> 4)) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) kw[t][i] = *(const u32x4*)(k16 + 32 * i + 8 * kb);
       }
       f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KS; ++i) dacc = A::mfma(qa[i], __builtin_bit_cast(vec8, kw[t][i]), dacc);
-      const bool inb = wave * 64 + t * 16 + mm < cn;
+      const bool inb = wave * WP + t * 16 + mm < cn;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sc[t][r] = inb ? dacc[r] * a.scale : -3.0e38f;
     }
@@ -228,11 +234,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // probabilities go to the wave's own LDS block; the four waves are merged at the end like chunks are.
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float m = row16_max(fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r])));
+    float mloc = sc[0][r];
+#pragma unroll
+    for (int t = 1; t < KT; ++t) mloc = fmaxf(mloc, sc[t][r]);
+    const float m = row16_max(mloc);
     float l = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool inb = wave * 64 + t * 16 + mm < cn;
+    for (int t = 0; t < KT; ++t) {
+      const bool inb = wave * WP + t * 16 + mm < cn;
       sc[t][r] = inb ? __builtin_amdgcn_exp2f((sc[t][r] - m) * kLog2e) : 0.f;
       l += sc[t][r];
     }
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     const int j = 4 * kb + r;
     if (j < NREP) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) pw[(wave * NREP + j) * 64 + t * 16 + mm] = sc[t][r];
+      for (int t = 0; t < KT; ++t) pw[(wave * NREP + j) * WP + t * 16 + mm] = sc[t][r];
       if (mm == 0) {
         st[(wave * NREP + j) * 2] = m;
         st[(wave * NREP + j) * 2 + 1] = l;
@@ -256,17 +265,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // token's value patched into its position
   {
     const int lp = pos - p0;
-    const bool vpatch = own_new && wave == (lp >> 6) && kb == ((lp >> 3) & 3);
+    const bool vpatch = own_new && wave == lp / WP && kb == ((lp >> 3) & 3);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < VS; ++i) {
       // only the 32 positions that hold the chunk's end or the new token need any of this (wave-uniform test)
-      const bool pi32 = own_new && wave == (lp >> 6) && i == ((lp >> 5) & 1);
-      if (wave * 64 + 32 * i + 32 <= cn && !pi32) continue;
-      const int nv = cn - (wave * 64 + 32 * i + 8 * kb);          // valid positions among this lane's eight
+      const bool pi32 = own_new && wave == lp / WP && i == ((lp % WP) >> 5);
+      if (wave * WP + 32 * i + 32 <= cn && !pi32) continue;
+      const int nv = cn - (wave * WP + 32 * i + 8 * kb);          // valid positions among this lane's eight
       unsigned mk[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) mk[c] = nv >= 2 * c + 2 ? 0xffffffffu : (nv == 2 * c + 1 ? 0x0000ffffu : 0u);
-      const bool pi = vpatch && i == ((lp >> 5) & 1);
+      const bool pi = vpatch && i == ((lp % WP) >> 5);
       // the new token's value replaces one 16-bit slot of one word: keep-mask / insert-shift per word, computed once
       unsigned keep[4], sh[4];
 #pragma unroll
@@ -282,13 +291,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         for (int c = 0; c < 4; ++c) vf[t][i][c] = (vf[t][i][c] & mk[c] & keep[c]) | (sh[c] < 32u ? nv16 << sh[c] : 0u);
       }
     }
-    vec8 pa[2];
+    vec8 pa[VS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < VS; ++i) {
       u32x4 w = {0u, 0u, 0u, 0u};
       if (mm < NREP) {
-        const f32x4 e0 = *(const f32x4*)(pw + (wave * NREP + mm) * 64 + 32 * i + 8 * kb);
-        const f32x4 e1 = *(const f32x4*)(pw + (wave * NREP + mm) * 64 + 32 * i + 8 * kb + 4);
+        const f32x4 e0 = *(const f32x4*)(pw + (wave * NREP + mm) * WP + 32 * i + 8 * kb);
+        const f32x4 e1 = *(const f32x4*)(pw + (wave * NREP + mm) * WP + 32 * i + 8 * kb + 4);
         w[0] = (unsigned)A::from_f32(e0[0]) | ((unsigned)A::from_f32(e0[1]) << 16);
         w[1] = (unsigned)A::from_f32(e0[2]) | ((unsigned)A::from_f32(e0[3]) << 16);
         w[2] = (unsigned)A::from_f32(e1[0]) | ((unsigned)A::from_f32(e1[1]) << 16);
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int t = 0; t < DT; ++t) {
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 2; ++i) o = A::mfma(pa[i], __builtin_bit_cast(vec8, vf[t][i]), o);
+      for (int i = 0; i < VS; ++i) o = A::mfma(pa[i], __builtin_bit_cast(vec8, vf[t][i]), o);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 4 * kb + r;
@@ -358,17 +367,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   }
   __syncthreads();
   if (!last_flag) return;
+  // the last arriver merges the chunks: (max, sum, partial output) triples of up to hundreds of chunks, read eight at a
+  // time (a chunk at a time is one dependent ~0.3 us access after the other: 16 chunks took ~9 us)
   const float* base = a.part + ((int64_t)h * a.chunks) * n_rep * (hd + 2);
   for (int e = tid; e < n_rep * hd; e += 256) {
     const int j = e / hd, d = e % hd;
+    const float* pj = base + (int64_t)j * (hd + 2);
+    const int64_t cstride = (int64_t)n_rep * (hd + 2);
     float M = -3.0e38f;
-    for (int c = 0; c < n_act; ++c) M = fmaxf(M, base[((int64_t)c * n_rep + j) * (hd + 2) + hd]);
+    for (int c0 = 0; c0 < n_act; c0 += 8) {
+      float mv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, n_act - 1) * cstride + hd];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) M = fmaxf(M, mv[q]);
+    }
     float num = 0.f, den = 0.f;
-    for (int c = 0; c < n_act; ++c) {
-      const float* pc = base + ((int64_t)c * n_rep + j) * (hd + 2);
-      const float w = __builtin_amdgcn_exp2f((pc[hd] - M) * 1.4426950408889634f);
-      num = __builtin_fmaf(w, pc[d], num);
-      den = __builtin_fmaf(w, pc[hd + 1], den);
+    for (int c0 = 0; c0 < n_act; c0 += 8) {
+      float mv[8], lv[8], ov[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float* pc = pj + (int64_t)min(c0 + q, n_act - 1) * cstride;
+        mv[q] = pc[hd];
+        lv[q] = pc[hd + 1];
+        ov[q] = pc[d];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float w = (c0 + q < n_act) ? __builtin_amdgcn_exp2f((mv[q] - M) * kLog2e) : 0.f;
+        num = __builtin_fmaf(w, ov[q], num);
+        den = __builtin_fmaf(w, lv[q], den);
+      }
     }
     a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(num / den);
   }
@@ -378,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
 extern "C" int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions) {
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 2 || max_positions < 1) return -1;
-  const int64_t n_rep = n_heads / n_kv_heads, chunks = (max_positions + paro::kChunk - 1) / paro::kChunk;
+  const int64_t n_rep = n_heads / n_kv_heads, chunks = (max_positions + paro::attn_chunk(max_positions) - 1) / paro::attn_chunk(max_positions);
   return 256 + (int64_t)n_kv_heads * chunks * n_rep * (head_dim + 2) * 4;   // tickets (zero-filled by the caller once) + partials
 }
 
@@ -394,8 +423,9 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
   if (head_dim != 64 && head_dim != 128) return fail(PARO_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
   if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return fail(PARO_ERR_INVALID, "q / k norm weights come together");
   const int64_t need = paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions);
-  if (max_positions < 8 || max_positions % 8 != 0 || max_positions > 65535 * kChunk)
-    return fail(PARO_ERR_INVALID, "max_positions must be a multiple of 8 in 8..%d (got %d)", 65535 * kChunk, max_positions);
+  if (max_positions < 8 || max_positions % 8 != 0 || max_positions > 65535 * 128)
+    return fail(PARO_ERR_INVALID, "max_positions must be a multiple of 8 in 8..%d (got %d)", 65535 * 128, max_positions);
+  const int kChunk = attn_chunk(max_positions);
   if (!workspace || workspace_bytes < need)
     return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;
@@ -424,7 +454,11 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
   const bool h16 = act_dtype == PARO_DTYPE_F16;
   const int n_rep = n_heads / n_kv_heads;
   const int nr = n_rep <= 1 ? 1 : (n_rep <= 2 ? 2 : (n_rep <= 4 ? 4 : 8));
-#define PARO_ATTN_LAUNCH(T, HD, NR) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR>), grid, dim3(256), 0, st, a)
+#define PARO_ATTN_LAUNCH(T, HD, NR) \
+  do { \
+    if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128>), grid, dim3(256), 0, st, a); \
+  } while (0)
 #define PARO_ATTN_NR(T, HD) \
   do { \
     if (nr == 1) PARO_ATTN_LAUNCH(T, HD, 1); \
