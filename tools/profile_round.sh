@@ -50,6 +50,7 @@ python tools/pmc_gemm_summary.py $OUT/gemm_pmc_* > $P/${R}_gemm_pmc.json 2> $OUT
 # ---- end to end
 rm -f $P/${R}_e2e.jsonl
 for m in qwen3-4b llama3-8b qwen3-0.6b; do timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e.jsonl 2>> $OUT/e2e.err; done
+timeout 300 python tools/bench_e2e.py --model qwen3-4b --prompt 600 >> $P/${R}_e2e.jsonl 2>> $OUT/e2e.err
 timeout 300 python tools/bench_e2e.py --model qwen3-4b --prompt 1900 >> $P/${R}_e2e.jsonl 2>> $OUT/e2e.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_stats -o e -- python $ROOT/tools/bench_e2e.py --model qwen3-4b --runs 1 --warmup 1 > $OUT/e2e_stats.log 2>&1
@@ -57,7 +58,8 @@ cd $ROOT
 S=$(find $OUT/e2e_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$S" ] && python tools/pmc_summary.py stats $S $P/${R}_e2e_qwen3-4b_kernel_stats.csv
 timeout 200 python tools/bench_fused.py --model qwen3-4b > $P/${R}_fused_vs_plain.jsonl 2>> $OUT/e2e.err
-timeout 200 python tools/bench_attn.py > $P/${R}_attn_decode.jsonl 2>> $OUT/e2e.err
+timeout 200 python tools/bench_attn.py --tmax 512 --positions 0,100,255,256,511 > $P/${R}_attn_decode.jsonl 2>> $OUT/e2e.err
+timeout 200 python tools/bench_attn.py --tmax 2048 >> $P/${R}_attn_decode.jsonl 2>> $OUT/e2e.err
 # ---- context probes: the vendor's dense kernels on the same shapes, grid-barrier cost, kernarg fetch latency, per-wave timeline
 timeout 300 python tools/bench_vendor.py --model llama3-8b > $P/${R}_vendor_llama3-8b.jsonl 2>> $OUT/vendor.err
 timeout 200 python tools/bench_vendor.py --model qwen3-4b --rows 1,8192 > $P/${R}_vendor_qwen3-4b.jsonl 2>> $OUT/vendor.err
