@@ -361,6 +361,12 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
     (allocate them zero-filled)."""
     lib = nat.load()
     T_max = kcache.size(1)
+    if tuple(kcache.shape) != (n_kv_heads, T_max, head_dim) or tuple(vcache.shape) != (n_kv_heads, head_dim, T_max) \
+            or not kcache.is_contiguous() or not vcache.is_contiguous() or kcache.dtype != qkv.dtype or vcache.dtype != qkv.dtype:
+        raise ValueError(f"caches must be contiguous {qkv.dtype} tensors: K [{n_kv_heads}, T, {head_dim}], V [{n_kv_heads}, {head_dim}, T] "
+                         f"(got K {tuple(kcache.shape)}, V {tuple(vcache.shape)})")
+    if tuple(rope.shape) != (T_max, head_dim) or rope.dtype != torch.float32 or pos.dtype != torch.int32:
+        raise ValueError("rope must be fp32 [T, head_dim] (cos then sin per position) and pos an int32 device scalar")
     y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
     ws = workspace if workspace is not None else attn_workspace(qkv.device, n_heads, n_kv_heads, head_dim, T_max)
     with torch.cuda.device(qkv.device):
