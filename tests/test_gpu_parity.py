@@ -868,6 +868,42 @@ def test_hf_from_pretrained_end_to_end(dev, tmp_path):
     assert gen.shape == (1, 13)
 
 
+# ---------------------------------------------------------------- seeded random shapes through the automatic routes
+
+def _fuzz_cases(n=120):
+    rng = np.random.default_rng(20260927)
+    row_choices = [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 24, 32, 33, 47, 64, 65, 100, 128, 129, 191, 192, 193, 255, 256, 257, 300, 513]
+    out = []
+    for i in range(n):
+        K = int(rng.integers(1, 17)) * 128
+        P = int(rng.integers(1, 5))
+        sizes = [int(rng.integers(1, 49)) * 16 for _ in range(P)]
+        if i % 6 == 0:
+            sizes[0] = int(rng.integers(60, 130)) * 16          # some wide partitions (>= 1024 columns: other heuristics)
+        rows = int(row_choices[int(rng.integers(0, len(row_choices)))])
+        out.append((i, K, tuple(sizes), rows, 64 if i % 3 == 1 else 128, bool(i % 2), bool(i % 5 == 0)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,K,sizes,rows,gs,use_bf16,with_bias", _fuzz_cases())
+def test_random_shapes_automatic_routes(dev, case, K, sizes, rows, gs, use_bf16, with_bias):
+    """Seeded random (K, merged partition sizes, rows, group_size, dtype, bias) through `PackedParoWeights.apply`, i.e.
+    through whatever kernel the dispatchers pick (fused GEMV, pre-rotated GEMV, every GEMM variant and K-split): the
+    row counts sit on every dispatch boundary (4/5, 8/9, 16/17, 32/33, 64/65, 128/129, 192/193, 255/256/257)."""
+    sizes = list(sizes)
+    L = po.make_layer(1000 + case, K, sizes, group_size=gs, bias=with_bias)
+    pk = _packed(L, dev, L.get("bias"))
+    x = np.random.default_rng(case).standard_normal((rows, K)).astype(np.float16)
+    xt = _t(x, dev).to(torch.bfloat16) if use_bf16 else _t(x, dev)
+    y = pk.apply(xt)
+    ideal = po.paro_linear_merged(xt.float().cpu().numpy(), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, L.get("bias"), group_size=gs, ideal=True)
+    got = y.float().cpu().numpy()
+    assert got.shape == (rows, sum(sizes)) and np.isfinite(got).all()
+    assert po.rel_err(got, ideal) < (2e-2 if use_bf16 else TIGHT_F16)
+
+
 # ---------------------------------------------------------------- quantisation group_size 64 (rotation group stays 128)
 
 GS64_SHAPES = [(256, [48, 16]), (1024, [3072, 3072]), (2560, [4096, 1024, 1024]), (4096, [2560])]
