@@ -904,6 +904,56 @@ def test_random_shapes_automatic_routes(dev, case, K, sizes, rows, gs, use_bf16,
     assert po.rel_err(got, ideal) < (2e-2 if use_bf16 else TIGHT_F16)
 
 
+def _fused_fuzz_cases(n=60):
+    rng = np.random.default_rng(927)
+    out = []
+    for i in range(n):
+        K = int(rng.integers(1, 25)) * 128
+        P = int(rng.integers(1, 4))
+        sizes = [int(rng.integers(1, 40)) * 16 for _ in range(P)]
+        if i % 5 == 0:
+            sizes[0] = int(rng.integers(64, 160)) * 16
+        out.append((i, K, tuple(sizes), int(rng.integers(1, 5)), i % 3, bool(rng.integers(0, 2)), 64 if i % 4 == 1 else 128, bool(i % 2)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,K,sizes,rows,prologue,with_res,gs,use_bf16", _fused_fuzz_cases())
+def test_random_shapes_fused_gemv(dev, case, K, sizes, rows, prologue, with_res, gs, use_bf16):
+    """Seeded random fused decode linears: prologue none / RMSNorm / SiLU*mul x residual x rows 1..4 x group_size x dtype."""
+    from paroquant_amd import ops, _native as nat
+    sizes = list(sizes)
+    N = sum(sizes)
+    L = po.make_layer(3000 + case, K, sizes, group_size=gs)
+    rng = np.random.default_rng(case)
+    dt = torch.bfloat16 if use_bf16 else torch.float16
+    pk = _packed(L, dev)
+    res = _t(rng.standard_normal((rows, N)).astype(np.float32), dev).to(dt) if with_res else None
+    if prologue == 2:      # SiLU * mul: x = [rows, 2 K] (gate then up)
+        xin = _t(rng.standard_normal((rows, 2 * K)).astype(np.float32), dev).to(dt)
+        xeff = po.silu_mul(xin.float().cpu().numpy(), K)
+        y = ops.w4a16_gemv_fused(xin, pk, nat.PROLOGUE_SILU_MUL, residual=res)
+    elif prologue == 1:    # RMSNorm: weight folded into the channel scales
+        w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+        pk = pk.fold_norm_weight(_t(w, dev))
+        xin = _t((rng.standard_normal((rows, K)) * 2.0).astype(np.float32), dev).to(dt)
+        xeff = po.rmsnorm(xin.float().cpu().numpy(), w, 1e-6)
+        y = ops.w4a16_gemv_fused(xin, pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=res)
+    else:
+        xin = _t(rng.standard_normal((rows, K)).astype(np.float32), dev).to(dt)
+        xeff = xin.float().cpu().numpy()
+        if res is None:
+            res = _t(rng.standard_normal((rows, N)).astype(np.float32), dev).to(dt)     # prologue none needs the residual to be "fused"
+        y = ops.w4a16_gemv_fused(xin, pk, 0, residual=res)
+    ideal = po.paro_linear_merged(xeff, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"], sizes,
+                                  None, group_size=gs, ideal=True)
+    if res is not None:
+        ideal = ideal + res.float().cpu().numpy().astype(np.float64)
+    got = y.float().cpu().numpy()
+    assert y.dtype == dt and np.isfinite(got).all()
+    assert po.rel_err(got, ideal) < (2e-2 if use_bf16 else TIGHT_F16)
+
+
 # ---------------------------------------------------------------- quantisation group_size 64 (rotation group stays 128)
 
 GS64_SHAPES = [(256, [48, 16]), (1024, [3072, 3072]), (2560, [4096, 1024, 1024]), (4096, [2560])]
