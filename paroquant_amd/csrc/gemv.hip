@@ -128,7 +128,10 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:
   // M=4 o 8.1/12.4 qkv 10.0/13.1; M=6 o 10.5/12.5 down 17.3/17.5 but qkv 15.2/13.5 gate_up 22.0/20.9;
   // M=16 gate_up 53/24).
-  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1))) mode = 1;
+  // (re-measured with the round-2 prologue, Llama-3-8B, us fused / pre-pass: M=6 qkv 11.3 / 13.2, gate_up 19.9 / 20.0;
+  // M=8 qkv 11.4 / 13.4, o 10.1 / 13.4, gate_up 21.5 / 20.8, down 17.5 / 16.8; M=12 qkv 16.7 / 14.9, gate_up 47 / 22:
+  // below 9 rows only the wide merged projections still prefer the pre-pass)
+  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves_in <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only

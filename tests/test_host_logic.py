@@ -236,9 +236,10 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*l70["qkv_proj"], 1) == (4, 3, 8, 0)
     assert shape(*l70["o_proj"], 1) == (4, 4, 8, 0)
     assert shape(*l70["down_proj"], 1) == (8, 4, 8, 0)
-    # small batches: fused up to 8 rows (4 for merged projections), rotate pre-pass above; 17..64 rows always pre-pass
+    # small batches: fused up to 8 rows (4 for WIDE merged projections), rotate pre-pass above; 17..64 rows always pre-pass
     assert shape(*l8["o_proj"], 8)[3] == 0 and shape(*l8["o_proj"], 9)[3] == 1
-    assert shape(*l8["qkv_proj"], 4)[3] == 0 and shape(*l8["qkv_proj"], 5)[3] == 1
+    assert shape(*l8["qkv_proj"], 8)[3] == 0 and shape(*l8["qkv_proj"], 9)[3] == 1
+    assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 5)[3] == 1
     assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
     # explicit knobs are respected, empty K-splits dropped
     assert shape(1536, [512], 1, tpw=2, ksplit=5, waves=8, mode=0) == (2, 4, 8, 0)
