@@ -108,14 +108,14 @@ class ParoDecoderLM:
 
     @classmethod
     def random(cls, name_or_cfg, device, n_layers: Optional[int] = None, max_positions: int = 1024, seed: int = 0,
-               vocab: Optional[int] = None) -> "ParoDecoderLM":
+               vocab: Optional[int] = None, dtype: torch.dtype = torch.float16) -> "ParoDecoderLM":
         import bench  # synthetic checkpoint-format layers (repo root on sys.path in tools / tests / bench)
         cfg = named_config(name_or_cfg, max_positions) if isinstance(name_or_cfg, str) else name_or_cfg
         if n_layers:
             cfg.n_layers = n_layers
         if vocab:
             cfg.vocab = vocab
-        self = cls(cfg, device)
+        self = cls(cfg, device, dtype)
         gen = torch.Generator(device=self.device)
         gen.manual_seed(seed)
         q, kv = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
@@ -141,7 +141,7 @@ class ParoDecoderLM:
         return self
 
     @classmethod
-    def from_checkpoint(cls, path: str, device, max_positions: int = 2048) -> "ParoDecoderLM":
+    def from_checkpoint(cls, path: str, device, max_positions: int = 2048, dtype: torch.dtype = torch.float16) -> "ParoDecoderLM":
         """Load an HF ``*-PARO`` checkpoint directory (config.json + safetensors; tensor names of cli/convert.py:264-277
         under the usual ``model.layers.N.{self_attn,mlp}.*_proj`` paths).  q/k/v and gate/up are merged into one
         fused linear each (3 / 2 rotations), the layer norms are folded into the channel scales."""
@@ -149,7 +149,7 @@ class ParoDecoderLM:
         with open(os.path.join(path, "config.json")) as f:
             hf = json.load(f)
         cfg = DecoderConfig.from_hf(hf, max_positions)
-        self = cls(cfg, device)
+        self = cls(cfg, device, dtype)
         t: Dict[str, torch.Tensor] = {}
         for fn in sorted(os.listdir(path)):
             if fn.endswith(".safetensors"):
