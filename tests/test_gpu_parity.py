@@ -810,18 +810,19 @@ def test_pack_library_gpu_matches_goldens(dev, golden_dir):
     assert np.abs(dq).max() <= 1 and (dq != 0).mean() < 1e-3
 
 
-def test_prepacked_roundtrip(dev, tmp_path):
+@pytest.mark.parametrize("gs", [128, 64])
+def test_prepacked_roundtrip(dev, tmp_path, gs):
     """save_prepacked / load_prepacked: a linear stored in the CDNA4 kernel layout comes back bit-identical and
-    computes the same outputs without any repack launch."""
+    computes the same outputs without any repack launch (the quantisation group is read off the packed tensors)."""
     from paroquant_amd import pack
-    L = po.make_layer(606, 1024, [512, 256, 256], bias=True)
+    L = po.make_layer(606, 1024, [512, 256, 256], group_size=gs, bias=True)
     pk = _packed(L, dev, L["bias"])
     f = str(tmp_path / "qkv.prepacked.safetensors")
     pack.save_prepacked(pk, f)
     pk2 = pack.load_prepacked(f, dev)
     for name in ("wq", "sz", "rot"):
         assert torch.equal(getattr(pk, name), getattr(pk2, name))
-    assert pk2.partition_sizes == [512, 256, 256] and pk2.K == 1024 and pk2.wq_order == pk.wq_order
+    assert pk2.partition_sizes == [512, 256, 256] and pk2.K == 1024 and pk2.wq_order == pk.wq_order and pk2.group_size == gs
     for rows in (1, 40, 300):
         x = torch.randn(rows, 1024, device=dev, dtype=torch.float16)
         assert torch.equal(pk.apply(x), pk2.apply(x))
