@@ -730,17 +730,18 @@ def test_rotate_quantized_linear_module(dev, golden_dir):
         m(x.float())
 
 
-def test_vllm_linear_method_contract(dev):
+@pytest.mark.parametrize("gs", [128, 64])
+def test_vllm_linear_method_contract(dev, gs):
     """ParoQuantLinearMethod: create_weights -> shard-id loaders -> process_weights_after_loading -> apply,
-    against the per-partition rotate + matmul + cat of the reference (plugin.py:281-311)."""
+    against the per-partition rotate + matmul + cat of the reference (plugin.py:281-311); group_size from the config."""
     from paroquant_amd.vllm_plugin import ParoQuantConfig, ParoQuantLinearMethod
     K, sizes = 1024, [512, 128, 128]
-    L = po.make_layer(123, K, sizes, bias=True)
-    cfg = ParoQuantConfig.from_config({"bits": 4, "group_size": 128, "krot": 8})
+    L = po.make_layer(123, K, sizes, group_size=gs, bias=True)
+    cfg = ParoQuantConfig.from_config({"bits": 4, "group_size": gs, "krot": 8})
     method = ParoQuantLinearMethod(cfg)
     layer = torch.nn.Module()
     method.create_weights(layer, K, sizes, K, sum(sizes), torch.float16)
-    assert layer.theta.shape == (3, 8, K // 2) and layer.pairs.dtype == torch.int16
+    assert layer.theta.shape == (3, 8, K // 2) and layer.pairs.dtype == torch.int16 and layer.qzeros.shape[0] == K // gs
     layer.qweight.data.copy_(torch.from_numpy(L["qweight"]))
     layer.qzeros.data.copy_(torch.from_numpy(L["qzeros"]))
     layer.scales.data.copy_(torch.from_numpy(L["scales"]))
@@ -755,8 +756,13 @@ def test_vllm_linear_method_contract(dev):
     bias = _t(L["bias"], dev)
     y = method.apply(layer, x, bias)
     ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
-                                  L["channel_scales"], sizes, L["bias"], ideal=True)
+                                  L["channel_scales"], sizes, L["bias"], group_size=gs, ideal=True)
     assert po.rel_err(_np(y), ideal) < TIGHT_F16
+    xb = torch.randn(70, K, device=dev).to(torch.bfloat16)               # vLLM's bf16 activations, a prefill-sized batch
+    yb = method.apply(layer, xb, bias.to(torch.bfloat16))
+    ideal_b = po.paro_linear_merged(xb.float().cpu().numpy(), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                    L["channel_scales"], sizes, L["bias"], group_size=gs, ideal=True)
+    assert yb.dtype == torch.bfloat16 and po.rel_err(yb.float().cpu().numpy(), ideal_b) < 2e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
