@@ -4,14 +4,16 @@
 // here it exists so that a whole decode step is five launches per layer (qkv GEMV, this, o GEMV, gate_up GEMV,
 // down GEMV) inside one HIP graph, and the end-to-end tokens/s of north_star can be measured.
 //
-// Grid = (KV heads, position chunks of 256).  A workgroup handles one chunk of one KV head for all of that head's
-// n_rep = Hq / Hkv query heads (they share every K / V byte): every global load of the chunk -- K and V as MFMA B
-// fragments, 16 bytes per lane and load -- is requested before anything else; scores and P V run on the matrix cores,
-// the soft-max of a wave's 64 positions in registers -- a CU ingests ~10 B / clock, so long contexts are spread over
-// many CUs rather than one workgroup per head.  The V cache is kept position-contiguous ([head][dim][position]) for that.  With more than one active chunk the partial (max, sum, unnormalised output) triples go to
-// a workspace and the LAST workgroup of a KV head to arrive (agent-scope release -> ticket -> acquire; no spinning,
-// so no dependence on dispatch order) merges them.  The position comes from DEVICE memory, so one captured graph
-// replays for every token: the grid always covers max_positions, chunks beyond `pos` exit at once.
+// Grid = (KV heads, position chunks of 256 -- 128 for caches above 512 positions).  A workgroup handles one chunk of
+// one KV head for all of that head's n_rep = Hq / Hkv query heads (they share every K / V byte): every global load of
+// the chunk -- K and V as MFMA B fragments, 16 bytes per lane and load -- is requested before anything else; scores and
+// P V run on the matrix cores, the soft-max of a wave's 64 / 32 positions in registers.  A CU ingests ~13 B / clock, so
+// longer contexts are spread over many CUs rather than one workgroup per head.  The V cache is kept position-contiguous
+// ([head][dim][position]) so that its fragments are 16-byte loads too.  With more than one active chunk the partial
+// (max, sum, unnormalised output) triples go to a workspace and the LAST workgroup of a KV head to arrive (agent-scope
+// release -> ticket -> acquire; no spinning, so no dependence on dispatch order) merges them, reading eight chunks'
+// triples at a time.  The position comes from DEVICE memory, so one captured graph replays for every token: the grid
+// always covers max_positions, chunks beyond `pos` exit at once.
 #include <stdlib.h>
 
 #include <type_traits>
