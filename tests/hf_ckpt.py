@@ -14,7 +14,7 @@ LINEARS = (("self_attn.q_proj", "h", "q"), ("self_attn.k_proj", "h", "kv"), ("se
 
 
 def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2, layers=2, vocab=128, seed=0,
-                          model_type="llama", head_dim=None):
+                          model_type="llama", head_dim=None, group_size=128):
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
     hd = head_dim or hidden // heads
@@ -33,7 +33,7 @@ def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2,
             tensors[pre + "self_attn.q_norm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hd))
             tensors[pre + "self_attn.k_norm.weight"] = f16(1.0 + 0.1 * rng.standard_normal(hd))
         for name, kin, kout in LINEARS:
-            L = po.make_layer(seed * 1000 + l * 10 + len(oracle_layers), dims[kin], [dims[kout]])
+            L = po.make_layer(seed * 1000 + l * 10 + len(oracle_layers), dims[kin], [dims[kout]], group_size=group_size)
             oracle_layers[pre + name] = L
             tensors[pre + name + ".qweight"] = torch.from_numpy(L["qweight"])
             tensors[pre + name + ".qzeros"] = torch.from_numpy(L["qzeros"])
@@ -47,7 +47,7 @@ def write_tiny_paro_llama(path: str, hidden=256, inter=512, heads=4, kv_heads=2,
            "vocab_size": vocab, "max_position_embeddings": 128, "rms_norm_eps": 1e-6, "rope_theta": 10000.0,
            "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False, "mlp_bias": False,
            "torch_dtype": "float16", "bos_token_id": 1, "eos_token_id": 2,
-           "quantization_config": {"quant_method": "paroquant", "bits": 4, "group_size": 128, "krot": 8}}
+           "quantization_config": {"quant_method": "paroquant", "bits": 4, "group_size": group_size, "krot": 8}}
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, indent=1)
     return oracle_layers

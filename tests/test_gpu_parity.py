@@ -836,7 +836,8 @@ def test_prepacked_roundtrip(dev, tmp_path, gs):
 
 # ---------------------------------------------------------------- a8: HF from_pretrained end to end
 
-def test_hf_from_pretrained_end_to_end(dev, tmp_path):
+@pytest.mark.parametrize("gs", [128, 64])
+def test_hf_from_pretrained_end_to_end(dev, tmp_path, gs):
     """A synthetic 2-layer Llama-style PARO checkpoint (safetensors + config.json with quantization_config, tensors
     from the oracle's packer) loads through AutoModelForCausalLM.from_pretrained -> ParoQuantHfQuantizer
     (transformers/quantizer.py:88-115): every quantised nn.Linear is swapped for RotateQuantizedLinear, repacked,
@@ -845,7 +846,7 @@ def test_hf_from_pretrained_end_to_end(dev, tmp_path):
     from paroquant_amd import RotateQuantizedLinear
     from tests.hf_ckpt import write_tiny_paro_llama
     from transformers import AutoModelForCausalLM
-    layers = write_tiny_paro_llama(str(tmp_path))
+    layers = write_tiny_paro_llama(str(tmp_path), group_size=gs)
     try:
         model = AutoModelForCausalLM.from_pretrained(str(tmp_path), dtype=torch.float16, device_map={"": "cuda:0"})
     except TypeError:
@@ -867,8 +868,9 @@ def test_hf_from_pretrained_end_to_end(dev, tmp_path):
         L = layers[k]
         K = x.shape[-1]
         ref = po.paro_linear(_np(x.reshape(-1, K)), L["qweight"], L["qzeros"], L["scales"], L["theta"][0], L["pairs"][0],
-                             L["channel_scales"][0], None, ideal=True)
+                             L["channel_scales"][0], None, gs, ideal=True)
         assert po.rel_err(_np(y.reshape(-1, y.shape[-1])), ref) < TIGHT_F16, k
+    assert all(m.group_size == gs for m in swapped.values())
     # greedy decode runs (prefill rows > 1, then single-token steps through the GEMV)
     with torch.no_grad():
         gen = model.generate(ids, max_new_tokens=4, do_sample=False)
