@@ -118,8 +118,10 @@ def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None):
 class DecodeStack:
     """All quantised linears of `n_layers` decoder layers, chained for one batch-1 decode token."""
 
-    def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0):
+    def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0, allreduce=None):
         self.model, self.tp, self.rank = model, tp, rank
+        # the collective after the row-parallel linears: the one-shot kernel (paroquant_amd.tp.OneShotAllReduce) or dist.all_reduce
+        self.allreduce = allreduce or (lambda y: (dist.all_reduce(y), y)[1])
         h, inter, q, kv, L = MODELS[model]
         self.n_layers = n_layers or L
         self.hidden, self.q_local, self.inter_local = h, q // tp, inter // tp
@@ -140,15 +142,17 @@ class DecodeStack:
             a = qkv.apply(h)[:, : self.q_local]            # attention stand-in: a view, no kernel
             h = o.apply(a)
             if tp > 1:
-                dist.all_reduce(h)                          # RowParallelLinear all-reduce (RCCL over xGMI)
+                h = self.allreduce(h)                       # RowParallelLinear all-reduce (one-shot xGMI kernel, or RCCL)
             d = gu.apply(h)[:, : self.inter_local]         # SiLU*mul stand-in: a view, no kernel
             h = down.apply(d)
             if tp > 1:
-                dist.all_reduce(h)
+                h = self.allreduce(h)
         return h
 
 
 def time_steps(fn, steps: int, warmup: int, world: int, dev):
+    if world > 1:
+        dist.barrier()          # ranks enter the warm-up together (a kernel-level collective spins on late peers)
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize(dev)
@@ -316,6 +320,8 @@ def parse_args(argv=None):
                     help="collective backend of the N > 1 run; gloo (+ --same-device) lets the whole TP path -- sharded HIP kernels, "
                          "all-reduce placement, max-over-ranks clock -- run with N processes on ONE GPU (tests; eager, no graph)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (only with --tp-backend gloo)")
+    ap.add_argument("--no-oneshot", action="store_true",
+                    help="TP runs: use the backend's all-reduce (RCCL / gloo) instead of the one-shot xGMI kernel")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise only the multi-process plumbing (spawn, rendezvous, barrier, max-over-ranks timing, JSON) "
                          "with backend gloo and a trivial CPU step -- used by the CPU test-suite; prints data: 'dry-run'")
@@ -398,7 +404,6 @@ def run(args, rank: int, local_rank: int, world: int):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.tp_backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            args.no_graph = True          # a gloo collective is a host operation: nothing to capture
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -410,36 +415,58 @@ def run(args, rank: int, local_rank: int, world: int):
         h, inter, q, kv, _ = MODELS[model]
         if q % (tp * 128) or inter % (tp * 128) or kv % (tp * 16):
             raise SystemExit(f"{model} does not shard {tp}-way: K slices must be multiples of 128, column slices of 16")
-    stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank)
+    allreduce, allreduce_name = None, None
+    if tp_mode and world > 1:
+        from paroquant_amd import tp as ptp
+        allreduce, allreduce_name = ptp.make_allreduce(dev, MODELS[model][0], prefer_oneshot=not args.no_oneshot)
+        if allreduce_name == "gloo":
+            args.no_graph = True          # a gloo collective is a host operation: nothing to capture
+    stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank, allreduce=allreduce)
 
-    out = stack.step(stack.x)           # eager warm-up (also sizes the shared workspace)
-    torch.cuda.synchronize(dev)
-    assert torch.isfinite(out.float()).all(), "non-finite activations in the synthetic decode chain"
+    def measure():
+        """Eager warm-up, HIP-graph capture of the step (when the collective allows it), timed region."""
+        out = stack.step(stack.x)           # eager warm-up (also sizes the shared workspace)
+        torch.cuda.synchronize(dev)
+        assert torch.isfinite(out.float()).all(), "non-finite activations in the synthetic decode chain"
+        graphed = not args.no_graph
+        fn = lambda: stack.step(stack.x)
+        if graphed:
+            try:
+                s = torch.cuda.Stream(dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(s):
+                    stack.step(stack.x)
+                torch.cuda.current_stream(dev).wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    stack.step(stack.x)
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                fn = graph.replay
+            except Exception as e:           # e.g. an RCCL build that cannot be captured: measure eagerly, say so
+                if tp <= 1:
+                    raise
+                print(f"[bench] HIP-graph capture of the TP step failed ({type(e).__name__}: {e}); timing eager launches",
+                      file=sys.stderr, flush=True)
+                graphed = False
+                torch.cuda.synchronize(dev)
+        w, e = time_steps(fn, args.steps, args.warmup, world, dev)
+        return w, e, graphed
 
-    use_graph = not args.no_graph
-    fn = lambda: stack.step(stack.x)
-    if use_graph:
-        try:
-            s = torch.cuda.Stream(dev)
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                stack.step(stack.x)
-            torch.cuda.current_stream(dev).wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                stack.step(stack.x)
-            graph.replay()
-            torch.cuda.synchronize(dev)
-            fn = graph.replay
-        except Exception as e:           # e.g. an RCCL build that cannot be captured: measure eagerly, say so
-            if tp <= 1:
-                raise
-            print(f"[bench] HIP-graph capture of the TP step failed ({type(e).__name__}: {e}); timing eager launches",
-                  file=sys.stderr, flush=True)
-            use_graph = False
-            torch.cuda.synchronize(dev)
-
-    wall, ev_ms = time_steps(fn, args.steps, args.warmup, world, dev)
+    wall, ev_ms, use_graph = measure()
+    if allreduce_name == "oneshot":
+        # a one-shot all-reduce that ever timed out on a peer produced garbage: never report such a run -- fall back to the
+        # backend's collective on every rank and measure again
+        bad = torch.tensor([1 if allreduce.gave_up() else 0], dtype=torch.int32, device=dev if args.tp_backend == "nccl" else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            if rank == 0:
+                print(f"[bench] the one-shot all-reduce gave up waiting for a peer; re-measuring with {args.tp_backend}", file=sys.stderr, flush=True)
+            allreduce_name = args.tp_backend
+            stack.allreduce = lambda y: (dist.all_reduce(y), y)[1]
+            if args.tp_backend == "gloo":
+                args.no_graph = True
+            wall, ev_ms, use_graph = measure()
     ms_per_step = wall * 1e3 / args.steps
     replicas = 1 if tp_mode else world
     tokens_per_s = replicas * args.steps / wall
@@ -469,11 +496,12 @@ def run(args, rank: int, local_rank: int, world: int):
         "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f16 activations x int4 weights (fp32 accumulate)",
         "data": "synthetic (random INT4 AWQ-format weights, random fp16 activations, random perfect-matching pairs)",
         "config": {"workload": f"{model}-PARO batch-1 decode: {stack.n_layers} layers x (qkv[P=3], o, gate_up[P=2], down) "
-                               f"W4A16 g128 krot8, {'TP=%d (RCCL all-reduce after o / down)' % tp if tp_mode else 'replica per GPU'}",
+                               f"W4A16 g128 krot8, {('TP=%d (%s all-reduce after o / down)' % (tp, {'oneshot': 'one-shot xGMI kernel', 'nccl': 'RCCL'}.get(allreduce_name, allreduce_name))) if tp_mode else 'replica per GPU'}",
                    "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
                    "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
-                   "collective_backend": (args.tp_backend if world > 1 and tp_mode else None)},
+                   "collective_backend": (args.tp_backend if world > 1 and tp_mode else None),
+                   "allreduce": allreduce_name},
         "roofline": roofline,
     }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 7
+#define PARO_ABI_VERSION 8
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -294,6 +294,23 @@ int paro_prefetch(const void* const* ptrs, const int64_t* bytes, int n, int work
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */
 int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * One-shot all-reduce(SUM) of a small activation vector across the ranks of one node: the collective after the
+ * row-parallel linears (o_proj, down_proj) of tensor-parallel decode, which the reference leaves to vLLM's
+ * RowParallelLinear (SURVEY section 8 row e).  One launch of one workgroup per rank, no host work, HIP-graph capturable:
+ * every rank stores its vector straight into a slot of every peer's buffer (xGMI peer stores), raises a flag there, waits
+ * (bounded) for the world's flags in its own buffer and sums the slots in rank order in fp32 -- bit-identical on all
+ * ranks.
+ *   buffer: paro_allreduce_buffer_bytes(world, max_elems) bytes per rank, zero-filled once, mapped into every peer
+ *           (hipIpc*; the Python side uses torch's CUDA-IPC tensor sharing); peers_dev = DEVICE array of the world's buffer
+ *           addresses as mapped in the calling process, own buffer at [rank].
+ *   n: elements, a multiple of 8, <= max_elems (the value the buffer was sized with).  x and y may alias.
+ * A peer that never arrives makes the call give up after a bounded spin: word 1 of the buffer becomes
+ * PARO_WS_STATUS_GIVEUP (sticky) and the sum is garbage -- the host checks that word at teardown / after warm-up. */
+int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems);
+int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act_dtype, const void* const* peers_dev, int world, int rank,
+                           int64_t max_elems, void* stream);
 
 #ifdef __cplusplus
 }

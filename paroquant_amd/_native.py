@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 7
+PARO_ABI_VERSION = 8
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
@@ -49,6 +49,8 @@ EXPORTS = (
     "paro_w4a16_linear",
     "paro_dequant_packed",
     "paro_prefetch",
+    "paro_allreduce_buffer_bytes",
+    "paro_allreduce_oneshot",
 )
 
 
@@ -165,6 +167,10 @@ def load() -> ctypes.CDLL:
                                       c_void_p]
     lib.paro_prefetch.restype = c_int
     lib.paro_prefetch.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]
+    lib.paro_allreduce_buffer_bytes.restype = c_int64
+    lib.paro_allreduce_buffer_bytes.argtypes = [c_int, c_int64]
+    lib.paro_allreduce_oneshot.restype = c_int
+    lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.paro_dequant_packed.restype = c_int
     lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:

@@ -621,8 +621,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       return g_begin + li;
     };
     const bool has_work = my_count > 0;
-    const int gf = has_work ? unit_group(0) : h.G - 1;
-    // (the first unit's coefficient requests went out at kernel entry: `pc_first`, group gf == gf_first)
+    // (the first unit's coefficient and tile requests went out at kernel entry: `pc_first` / `tc_first`, group gf_first ==
+    // unit_group(0), or the clamped dummy unit of a wave without work)
     // Issue priority: the CU returns vector-memory data in request order.  Left alone, each SIMD issues
     // [wave 0: coefficients, tiles][wave 4: coefficients, tiles] ..., so the small L2-resident coefficient loads of
     // the later waves come back behind the earlier waves' HBM tile loads.  Every wave therefore ran at priority 3

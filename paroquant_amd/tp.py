@@ -76,3 +76,110 @@ def row_parallel_forward(apply_fn, x_full: torch.Tensor, rank: int, world: int, 
     if world > 1:
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
     return y
+
+
+class OneShotAllReduce:
+    """All-reduce(SUM) of the row-parallel linears' small decode outputs in ONE kernel launch per rank
+    (``paro_allreduce_oneshot``, csrc/allreduce.hip): every rank stores its vector straight into a slot of every peer's
+    buffer over xGMI, flags it, waits for the world's flags in its own buffer and sums in rank order.  No host work per
+    call, so a tensor-parallel decode step stays one HIP graph whatever the collective library can or cannot capture.
+
+    The per-rank buffers are exchanged once through torch's CUDA-IPC tensor sharing over ``group`` (any backend that can
+    ``all_gather_object``: nccl or gloo).  ``self_test`` compares a few calls against ``dist.all_reduce``;
+    :func:`make_allreduce` falls back to the library collective when the exchange or the test fails."""
+
+    def __init__(self, device, max_elems: int, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _native as nat
+        self.lib = nat.load()
+        self.nat = nat
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        self.max_elems = int(max_elems)
+        nbytes = self.lib.paro_allreduce_buffer_bytes(self.world, self.max_elems)
+        if nbytes < 0:
+            raise ValueError(f"one-shot all-reduce supports up to 16 ranks and >= 8 elements (world {self.world}, {max_elems} elements)")
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        rebuild, args = reduce_tensor(self.buf)              # (rebuild_cuda_tensor, IPC handle + geometry)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, args, group=group)
+        self._mapped = []                                     # the peers' buffers as mapped here: kept alive with self
+        ptrs, err = [], None
+        try:
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs.append(self.buf.data_ptr())
+                else:
+                    t = rebuild(*gathered[r])
+                    self._mapped.append(t)
+                    ptrs.append(t.data_ptr())
+            self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+            torch.cuda.synchronize(self.device)
+        except Exception as e:                                # e.g. IPC mapping refused on this rank
+            err = e
+        # every rank runs the same collectives whatever happened locally: agree on the outcome, then raise together
+        if not self._agree(err is None):
+            raise RuntimeError(f"peer buffers could not be mapped on every rank (rank {self.rank}: {err})")
+        dist.barrier(group=group)                             # every buffer is zeroed and mapped before the first store lands
+
+    def _agree(self, ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
+    def __call__(self, y: torch.Tensor) -> torch.Tensor:
+        """In place, like ``dist.all_reduce``: y <- sum over ranks of y."""
+        n = y.numel()
+        if not y.is_contiguous() or y.dtype not in (torch.float16, torch.bfloat16) or n % 8 or n > self.max_elems:
+            raise ValueError(f"one-shot all-reduce takes contiguous fp16 / bf16 vectors of a multiple of 8 up to {self.max_elems} elements")
+        with torch.cuda.device(y.device):
+            self.nat.check(self.lib.paro_allreduce_oneshot(y.data_ptr(), y.data_ptr(), n, self.nat.dtype_code(y.dtype), self.peers.data_ptr(),
+                                                           self.world, self.rank, self.max_elems, self.nat.current_stream_ptr(y.device)))
+        return y
+
+    def gave_up(self) -> bool:
+        """True when a call timed out waiting for a peer (sticky status word; synchronises)."""
+        torch.cuda.synchronize(self.device)
+        return int(self.buf[4:8].view(torch.int32).item()) != 0
+
+    def self_test(self, iters: int = 4) -> bool:
+        """A few calls on seeded per-rank data against the library collective; every rank returns the same verdict."""
+        ok = True
+        n = min(self.max_elems, 4096) // 8 * 8
+        backend = dist.get_backend(self.group)
+        for i in range(iters):
+            g = torch.Generator(device="cpu").manual_seed(1234 + 17 * i + self.rank)
+            x = (torch.randn(n, generator=g) * 0.5).to(torch.float16)
+            ref = x.float().to(self.device) if backend == "nccl" else x.float()
+            dist.all_reduce(ref, group=self.group)           # the same collective sequence on every rank, whatever fails locally
+            try:
+                got = self(x.to(self.device).clone()).float().cpu()
+                ok = ok and bool(torch.isfinite(got).all()) and float((got - ref.cpu()).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+            except Exception:
+                ok = False
+        try:
+            ok = ok and not self.gave_up()
+        except Exception:
+            ok = False
+        return self._agree(ok)
+
+
+def make_allreduce(device, max_elems: int, group=None, prefer_oneshot: bool = True):
+    """``(fn, name)``: the in-place all-reduce a tensor-parallel decode step should use -- the one-shot kernel when it can
+    be set up and passes its self-test on every rank, else ``dist.all_reduce`` (RCCL under the nccl backend)."""
+    fallback = (lambda y: (dist.all_reduce(y, group=group), y)[1]), dist.get_backend(group)
+    if not prefer_oneshot or dist.get_world_size(group) == 1:
+        return fallback
+    try:
+        ar = OneShotAllReduce(device, max_elems, group)      # raises on EVERY rank or on none (the ranks agree inside)
+    except Exception as e:
+        if dist.get_rank(group) == 0:
+            print(f"[paroquant_amd.tp] one-shot all-reduce unavailable ({type(e).__name__}: {e}); using {fallback[1]}", flush=True)
+        return fallback
+    if ar.self_test():
+        return ar, "oneshot"
+    if dist.get_rank(group) == 0:
+        print(f"[paroquant_amd.tp] one-shot all-reduce failed its self-test; using {fallback[1]}", flush=True)
+    return fallback

@@ -1363,3 +1363,27 @@ def test_tp_bench_path_on_one_gpu(dev, world, workload):
     assert r["n_gpus"] == world and r["scaling"] == "strong" and r["config"]["parallelism"] == f"tp{world}"
     assert r["value"] > 0 and r["config"]["tp1_reference"]["tokens_per_s"] > 0
     assert r["roofline"]["launches_per_step"] == 8
+    # the collective is the one-shot kernel (self-tested against gloo inside the bench), so the TP step is one HIP graph
+    assert r["config"]["allreduce"] == "oneshot" and r["config"]["hip_graph"] is True
+    out2 = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", "2", "--no-oneshot",
+                           "--tp-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1"],
+                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    r2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
+    assert r2["config"]["allreduce"] == "gloo" and r2["config"]["hip_graph"] is False
+
+
+# ---------------------------------------------------------------- e: one-shot all-reduce of the row-parallel outputs
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_ranks_share_one_gpu(dev, world):
+    """paro_allreduce_oneshot through CUDA-IPC-mapped peer buffers, `world` processes on this one GPU (gloo as the control
+    channel): against gloo's all-reduce, bit-identical across ranks, fp16 / bf16, and replayed from a HIP graph."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29600 + world), os.path.join(root, "tests", "_oneshot_worker.py")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ONESHOT_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
