@@ -302,13 +302,23 @@ int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);
  * every rank stores its vector straight into a slot of every peer's buffer (xGMI peer stores), raises a flag there, waits
  * (bounded) for the world's flags in its own buffer and sums the slots in rank order in fp32 -- bit-identical on all
  * ranks.
- *   buffer: paro_allreduce_buffer_bytes(world, max_elems) bytes per rank, zero-filled once, mapped into every peer
- *           (hipIpc*; the Python side uses torch's CUDA-IPC tensor sharing); peers_dev = DEVICE array of the world's buffer
- *           addresses as mapped in the calling process, own buffer at [rank].
+ *   buffer: paro_allreduce_buffer_bytes(world, max_elems) bytes per rank of fine-grained device memory
+ *           (paro_allreduce_buffer_create), mapped into every peer (paro_allreduce_buffer_open on the 64-byte handle);
+ *           peers_dev = DEVICE array of the world's buffer addresses as mapped in the calling process, own buffer at [rank].
  *   n: elements, a multiple of 8, <= max_elems (the value the buffer was sized with).  x and y may alias.
  * A peer that never arrives makes the call give up after a bounded spin: word 1 of the buffer becomes
  * PARO_WS_STATUS_GIVEUP (sticky) and the sum is garbage -- the host checks that word at teardown / after warm-up. */
 int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems);
+/* Setup-time helpers (they allocate and synchronise): the buffer must be FINE-GRAINED device memory -- peers write into it
+ * and the owner polls it within one kernel, and ordinary device memory is coherent across GPUs only at kernel boundaries.
+ * create: hipExtMallocWithFlags(hipDeviceMallocFinegrained) + zero fill + hipIpcGetMemHandle (64 opaque bytes to hand to the
+ * peers); open / close: hipIpcOpenMemHandle / hipIpcCloseMemHandle in a peer process; destroy: hipFree in the owner;
+ * status: synchronises `stream`, PARO_ERR_LAUNCH if a call ever gave up. */
+int paro_allreduce_buffer_create(int64_t bytes, void** out_ptr, void* out_handle64);
+int paro_allreduce_buffer_open(const void* handle64, void** out_ptr);
+int paro_allreduce_buffer_close(void* peer_ptr);
+int paro_allreduce_buffer_destroy(void* own_ptr);
+int paro_allreduce_status(const void* own_ptr, void* stream);
 int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act_dtype, const void* const* peers_dev, int world, int rank,
                            int64_t max_elems, void* stream);
 

@@ -50,6 +50,11 @@ EXPORTS = (
     "paro_dequant_packed",
     "paro_prefetch",
     "paro_allreduce_buffer_bytes",
+    "paro_allreduce_buffer_create",
+    "paro_allreduce_buffer_open",
+    "paro_allreduce_buffer_close",
+    "paro_allreduce_buffer_destroy",
+    "paro_allreduce_status",
     "paro_allreduce_oneshot",
 )
 
@@ -169,6 +174,16 @@ def load() -> ctypes.CDLL:
     lib.paro_prefetch.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]
     lib.paro_allreduce_buffer_bytes.restype = c_int64
     lib.paro_allreduce_buffer_bytes.argtypes = [c_int, c_int64]
+    lib.paro_allreduce_buffer_create.restype = c_int
+    lib.paro_allreduce_buffer_create.argtypes = [c_int64, POINTER(c_void_p), c_void_p]
+    lib.paro_allreduce_buffer_open.restype = c_int
+    lib.paro_allreduce_buffer_open.argtypes = [c_void_p, POINTER(c_void_p)]
+    lib.paro_allreduce_buffer_close.restype = c_int
+    lib.paro_allreduce_buffer_close.argtypes = [c_void_p]
+    lib.paro_allreduce_buffer_destroy.restype = c_int
+    lib.paro_allreduce_buffer_destroy.argtypes = [c_void_p]
+    lib.paro_allreduce_status.restype = c_int
+    lib.paro_allreduce_status.argtypes = [c_void_p, c_void_p]
     lib.paro_allreduce_oneshot.restype = c_int
     lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.paro_dequant_packed.restype = c_int

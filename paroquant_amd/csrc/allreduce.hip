@@ -103,11 +103,70 @@ extern "C" int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act
   a.rank = rank;
   a.n = (int)n;
   a.slot_bytes = ((max_elems * 2 + 255) / 256) * 256;
-  a.spin_limit = 1 << 24;   // ~20 s of ~1 us naps
+  a.spin_limit = 1 << 22;   // ~4 s of ~1 us naps (callers barrier before phases in which ranks can be seconds apart)
   hipStream_t st = (hipStream_t)stream;
   if (act_dtype == PARO_DTYPE_F16)
     hipLaunchKernelGGL(allreduce_oneshot_kernel<f16>, dim3(1), dim3(1024), 0, st, a);
   else
     hipLaunchKernelGGL(allreduce_oneshot_kernel<bf16>, dim3(1), dim3(1024), 0, st, a);
   return check_launch("paro_allreduce_oneshot");
+}
+
+// ---- the per-rank buffer: FINE-GRAINED device memory.  Peers write into it and this rank polls it inside one kernel:
+// ordinary (coarse-grained) device memory is only coherent across agents at kernel boundaries -- a flag polled through
+// this GPU's L2 could stay stale for ever -- so the buffer is allocated here with hipDeviceMallocFinegrained and shared
+// through HIP IPC handles (64 opaque bytes the caller passes between its processes).  Setup-time calls: they allocate
+// and synchronise, unlike everything on the hot path.
+extern "C" int paro_allreduce_buffer_create(int64_t bytes, void** out_ptr, void* out_handle64) {
+  using namespace paro;
+  if (bytes < kArDataOff || !out_ptr || !out_handle64) return fail(PARO_ERR_INVALID, "bad arguments");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipExtMallocWithFlags(finegrained, %lld bytes): %s", (long long)bytes, hipGetErrorString(e));
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(PARO_ERR_LAUNCH, "all-reduce buffer setup: %s", hipGetErrorString(e));
+  }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  __builtin_memcpy(out_handle64, &h, 64);
+  *out_ptr = p;
+  return PARO_OK;
+}
+
+extern "C" int paro_allreduce_buffer_open(const void* handle64, void** out_ptr) {
+  using namespace paro;
+  if (!handle64 || !out_ptr) return fail(PARO_ERR_INVALID, "null pointer");
+  hipIpcMemHandle_t h;
+  __builtin_memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+  *out_ptr = p;
+  return PARO_OK;
+}
+
+extern "C" int paro_allreduce_buffer_close(void* peer_ptr) {
+  if (!peer_ptr) return PARO_OK;
+  return hipIpcCloseMemHandle(peer_ptr) == hipSuccess ? PARO_OK : paro::fail(PARO_ERR_LAUNCH, "hipIpcCloseMemHandle failed");
+}
+
+extern "C" int paro_allreduce_buffer_destroy(void* own_ptr) {
+  if (!own_ptr) return PARO_OK;
+  return hipFree(own_ptr) == hipSuccess ? PARO_OK : paro::fail(PARO_ERR_LAUNCH, "hipFree failed");
+}
+
+// Diagnostic (synchronises `stream`): PARO_OK, or PARO_ERR_LAUNCH when a call gave up waiting for a peer.
+extern "C" int paro_allreduce_status(const void* own_ptr, void* stream) {
+  using namespace paro;
+  if (!own_ptr) return fail(PARO_ERR_INVALID, "null pointer");
+  unsigned w[2] = {0u, 0u};
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemcpy(w, own_ptr, 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(PARO_ERR_LAUNCH, "all-reduce status read: %s", hipGetErrorString(e));
+  if (w[1] != 0u) return fail(PARO_ERR_LAUNCH, "one-shot all-reduce gave up waiting for a peer (epoch %u)", w[0]);
+  return PARO_OK;
 }

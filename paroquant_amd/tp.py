@@ -84,12 +84,14 @@ class OneShotAllReduce:
     buffer over xGMI, flags it, waits for the world's flags in its own buffer and sums in rank order.  No host work per
     call, so a tensor-parallel decode step stays one HIP graph whatever the collective library can or cannot capture.
 
-    The per-rank buffers are exchanged once through torch's CUDA-IPC tensor sharing over ``group`` (any backend that can
-    ``all_gather_object``: nccl or gloo).  ``self_test`` compares a few calls against ``dist.all_reduce``;
-    :func:`make_allreduce` falls back to the library collective when the exchange or the test fails."""
+    The per-rank buffers are FINE-GRAINED device memory allocated by the library (peers write into them and the owner
+    polls them inside one kernel: ordinary device memory is coherent across GPUs only at kernel boundaries) and exchanged
+    once as HIP IPC handles over ``group`` (any backend that can ``all_gather_object``: nccl or gloo).  ``self_test``
+    compares a few calls against ``dist.all_reduce``; :func:`make_allreduce` falls back to the library collective when the
+    exchange or the test fails."""
 
     def __init__(self, device, max_elems: int, group=None):
-        from torch.multiprocessing.reductions import reduce_tensor
+        import ctypes
         from . import _native as nat
         self.lib = nat.load()
         self.nat = nat
@@ -97,37 +99,58 @@ class OneShotAllReduce:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device(device)
         self.max_elems = int(max_elems)
+        self._own, self._opened = None, []
         nbytes = self.lib.paro_allreduce_buffer_bytes(self.world, self.max_elems)
         if nbytes < 0:
             raise ValueError(f"one-shot all-reduce supports up to 16 ranks and >= 8 elements (world {self.world}, {max_elems} elements)")
-        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-        torch.cuda.synchronize(self.device)
-        rebuild, args = reduce_tensor(self.buf)              # (rebuild_cuda_tensor, IPC handle + geometry)
-        gathered = [None] * self.world
-        dist.all_gather_object(gathered, args, group=group)
-        self._mapped = []                                     # the peers' buffers as mapped here: kept alive with self
-        ptrs, err = [], None
-        try:
-            for r in range(self.world):
-                if r == self.rank:
-                    ptrs.append(self.buf.data_ptr())
-                else:
-                    t = rebuild(*gathered[r])
-                    self._mapped.append(t)
-                    ptrs.append(t.data_ptr())
-            self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
-            torch.cuda.synchronize(self.device)
-        except Exception as e:                                # e.g. IPC mapping refused on this rank
-            err = e
-        # every rank runs the same collectives whatever happened locally: agree on the outcome, then raise together
+        handle, err = None, None
+        with torch.cuda.device(self.device):
+            try:
+                own = ctypes.c_void_p()
+                hbuf = ctypes.create_string_buffer(64)
+                nat.check(self.lib.paro_allreduce_buffer_create(nbytes, ctypes.byref(own), hbuf))
+                self._own, handle = own.value, hbuf.raw
+            except Exception as e:
+                err = e
+            # every rank runs the same collectives whatever happened locally: exchange, agree, then raise together
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, handle, group=group)
+            ptrs = []
+            if err is None and all(h is not None for h in gathered):
+                try:
+                    for r in range(self.world):
+                        if r == self.rank:
+                            ptrs.append(self._own)
+                        else:
+                            p = ctypes.c_void_p()
+                            nat.check(self.lib.paro_allreduce_buffer_open(gathered[r], ctypes.byref(p)))
+                            self._opened.append(p.value)
+                            ptrs.append(p.value)
+                    self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+                    torch.cuda.synchronize(self.device)
+                except Exception as e:                        # e.g. IPC mapping refused on this rank
+                    err = e
+            elif err is None:
+                err = RuntimeError("a peer could not allocate its buffer")
         if not self._agree(err is None):
-            raise RuntimeError(f"peer buffers could not be mapped on every rank (rank {self.rank}: {err})")
+            self.close()
+            raise RuntimeError(f"peer buffers could not be set up on every rank (rank {self.rank}: {err})")
         dist.barrier(group=group)                             # every buffer is zeroed and mapped before the first store lands
 
     def _agree(self, ok: bool) -> bool:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(flag.item())
+
+    def close(self) -> None:
+        """Unmap the peers' buffers and free the own one (after a barrier of the caller's: peers may still be storing)."""
+        with torch.cuda.device(self.device):
+            for p in self._opened:
+                self.lib.paro_allreduce_buffer_close(p)
+            self._opened = []
+            if self._own:
+                self.lib.paro_allreduce_buffer_destroy(self._own)
+                self._own = None
 
     def __call__(self, y: torch.Tensor) -> torch.Tensor:
         """In place, like ``dist.all_reduce``: y <- sum over ranks of y."""
@@ -140,9 +163,9 @@ class OneShotAllReduce:
         return y
 
     def gave_up(self) -> bool:
-        """True when a call timed out waiting for a peer (sticky status word; synchronises)."""
-        torch.cuda.synchronize(self.device)
-        return int(self.buf[4:8].view(torch.int32).item()) != 0
+        """True when a call timed out waiting for a peer (sticky status word; synchronises the current stream)."""
+        with torch.cuda.device(self.device):
+            return self.lib.paro_allreduce_status(self._own, self.nat.current_stream_ptr(self.device)) != 0
 
     def self_test(self, iters: int = 4) -> bool:
         """A few calls on seeded per-rank data against the library collective; every rank returns the same verdict."""
