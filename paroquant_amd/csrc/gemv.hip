@@ -74,6 +74,11 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     tpw = (tiles >= 512 && G >= 128) ? 8 : 4;
     ksplit = 4;
     waves = 8;
+    // per-rank shapes of tensor-parallel 70B-class models (tools/sweep_gemv.py --tp 4 / 8): wide enough for ~200 column
+    // blocks of 4 tiles -> no K-split (TP = 4 gate_up 8192 -> 14336: 16.9 -> 15.0 us); very narrow (TP = 8 qkv
+    // 8192 -> 1280: 80 tiles) -> 2-tile blocks, 16 waves (6.7 -> 6.0 us)
+    if (tiles >= 768 && G < 128 && rows <= 4) { tpw = 4; ksplit = 1; waves = 16; }
+    else if (tiles < 128 && rows <= 4) { tpw = 2; waves = 16; }
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj class
     tpw = 4; ksplit = 4;
     waves = G / 4 <= 8 ? 4 : 8;   // 8 groups per split: 4 waves x 2 units beat 8 x 1 (o_proj 7.0 -> 6.6 us on the same box)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--mode", default="0")
     ap.add_argument("--order", type=int, default=-1, help="wq tile order: 0 [tile][group], 1 [group][tile], -1 auto")
     ap.add_argument("--only", default="", help="comma-separated linear names to run")
+    ap.add_argument("--tp", type=int, default=1, help="per-rank shapes of a tensor-parallel split")
     ap.add_argument("--share_rot", type=int, default=0, help="1: every weight copy uses copy 0's rotation schedule and "
                     "channel scales (they stay cache resident): measures what the cold first touch of those small streams costs")
     args = ap.parse_args()
@@ -44,7 +45,7 @@ def main():
     ksps = [int(k) for k in args.ksplit.split(",")]
     wvs = [int(k) for k in args.waves.split(",")]
     modes = [int(k) for k in args.mode.split(",")]
-    for name, K, sizes, _ in layer_shapes(args.model):
+    for name, K, sizes, _ in layer_shapes(args.model, args.tp):
         nb = alg_bytes(K, sum(sizes), len(sizes))
         copies = max(2, min(48, int((1 << 30) // nb) + 1))
         if args.only and name not in args.only.split(","):
@@ -88,7 +89,7 @@ def main():
                 times[k].append(e0.elapsed_time(e1) * 1e3 / args.reps)
         for (tpw, ksp, wv, mode), ts in sorted(times.items(), key=lambda kv: np.median(kv[1])):
             us = float(np.median(ts))
-            print(json.dumps({"model": args.model, "linear": name, "K": K, "N": sum(sizes), "rows": args.rows, "tpw": tpw,
+            print(json.dumps({"model": args.model, "tp": args.tp, "linear": name, "K": K, "N": sum(sizes), "rows": args.rows, "tpw": tpw,
                               "ksplit": ksp, "waves": wv, "mode": mode, "order": packs[0].wq_order, "us": round(us, 3), "min_us": round(min(ts), 3), "GBps": round(nb / us / 1e3, 1),
                               "frac": round(nb / us / 1e3 / 8000, 4)}), flush=True)
         del graphs, packs
