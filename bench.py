@@ -425,6 +425,8 @@ def run(args, rank: int, local_rank: int, world: int):
 
     def measure():
         """Eager warm-up, HIP-graph capture of the step (when the collective allows it), timed region."""
+        if world > 1:
+            dist.barrier()                  # ranks finish building their shards seconds apart; a kernel-level collective's wait is bounded
         out = stack.step(stack.x)           # eager warm-up (also sizes the shared workspace)
         torch.cuda.synchronize(dev)
         assert torch.isfinite(out.float()).all(), "non-finite activations in the synthetic decode chain"
