@@ -306,6 +306,8 @@ int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);
  *           (paro_allreduce_buffer_create), mapped into every peer (paro_allreduce_buffer_open on the 64-byte handle);
  *           peers_dev = DEVICE array of the world's buffer addresses as mapped in the calling process, own buffer at [rank].
  *   n: elements, a multiple of 8, <= max_elems (the value the buffer was sized with).  x and y may alias.
+ *   residual: optional vector added to the sum before the one rounding (y = sum_r x_r + residual: the decoder's residual
+ *             stream after o_proj / down_proj), or NULL.
  * A peer that never arrives makes the call give up after a bounded spin: word 1 of the buffer becomes
  * PARO_WS_STATUS_GIVEUP (sticky) and the sum is garbage -- the host checks that word at teardown / after warm-up. */
 int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems);
@@ -319,8 +321,8 @@ int paro_allreduce_buffer_open(const void* handle64, void** out_ptr);
 int paro_allreduce_buffer_close(void* peer_ptr);
 int paro_allreduce_buffer_destroy(void* own_ptr);
 int paro_allreduce_status(const void* own_ptr, void* stream);
-int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act_dtype, const void* const* peers_dev, int world, int rank,
-                           int64_t max_elems, void* stream);
+int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype, const void* const* peers_dev,
+                           int world, int rank, int64_t max_elems, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,7 +185,7 @@ def load() -> ctypes.CDLL:
     lib.paro_allreduce_status.restype = c_int
     lib.paro_allreduce_status.argtypes = [c_void_p, c_void_p]
     lib.paro_allreduce_oneshot.restype = c_int
-    lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
+    lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.paro_dequant_packed.restype = c_int
     lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:

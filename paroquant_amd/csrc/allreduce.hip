@@ -21,6 +21,7 @@ constexpr int kArFlagOff = 256, kArDataOff = 4096, kArMaxWorld = 16;
 
 struct ArArgs {
   const unsigned short* x;
+  const unsigned short* residual;   // added to the sum (the decoder's residual stream), or null
   unsigned short* y;
   unsigned char* const* peers;   // device array [world]: every rank's buffer as mapped in THIS process
   int world, rank, n;
@@ -71,6 +72,14 @@ __global__ __launch_bounds__(1024) void allreduce_oneshot_kernel(const ArArgs a)
         acc[2 * e + 1] += A::to_f32(v[e] >> 16);
       }
     }
+    if (a.residual) {
+      const u32x4 rv = ((const u32x4*)a.residual)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += A::to_f32(rv[e] & 0xffffu);
+        acc[2 * e + 1] += A::to_f32(rv[e] >> 16);
+      }
+    }
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (unsigned)A::from_f32(acc[2 * e]) | ((unsigned)A::from_f32(acc[2 * e + 1]) << 16);
@@ -88,8 +97,8 @@ extern "C" int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems) {
   return paro::kArDataOff + 2 * (int64_t)world * slot;
 }
 
-extern "C" int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act_dtype, const void* const* peers_dev, int world,
-                                      int rank, int64_t max_elems, void* stream) {
+extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype,
+                                      const void* const* peers_dev, int world, int rank, int64_t max_elems, void* stream) {
   using namespace paro;
   if (!x || !y || !peers_dev) return fail(PARO_ERR_INVALID, "null pointer");
   if (world < 1 || world > kArMaxWorld || rank < 0 || rank >= world) return fail(PARO_ERR_INVALID, "bad world / rank (%d / %d)", world, rank);
@@ -97,6 +106,7 @@ extern "C" int paro_allreduce_oneshot(const void* x, void* y, int64_t n, int act
   if (act_dtype != PARO_DTYPE_F16 && act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
   ArArgs a;
   a.x = (const unsigned short*)x;
+  a.residual = (const unsigned short*)residual;
   a.y = (unsigned short*)y;
   a.peers = (unsigned char* const*)peers_dev;
   a.world = world;

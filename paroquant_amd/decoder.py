@@ -92,8 +92,18 @@ class ParoDecoderLM:
     """Greedy decoder over ParoQuant linears.  Build with :meth:`from_checkpoint` (an HF ``*-PARO`` directory,
     Llama / Qwen3 naming) or :meth:`random` (synthetic weights of a named architecture, for benchmarks)."""
 
-    def __init__(self, cfg: DecoderConfig, device, dtype=torch.float16):
+    def __init__(self, cfg: DecoderConfig, device, dtype=torch.float16, tp_rank: int = 0, tp_world: int = 1, allreduce=None):
+        """``tp_world > 1``: this object is ONE rank of a Megatron tensor-parallel model (one process per GPU): qkv / gate_up
+        column-parallel (this rank's heads and MLP columns), o / down row-parallel followed by ``allreduce(part, residual,
+        out)`` (``paroquant_amd.tp.make_allreduce``), embedding / norms / lm_head replicated; every rank computes the same
+        token (the all-reduce sums in rank order, bit-identical on all ranks)."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.tp_rank, self.tp_world, self.allreduce = int(tp_rank), int(tp_world), allreduce
+        if cfg.n_heads % self.tp_world or cfg.n_kv_heads % self.tp_world or cfg.inter % self.tp_world:
+            raise ValueError(f"heads {cfg.n_heads} / kv heads {cfg.n_kv_heads} / intermediate {cfg.inter} do not split {self.tp_world}-way")
+        self.nh, self.nkv, self.inter_l = cfg.n_heads // self.tp_world, cfg.n_kv_heads // self.tp_world, cfg.inter // self.tp_world
+        if self.tp_world > 1 and ((self.nh * cfg.head_dim) % 128 or self.inter_l % 128 or allreduce is None):
+            raise ValueError("tensor parallelism needs K slices in multiples of 128 (the rotation group) and an all-reduce")
         self.layers: List[_Layer] = []
         self.embed = self.lm_head = self.final_norm = None
         self.rope = rope_table(cfg, self.device)
@@ -102,30 +112,33 @@ class ParoDecoderLM:
     # ------------------------------------------------------------------ construction
     def _alloc_cache(self, layer: _Layer):
         c = self.cfg
-        layer.kcache = torch.zeros(c.n_kv_heads, c.max_positions, c.head_dim, dtype=self.dtype, device=self.device)
+        layer.kcache = torch.zeros(self.nkv, c.max_positions, c.head_dim, dtype=self.dtype, device=self.device)
         # V is kept position-contiguous ([head][dim][position]): the attention kernel's P V product reads it as MFMA fragments
-        layer.vcache = torch.zeros(c.n_kv_heads, c.head_dim, c.max_positions, dtype=self.dtype, device=self.device)
+        layer.vcache = torch.zeros(self.nkv, c.head_dim, c.max_positions, dtype=self.dtype, device=self.device)
 
     @classmethod
     def random(cls, name_or_cfg, device, n_layers: Optional[int] = None, max_positions: int = 1024, seed: int = 0,
-               vocab: Optional[int] = None, dtype: torch.dtype = torch.float16) -> "ParoDecoderLM":
+               vocab: Optional[int] = None, dtype: torch.dtype = torch.float16, tp_rank: int = 0, tp_world: int = 1,
+               allreduce=None) -> "ParoDecoderLM":
         import bench  # synthetic checkpoint-format layers (repo root on sys.path in tools / tests / bench)
         cfg = named_config(name_or_cfg, max_positions) if isinstance(name_or_cfg, str) else name_or_cfg
         if n_layers:
             cfg.n_layers = n_layers
         if vocab:
             cfg.vocab = vocab
-        self = cls(cfg, device, dtype)
-        gen = torch.Generator(device=self.device)
-        gen.manual_seed(seed)
-        q, kv = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
-        rnd = lambda *s: torch.randn(*s, device=self.device, generator=gen)
+        self = cls(cfg, device, dtype, tp_rank, tp_world, allreduce)
+        gen = torch.Generator(device=self.device)      # the rank's own shard of the quantised linears ...
+        gen.manual_seed(seed + 1000 * tp_rank)
+        shared = torch.Generator(device=self.device)   # ... and what every rank holds identically (norms, embedding, lm_head)
+        shared.manual_seed(seed + 77)
+        q, kv = self.nh * cfg.head_dim, self.nkv * cfg.head_dim
+        rnd = lambda *s: torch.randn(*s, device=self.device, generator=shared)
         for _ in range(cfg.n_layers):
             L = _Layer()
             L.qkv = bench.synth_packed(cfg.hidden, [q, kv, kv], self.device, gen)
             L.o = bench.synth_packed(q, [cfg.hidden], self.device, gen)
-            L.gate_up = bench.synth_packed(cfg.hidden, [cfg.inter, cfg.inter], self.device, gen)
-            L.down = bench.synth_packed(cfg.inter, [cfg.hidden], self.device, gen)
+            L.gate_up = bench.synth_packed(cfg.hidden, [self.inter_l, self.inter_l], self.device, gen)
+            L.down = bench.synth_packed(self.inter_l, [cfg.hidden], self.device, gen)
             L.in_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
             L.post_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
             L.qkv.fold_norm_weight(L.in_norm)
@@ -137,6 +150,46 @@ class ParoDecoderLM:
         self.embed = (rnd(cfg.vocab, cfg.hidden) * 0.5).to(self.dtype)
         self.lm_head = (rnd(cfg.vocab, cfg.hidden) * (cfg.hidden ** -0.5)).to(self.dtype)
         self.final_norm = (1.0 + 0.05 * rnd(cfg.hidden)).to(self.dtype)
+        self._static()
+        return self
+
+    @classmethod
+    def from_raw(cls, cfg: DecoderConfig, raw_layers, shared: Dict[str, torch.Tensor], device, dtype: torch.dtype = torch.float16,
+                 tp_rank: int = 0, tp_world: int = 1, allreduce=None) -> "ParoDecoderLM":
+        """Build from checkpoint-format tensors of the FULL model and keep this rank's Megatron shard (reference:
+        vllm/plugin.py:33-50,196-198; ``paroquant_amd.tp``).  ``raw_layers[l]`` = dict(qkv=, o=, gate_up=, down=: merged-layer
+        dicts with qweight / qzeros / scales / theta [P, krot, K/2] / pairs [P, krot, K] / channel_scales [P, 1, K] / sizes;
+        in_norm=, post_norm=, q_norm=, k_norm=); ``shared`` = dict(embed=, lm_head=, final_norm=)."""
+        from . import tp as ptp
+        self = cls(cfg, device, dtype, tp_rank, tp_world, allreduce)
+        dev = self.device
+        tt = lambda v: v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+
+        def pack(d, kind):
+            lay = {k: tt(d[k]) for k in ("qweight", "qzeros", "scales", "theta", "pairs", "channel_scales")}
+            sizes = list(d["sizes"])
+            if tp_world > 1:
+                if kind == "col":
+                    lay = ptp.shard_column_parallel({**lay, "bias": None}, sizes, tp_rank, tp_world)
+                    sizes = [n // tp_world for n in sizes]
+                else:
+                    lay = ptp.shard_row_parallel({**lay, "bias": None}, tp_rank, tp_world)
+            return PackedParoWeights(lay["qweight"].to(dev), lay["qzeros"].to(dev), lay["scales"].to(dev), lay["theta"].to(dev),
+                                     lay["pairs"].to(dev), lay["channel_scales"].to(dev), sizes)
+
+        for r in raw_layers:
+            L = _Layer()
+            L.qkv, L.o = pack(r["qkv"], "col"), pack(r["o"], "row")
+            L.gate_up, L.down = pack(r["gate_up"], "col"), pack(r["down"], "row")
+            L.in_norm, L.post_norm = tt(r["in_norm"]).to(dev, dtype), tt(r["post_norm"]).to(dev, dtype)
+            L.qkv.fold_norm_weight(L.in_norm)
+            L.gate_up.fold_norm_weight(L.post_norm)
+            L.q_norm = tt(r["q_norm"]).to(dev, dtype) if r.get("q_norm") is not None else None
+            L.k_norm = tt(r["k_norm"]).to(dev, dtype) if r.get("k_norm") is not None else None
+            self._alloc_cache(L)
+            self.layers.append(L)
+        self.embed, self.lm_head = tt(shared["embed"]).to(dev, dtype), tt(shared["lm_head"]).to(dev, dtype)
+        self.final_norm = tt(shared["final_norm"]).to(dev, dtype)
         self._static()
         return self
 
@@ -199,15 +252,16 @@ class ParoDecoderLM:
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)       # its position
         self.h = torch.zeros(1, c.hidden, dtype=dt, device=dev)        # residual stream (ping)
         self.h2 = torch.zeros(1, c.hidden, dtype=dt, device=dev)       # residual stream (pong)
-        qkv_w = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim
+        qkv_w = (self.nh + 2 * self.nkv) * c.head_dim
         self.qkv_buf = torch.zeros(1, qkv_w, dtype=dt, device=dev)
-        self.attn_buf = torch.zeros(1, c.n_heads * c.head_dim, dtype=dt, device=dev)
-        self.gu_buf = torch.zeros(1, 2 * c.inter, dtype=dt, device=dev)
+        self.attn_buf = torch.zeros(1, self.nh * c.head_dim, dtype=dt, device=dev)
+        self.gu_buf = torch.zeros(1, 2 * self.inter_l, dtype=dt, device=dev)
+        self.part = torch.zeros(1, c.hidden, dtype=dt, device=dev)     # this rank's partial sum of a row-parallel linear (TP)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
         # different streams at the same time and must not share tickets
-        self.attn_ws = torch.zeros(nat.load().paro_attn_decode_workspace_bytes(c.n_heads, c.n_kv_heads, c.head_dim, c.max_positions),
+        self.attn_ws = torch.zeros(nat.load().paro_attn_decode_workspace_bytes(self.nh, self.nkv, c.head_dim, c.max_positions),
                                    dtype=torch.uint8, device=dev)
         self.lm_ws = ops.lm_head_workspace(dev, c.vocab)
         self.lm_head = self.lm_head.contiguous()
@@ -226,11 +280,18 @@ class ParoDecoderLM:
         h, h2 = self.h, self.h2
         for L in self.layers:
             ops.w4a16_gemv_fused(h, L.qkv, R, c.rms_eps, out=self.qkv_buf)
-            ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, c.n_heads, c.n_kv_heads, c.head_dim,
+            ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv, c.head_dim,
                             L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws)
-            ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                     # h2 = h + o(attn)
-            ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
-            ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                    # h = h2 + down(act)
+            if self.tp_world == 1:
+                ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                 # h2 = h + o(attn)
+                ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
+                ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                # h = h2 + down(act)
+            else:   # row-parallel o / down: partial sums, one all-reduce each with the residual added in its summation
+                ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, out=self.part)
+                self.allreduce(self.part, residual=h, out=h2)
+                ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
+                ops.w4a16_gemv_fused(self.gu_buf, L.down, S, out=self.part)
+                self.allreduce(self.part, residual=h2, out=h)
         if self.fused_tail:
             ops.lm_head(h, self.final_norm, self.lm_head, self.logits, c.rms_eps, self.lm_ws)
             ops.argmax_advance(self.lm_ws, c.vocab, self.tok, self.pos, self.out_tokens)
@@ -268,6 +329,16 @@ class ParoDecoderLM:
         T = int(ids.numel())
         if T > c.max_positions:
             raise ValueError("prompt longer than max_positions")
+        if self.tp_world > 1:
+            # tensor-parallel ranks take the prompt through the decode step, one teacher-forced token at a time (every rank
+            # the same launches, so the kernel-level all-reduces pair up); a sharded prefill GEMM path is not built
+            ids_d = ids.to(self.device)
+            for i in range(T):
+                self.tok.copy_(ids_d[i:i + 1])
+                self.pos.fill_(i)
+                self.decode_step()
+            self.out_tokens[:T] = ids_d
+            return self.logits.clone()                 # tok / pos already hold the first generated token and T
         h = self.embed[ids.to(self.device)]                                           # [T, hidden]
         rs = lambda x: torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + c.rms_eps)
         half = c.head_dim // 2

@@ -10,7 +10,7 @@ dim by ``tp_rank`` exactly as ``_maybe_shard_input`` does.
 """
 from __future__ import annotations
 
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -152,15 +152,20 @@ class OneShotAllReduce:
                 self.lib.paro_allreduce_buffer_destroy(self._own)
                 self._own = None
 
-    def __call__(self, y: torch.Tensor) -> torch.Tensor:
-        """In place, like ``dist.all_reduce``: y <- sum over ranks of y."""
+    def __call__(self, y: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``out <- sum over ranks of y (+ residual)``; ``out`` defaults to ``y`` (in place, like ``dist.all_reduce``)."""
         n = y.numel()
+        out = y if out is None else out
         if not y.is_contiguous() or y.dtype not in (torch.float16, torch.bfloat16) or n % 8 or n > self.max_elems:
             raise ValueError(f"one-shot all-reduce takes contiguous fp16 / bf16 vectors of a multiple of 8 up to {self.max_elems} elements")
+        if out.numel() != n or out.dtype != y.dtype or not out.is_contiguous() or \
+                (residual is not None and (residual.numel() != n or residual.dtype != y.dtype or not residual.is_contiguous())):
+            raise ValueError("residual / out must match y (contiguous, same dtype and size)")
         with torch.cuda.device(y.device):
-            self.nat.check(self.lib.paro_allreduce_oneshot(y.data_ptr(), y.data_ptr(), n, self.nat.dtype_code(y.dtype), self.peers.data_ptr(),
-                                                           self.world, self.rank, self.max_elems, self.nat.current_stream_ptr(y.device)))
-        return y
+            self.nat.check(self.lib.paro_allreduce_oneshot(y.data_ptr(), None if residual is None else residual.data_ptr(), out.data_ptr(), n,
+                                                           self.nat.dtype_code(y.dtype), self.peers.data_ptr(), self.world, self.rank,
+                                                           self.max_elems, self.nat.current_stream_ptr(y.device)))
+        return out
 
     def gave_up(self) -> bool:
         """True when a call timed out waiting for a peer (sticky status word; synchronises the current stream)."""
@@ -192,7 +197,15 @@ class OneShotAllReduce:
 def make_allreduce(device, max_elems: int, group=None, prefer_oneshot: bool = True):
     """``(fn, name)``: the in-place all-reduce a tensor-parallel decode step should use -- the one-shot kernel when it can
     be set up and passes its self-test on every rank, else ``dist.all_reduce`` (RCCL under the nccl backend)."""
-    fallback = (lambda y: (dist.all_reduce(y, group=group), y)[1]), dist.get_backend(group)
+    def _library(y, residual=None, out=None):
+        dist.all_reduce(y, group=group)
+        if residual is not None:
+            y = torch.add(y, residual, out=out if out is not None else y)
+        elif out is not None and out is not y:
+            out.copy_(y)
+            y = out
+        return y
+    fallback = _library, dist.get_backend(group)
     if not prefer_oneshot or dist.get_world_size(group) == 1:
         return fallback
     try:

@@ -1387,3 +1387,17 @@ def test_oneshot_allreduce_ranks_share_one_gpu(dev, world):
                           "--master-port", str(29600 + world), os.path.join(root, "tests", "_oneshot_worker.py")],
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONESHOT_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_decoder_ranks_share_one_gpu(dev, world):
+    """The end-to-end decode harness tensor-parallel (heads and MLP columns sharded, one-shot all-reduce with the residual
+    added in its summation after o / down): logits and greedy tokens of the unsharded model, eager and from a HIP graph."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29620 + world), os.path.join(root, "tests", "_tp_decoder_worker.py")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "TP_DECODER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
