@@ -97,16 +97,19 @@ def synth_pairs(rng: np.random.Generator, krot: int, K: int) -> np.ndarray:
     return out.reshape(krot, K)
 
 
-def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None):
+def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None, gain_k: int = 0):
     """Random layer in checkpoint format (SURVEY section 8d synthetic inputs), unit gain, repacked by the
-    product path (torch.ops.paro.repack_awq)."""
+    product path (torch.ops.paro.repack_awq).  `gain_k`: the in_features the gain is normalised for -- the FULL K for a
+    row-parallel shard, whose tp partial outputs are summed by the all-reduce (unit gain after the sum, as in a real shard)."""
     from paroquant_amd.linear import PackedParoWeights
     N = sum(sizes)
     P = len(sizes)
     G = K // 128
     qweight = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
     qzeros = torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
-    gain = 1.0 / (6.52 * (K ** 0.5) * (1.75 ** 0.5))        # unit RMS gain through rotate + dequant matmul
+    # unit RMS gain through rotate + dequant matmul: E[(w - z)^2] = 42.5 = 6.52^2, E[cs^2] = 1.75, E[(u + 0.5)^2] = 13/12 --
+    # exact enough that 80 layers (320 chained linears, llama3-70b) stay inside fp16
+    gain = 1.0 / (6.52 * ((gain_k or K) ** 0.5) * (1.75 ** 0.5) * ((13.0 / 12.0) ** 0.5))
     scales = ((torch.rand(G, N, device=dev, generator=gen) + 0.5) * gain).half()
     theta = (torch.randn(P, 8, K // 2, device=dev, generator=gen) * 0.1).half()
     rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=dev).item()))
@@ -130,7 +133,7 @@ class DecodeStack:
         self.shapes = layer_shapes(model, tp)
         self.layers = []
         for _ in range(self.n_layers):
-            self.layers.append([synth_packed(K, sizes, dev, gen) for (_, K, sizes, _) in self.shapes])
+            self.layers.append([synth_packed(K, sizes, dev, gen, gain_k=K * tp if kind == "row" else 0) for (_, K, sizes, kind) in self.shapes])
         self.x = torch.randn(1, h, device=dev, dtype=torch.float16, generator=gen)
         self.launches_per_step = 4 * self.n_layers
         self.bytes_per_step = self.n_layers * sum(alg_bytes(K, sum(s), len(s)) for (_, K, s, _) in self.shapes)
@@ -264,7 +267,8 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
     return out
 
 
-def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5, warmup: int = 2):
+def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5, warmup: int = 2,
+               tp_rank: int = 0, tp_world: int = 1, allreduce=None):
     """End-to-end batch-1 greedy decode of the whole model on the fused harness (paroquant_amd/decoder.py: five launches
     per layer + final norm / lm_head / argmax, one HIP graph per token), with the reference's benchmark protocol
     (cli/benchmark.py:8-26: 2 warm-up + 5 runs, 128 new tokens; inference/base.py:62-77: tps = decode tokens /
@@ -272,8 +276,8 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     from paroquant_amd.decoder import MODEL_CONFIGS, ParoDecoderLM
     if model not in MODEL_CONFIGS:
         return None
-    lm = ParoDecoderLM.random(model, dev, max_positions=prompt + new + 8)
-    ids = torch.randint(0, lm.cfg.vocab, (prompt,), device=dev)
+    lm = ParoDecoderLM.random(model, dev, max_positions=prompt + new + 8, tp_rank=tp_rank, tp_world=tp_world, allreduce=allreduce)
+    ids = torch.randint(0, lm.cfg.vocab, (prompt,), device=dev, generator=torch.Generator(device=dev).manual_seed(11))  # same prompt on every rank
     stats = []
     for i in range(warmup + runs):
         _, st = lm.generate(ids, new)
@@ -285,7 +289,8 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     return {"value": round(tps, 1), "unit": "tokens/s", "ms_per_token": round(ms, 4),
             "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
             "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
-            "launches_per_token": 5 * lm.cfg.n_layers + 3,
+            "launches_per_token": (5 if tp_world == 1 else 7) * lm.cfg.n_layers + 3,
+            "parallelism": f"tp{tp_world}" + (" (bytes_per_token and GBps are per rank)" if tp_world > 1 else ""),
             "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),
             "GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),
             "note": "whole model: fused GEMVs (RMSNorm / SiLU*mul / residual fused), decode attention with KV cache, fp16 lm_head"}
@@ -534,6 +539,19 @@ def run(args, rank: int, local_rank: int, world: int):
                 ref = {"error": f"{type(e).__name__}: {e}"}
         dist.barrier()
         result["config"]["tp1_reference"] = ref
+        # the whole model tensor-parallel on the fused harness (attention heads sharded, residual added inside the one-shot
+        # all-reduce): every rank runs it, never fatal for the contract line; a one-shot that gave up is reported, not hidden
+        if not args.no_e2e and allreduce_name == "oneshot" and stack.n_layers == MODELS[model][4]:
+            del stack
+            torch.cuda.empty_cache()
+            try:
+                e2e = end_to_end(model, dev, tp_rank=rank, tp_world=world, allreduce=allreduce)
+                if e2e is not None and allreduce.gave_up():
+                    e2e = {"error": "the one-shot all-reduce timed out waiting for a peer during the end-to-end leg"}
+            except Exception as e:
+                e2e = {"error": f"{type(e).__name__}: {e}"}
+            result["end_to_end"] = e2e
+            stack = None
 
     if rank == 0:
         if args.per_shape:
@@ -543,7 +561,7 @@ def run(args, rank: int, local_rank: int, world: int):
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
         else:
             result["cpu_baseline"] = None
-        if not args.no_e2e and world == 1 and not tp_mode and stack.n_layers == MODELS[model][4]:
+        if not args.no_e2e and world == 1 and not tp_mode and stack is not None and stack.n_layers == MODELS[model][4]:
             del stack
             torch.cuda.empty_cache()
             try:

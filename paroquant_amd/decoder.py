@@ -67,6 +67,7 @@ MODEL_CONFIGS = {
     "qwen3-0.6b": (1024, 3072, 16, 8, 128, 28, 151936, True, 1e6),
     "qwen3-4b": (2560, 9728, 32, 8, 128, 36, 151936, True, 1e6),
     "llama3-8b": (4096, 14336, 32, 8, 128, 32, 128256, False, 5e5),
+    "llama3-70b": (8192, 28672, 64, 8, 128, 80, 128256, False, 5e5),
 }
 
 

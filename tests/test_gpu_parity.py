@@ -1373,6 +1373,22 @@ def test_tp_bench_path_on_one_gpu(dev, world, workload):
     assert r2["config"]["allreduce"] == "gloo" and r2["config"]["hip_graph"] is False
 
 
+def test_tp_bench_end_to_end_leg(dev):
+    """At full depth the TP bench also reports the whole model tensor-parallel on the fused harness (`end_to_end`, tp2)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "qwen3-0.6b-tp", "--tp-backend", "gloo", "--same-device",
+                          "--steps", "3", "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    e = r["end_to_end"]
+    assert "error" not in e, e
+    assert e["value"] > 0 and e["parallelism"].startswith("tp2") and e["launches_per_token"] == 7 * 28 + 3
+
+
 # ---------------------------------------------------------------- e: one-shot all-reduce of the row-parallel outputs
 
 @pytest.mark.parametrize("world", [2, 4])
