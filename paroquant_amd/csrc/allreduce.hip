@@ -155,6 +155,23 @@ extern "C" int paro_allreduce_buffer_open(const void* handle64, void** out_ptr) 
   void* p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return fail(PARO_ERR_LAUNCH, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+  // Probe the mapping before any kernel touches it (a kernel store through a dead mapping is a fatal memory fault; the host
+  // sees an error code instead and the caller falls back to the library collective): the owning device must be peer-
+  // accessible from the current one, and a 4-byte read of the (read-only here) status word must come back.
+  int cur = -1;
+  hipPointerAttribute_t attr;
+  bool ok = hipGetDevice(&cur) == hipSuccess && hipPointerGetAttributes(&attr, p) == hipSuccess;
+  if (ok && attr.device != cur) {
+    int can = 0;
+    ok = hipDeviceCanAccessPeer(&can, cur, attr.device) == hipSuccess && can != 0;
+  }
+  unsigned probe = 0;
+  ok = ok && hipMemcpy(&probe, static_cast<const char*>(p) + 4, 4, hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    (void)hipIpcCloseMemHandle(p);
+    return fail(PARO_ERR_LAUNCH, "peer buffer is not accessible from device %d", cur);
+  }
   *out_ptr = p;
   return PARO_OK;
 }

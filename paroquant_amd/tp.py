@@ -196,7 +196,12 @@ class OneShotAllReduce:
 
 def make_allreduce(device, max_elems: int, group=None, prefer_oneshot: bool = True):
     """``(fn, name)``: the in-place all-reduce a tensor-parallel decode step should use -- the one-shot kernel when it can
-    be set up and passes its self-test on every rank, else ``dist.all_reduce`` (RCCL under the nccl backend)."""
+    be set up and passes its self-test on every rank, else ``dist.all_reduce`` (RCCL under the nccl backend).
+    ``PARO_ONESHOT=0`` in the environment forces the library collective (operator override; set it on every rank)."""
+    import os
+    if os.environ.get("PARO_ONESHOT", "1") == "0":
+        prefer_oneshot = False
+
     def _library(y, residual=None, out=None):
         dist.all_reduce(y, group=group)
         if residual is not None:
