@@ -28,6 +28,7 @@ from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 
 from . import _native as nat
 from . import ops
@@ -100,6 +101,7 @@ class ParoDecoderLM:
         token (the all-reduce sums in rank order, bit-identical on all ranks)."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.tp_rank, self.tp_world, self.allreduce = int(tp_rank), int(tp_world), allreduce
+        self.tp_group = getattr(allreduce, "group", None)       # the prefill's [T, hidden] all-reduce goes through the process group
         if cfg.n_heads % self.tp_world or cfg.n_kv_heads % self.tp_world or cfg.inter % self.tp_world:
             raise ValueError(f"heads {cfg.n_heads} / kv heads {cfg.n_kv_heads} / intermediate {cfg.inter} do not split {self.tp_world}-way")
         self.nh, self.nkv, self.inter_l = cfg.n_heads // self.tp_world, cfg.n_kv_heads // self.tp_world, cfg.inter // self.tp_world
@@ -330,9 +332,10 @@ class ParoDecoderLM:
         T = int(ids.numel())
         if T > c.max_positions:
             raise ValueError("prompt longer than max_positions")
-        if self.tp_world > 1:
-            # tensor-parallel ranks take the prompt through the decode step, one teacher-forced token at a time (every rank
-            # the same launches, so the kernel-level all-reduces pair up); a sharded prefill GEMM path is not built
+        sharded = self.tp_world > 1
+        if sharded and not (dist.is_available() and dist.is_initialized()):
+            # no process group to all-reduce [T, hidden] over (the decode step's kernel-level collective is sized for one
+            # row): take the prompt through the decode step, one teacher-forced token at a time
             ids_d = ids.to(self.device)
             for i in range(T):
                 self.tok.copy_(ids_d[i:i + 1])
@@ -340,6 +343,11 @@ class ParoDecoderLM:
                 self.decode_step()
             self.out_tokens[:T] = ids_d
             return self.logits.clone()                 # tok / pos already hold the first generated token and T
+
+        def reduce_rows(part):                         # RowParallelLinear's all-reduce of [T, hidden] (RCCL / the group's backend)
+            if sharded:
+                dist.all_reduce(part, group=self.tp_group)
+            return part
         h = self.embed[ids.to(self.device)]                                           # [T, hidden]
         rs = lambda x: torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + c.rms_eps)
         half = c.head_dim // 2
@@ -355,19 +363,19 @@ class ParoDecoderLM:
 
         for L in self.layers:
             qkv = (L.qkv.apply(h).float() * rs(h)).to(dt)          # norm weight is folded into the channel scales
-            q, k, v = qkv.split([c.n_heads * c.head_dim, c.n_kv_heads * c.head_dim, c.n_kv_heads * c.head_dim], dim=-1)
-            q = rope(headnorm(q.view(T, c.n_heads, c.head_dim), L.q_norm))
-            k = rope(headnorm(k.view(T, c.n_kv_heads, c.head_dim), L.k_norm))
-            v = v.view(T, c.n_kv_heads, c.head_dim)
+            q, k, v = qkv.split([self.nh * c.head_dim, self.nkv * c.head_dim, self.nkv * c.head_dim], dim=-1)   # this rank's heads
+            q = rope(headnorm(q.view(T, self.nh, c.head_dim), L.q_norm))
+            k = rope(headnorm(k.view(T, self.nkv, c.head_dim), L.k_norm))
+            v = v.view(T, self.nkv, c.head_dim)
             L.kcache[:, :T] = k.transpose(0, 1)
             L.vcache[:, :, :T] = v.permute(1, 2, 0)
             att = torch.nn.functional.scaled_dot_product_attention(
                 q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None], is_causal=True,
-                enable_gqa=c.n_heads != c.n_kv_heads)[0].transpose(0, 1).reshape(T, -1)
-            h = h + L.o.apply(att.contiguous())
+                enable_gqa=self.nh != self.nkv)[0].transpose(0, 1).reshape(T, -1)
+            h = h + reduce_rows(L.o.apply(att.contiguous()))
             gu = (L.gate_up.apply(h).float() * rs(h)).to(dt)
-            act = torch.nn.functional.silu(gu[:, :c.inter]) * gu[:, c.inter:]
-            h = h + L.down.apply(act.contiguous())
+            act = torch.nn.functional.silu(gu[:, :self.inter_l]) * gu[:, self.inter_l:]
+            h = h + reduce_rows(L.down.apply(act.contiguous()))
         logits = torch.matmul(self._final_norm(h[-1:]), self.lm_head.t())
         self.out_tokens[:T] = ids.to(self.device)
         self.tok.copy_(torch.argmax(logits, dim=-1))

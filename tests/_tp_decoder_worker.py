@@ -52,6 +52,11 @@ def main():
     err = float((lg_tp - lg_ref).abs().max()) / float(lg_ref.abs().max())
     assert err < 2e-2, err                                   # row-parallel partial sums are rounded per rank before the all-reduce
     assert tk_tp == tk_ref, (tk_tp, tk_ref)
+    # the sharded prefill (local heads / MLP columns through the GEMM path, [T, hidden] all-reduced over the process group)
+    pl_tp, pl_ref = lm_tp.prefill(ids).float(), lm_ref.prefill(ids).float()
+    perr = float((pl_tp - pl_ref).abs().max()) / float(pl_ref.abs().max())
+    assert perr < 2e-2, perr
+    assert int(lm_tp.tok.item()) == int(lm_ref.tok.item()) and int(lm_tp.pos.item()) == int(ids.numel())
     # every rank holds the same tokens, and the captured graph replays the same sequence
     gathered = [None] * world
     dist.all_gather_object(gathered, tk_tp)
