@@ -4,97 +4,102 @@
 // all-reduce is tens of microseconds, 160 of them per 70B-class token.
 //
 // Every rank owns one buffer (mapped into all peers through HIP IPC by the caller):
-//   [0]                     u32 epoch of the last completed call          [4] u32 status (0 / PARO_WS_STATUS_GIVEUP)
-//   [256 + (set, r) * 64]   u32 flag: rank r's data of epoch e has landed in slot (set, r)            set = e & 1
-//   [4096 + (set, r) * S]   slot: rank r's partial vector of that epoch
-// One call = one launch of one workgroup:  write my vector into slot (set, me) of EVERY rank's buffer (plain stores over
-// xGMI) -> system-scope release -> barrier -> store epoch into flag (set, me) of every rank -> spin on my own flags
-// (bounded) -> system-scope acquire -> sum the world slots in rank order in fp32 (bit-identical on every rank) -> epoch.
-// Two slot sets suffice: a rank cannot enter call e + 2 before every peer has flagged e + 1, which a peer only does once
-// it has finished summing call e.  Nothing on the host side: the launch is HIP-graph capturable, the epoch lives in the
-// buffer.
+//   [4]                     u32 status (0 / PARO_WS_STATUS_GIVEUP)
+//   [64 + 4 * wg]           u32 epoch of workgroup wg's last completed call
+//   [4096 + (set, r) * S]   slot of rank r: 8-byte granules {two activations, u32 epoch tag}             set = epoch & 1
+// The data IS the flag (the K-split hand-off's recipe, gemv_impl.hpp, stretched over the links): a rank stores each pair
+// of activations together with the call's epoch as ONE 8-byte system-scope store into its slot in every peer, and polls
+// the granules of its own buffer until their tags read the epoch.  No fence, no flag round trip, no barrier on the data
+// path: the latency of a call is one store flight plus the polls.  Every thread owns one granule, a launch is
+// ceil(n / 2048) workgroups, each with its own epoch word (all ranks pass the same n, so the words agree across ranks).
+// The world's values are summed in rank order in fp32 -- bit-identical on every rank.  Two slot sets suffice: a rank
+// cannot enter call e + 2 before every peer's granules of e + 1 have arrived, which a peer only sends once it has
+// finished summing call e.  Nothing on the host side: the launch is HIP-graph capturable, the epochs live in the buffer.
 #include "common.hpp"
 
 namespace paro {
 
-constexpr int kArFlagOff = 256, kArDataOff = 4096, kArMaxWorld = 16;
+constexpr int kArEpochOff = 64, kArDataOff = 4096, kArMaxWorld = 16, kArThreads = 1024;
+constexpr int kArMaxWgs = (kArDataOff - kArEpochOff) / 4;
 
 struct ArArgs {
-  const unsigned short* x;
-  const unsigned short* residual;   // added to the sum (the decoder's residual stream), or null
-  unsigned short* y;
+  const unsigned* x;             // two activations per word
+  const unsigned* residual;      // added to the sum (the decoder's residual stream), or null
+  unsigned* y;
   unsigned char* const* peers;   // device array [world]: every rank's buffer as mapped in THIS process
-  int world, rank, n;
-  long long slot_bytes;
+  int world, rank, ng;           // ng = granules = n / 2
+  long long slot_granules;
   int spin_limit;
 };
 
 template <typename AT>
-__global__ __launch_bounds__(1024) void allreduce_oneshot_kernel(const ArArgs a) {
+__global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArArgs a) {
   typedef Act<AT> A;
   const int tid = threadIdx.x;
+  const int g = blockIdx.x * kArThreads + tid;
   unsigned char* mine = a.peers[a.rank];
-  const unsigned epoch = __hip_atomic_load((const unsigned*)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-  const int set = (int)(epoch & 1u);
-  const int nv = a.n >> 3;   // 16-byte vectors
-  // 1. my partial vector into slot (set, rank) of every rank
-  for (int p = 0; p < a.world; ++p) {
-    u32x4* dst = (u32x4*)(a.peers[p] + kArDataOff + (long long)(set * a.world + a.rank) * a.slot_bytes);
-    for (int i = tid; i < nv; i += 1024) dst[i] = ((const u32x4*)a.x)[i];
-  }
-  // 2. every thread's stores are out system-wide before anyone raises a flag
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  __syncthreads();
-  if (tid < a.world)
-    __hip_atomic_store((unsigned*)(a.peers[tid] + kArFlagOff + (set * a.world + a.rank) * 64), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // 3. all ranks' data of this epoch has landed here
-  if (tid < a.world) {
-    const unsigned* f = (const unsigned*)(mine + kArFlagOff + (set * a.world + tid) * 64);
-    // fast polls first (the common case: the peers are a few microseconds apart), then ~1 us naps: ranks may be far apart
-    // once (a peer still capturing its graph while this one already replays), so the bound is seconds, not milliseconds
-    int spin = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch && spin < a.spin_limit) {
+  unsigned* my_epoch = (unsigned*)(mine + kArEpochOff) + blockIdx.x;
+  unsigned epoch = __hip_atomic_load(my_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  if (epoch == 0u) epoch = 2u;        // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
+  const long long slot0 = (long long)((int)(epoch & 1u) * a.world) * a.slot_granules;
+  if (g < a.ng) {
+    const unsigned mydata = a.x[g];
+    const unsigned long long gran = ((unsigned long long)epoch << 32) | mydata;
+    // 1. my granule into slot (set, rank) of every peer: one 8-byte store each, data and tag together
+    for (int p = 0; p < a.world; ++p) {
+      if (p == a.rank) continue;
+      unsigned long long* dst = (unsigned long long*)(a.peers[p] + kArDataOff) + slot0 + (long long)a.rank * a.slot_granules + g;
+      __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned res = a.residual ? a.residual[g] : 0u;
+    // 2. the peers' granules of this epoch: every poll of a round is issued before any is looked at; fast polls first
+    // (the common case: the peers are a few microseconds apart), then ~1 us naps -- ranks may be far apart once (a peer
+    // still capturing its graph while this one already replays), so the bound is seconds, not milliseconds
+    const unsigned long long* src = (const unsigned long long*)(mine + kArDataOff) + slot0 + g;
+    unsigned long long got[kArMaxWorld];
+    bool all = false;
+    for (int spin = 0; !all; ++spin) {
+#pragma unroll
+      for (int r = 0; r < kArMaxWorld; ++r)
+        if (r < a.world && r != a.rank) got[r] = __hip_atomic_load(src + (long long)r * a.slot_granules, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      all = true;
+#pragma unroll
+      for (int r = 0; r < kArMaxWorld; ++r)
+        if (r < a.world && r != a.rank) all = all && (unsigned)(got[r] >> 32) == epoch;
+      if (all) break;
+      if (spin >= a.spin_limit) {
+        ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
+        break;
+      }
       if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
-      ++spin;
     }
-    if (spin >= a.spin_limit) ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  // 4. sum in rank order (the same order on every rank: bit-identical results)
-  for (int i = tid; i < nv; i += 1024) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < a.world; ++r) {
-      const u32x4 v = *(const u32x4*)(mine + kArDataOff + (long long)(set * a.world + r) * a.slot_bytes + (long long)i * 16);
+    // 3. sum in rank order (the same order on every rank: bit-identical results), one rounding
+    float lo = 0.f, hi = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] += A::to_f32(v[e] & 0xffffu);
-        acc[2 * e + 1] += A::to_f32(v[e] >> 16);
+    for (int r = 0; r < kArMaxWorld; ++r)
+      if (r < a.world) {
+        const unsigned v = r == a.rank ? mydata : (unsigned)got[r];
+        lo += A::to_f32(v & 0xffffu);
+        hi += A::to_f32(v >> 16);
       }
-    }
     if (a.residual) {
-      const u32x4 rv = ((const u32x4*)a.residual)[i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] += A::to_f32(rv[e] & 0xffffu);
-        acc[2 * e + 1] += A::to_f32(rv[e] >> 16);
-      }
+      lo += A::to_f32(res & 0xffffu);
+      hi += A::to_f32(res >> 16);
     }
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (unsigned)A::from_f32(acc[2 * e]) | ((unsigned)A::from_f32(acc[2 * e + 1]) << 16);
-    ((u32x4*)a.y)[i] = o;
+    a.y[g] = (unsigned)A::from_f32(lo) | ((unsigned)A::from_f32(hi) << 16);
   }
-  // 5. this call is complete (every thread read the epoch before the first barrier)
-  if (tid == 0) __hip_atomic_store((unsigned*)mine, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // 4. this workgroup's call is complete (every wave read the epoch word before it arrives here)
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(my_epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+static long long ar_slot_granules(int64_t max_elems) { return ((max_elems / 2 + 31) / 32) * 32; }
 
 }  // namespace paro
 
 extern "C" int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems) {
-  if (world < 1 || world > paro::kArMaxWorld || max_elems < 8) return -1;
-  const int64_t slot = ((max_elems * 2 + 255) / 256) * 256;
-  return paro::kArDataOff + 2 * (int64_t)world * slot;
+  if (world < 1 || world > paro::kArMaxWorld || max_elems < 8 || max_elems > (int64_t)paro::kArMaxWgs * paro::kArThreads * 2) return -1;
+  return paro::kArDataOff + 2 * (int64_t)world * paro::ar_slot_granules(max_elems) * 8;
 }
 
 extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype,
@@ -102,23 +107,25 @@ extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void*
   using namespace paro;
   if (!x || !y || !peers_dev) return fail(PARO_ERR_INVALID, "null pointer");
   if (world < 1 || world > kArMaxWorld || rank < 0 || rank >= world) return fail(PARO_ERR_INVALID, "bad world / rank (%d / %d)", world, rank);
+  if (max_elems > (int64_t)kArMaxWgs * kArThreads * 2) return fail(PARO_ERR_INVALID, "max_elems out of range");
   if (n < 8 || n % 8 != 0 || n > max_elems) return fail(PARO_ERR_INVALID, "element count must be a multiple of 8 in 8..%lld (got %lld)", (long long)max_elems, (long long)n);
   if (act_dtype != PARO_DTYPE_F16 && act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
   ArArgs a;
-  a.x = (const unsigned short*)x;
-  a.residual = (const unsigned short*)residual;
-  a.y = (unsigned short*)y;
+  a.x = (const unsigned*)x;
+  a.residual = (const unsigned*)residual;
+  a.y = (unsigned*)y;
   a.peers = (unsigned char* const*)peers_dev;
   a.world = world;
   a.rank = rank;
-  a.n = (int)n;
-  a.slot_bytes = ((max_elems * 2 + 255) / 256) * 256;
+  a.ng = (int)(n / 2);
+  a.slot_granules = ar_slot_granules(max_elems);
   a.spin_limit = 1 << 22;   // ~4 s of ~1 us naps (callers barrier before phases in which ranks can be seconds apart)
   hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((a.ng + kArThreads - 1) / kArThreads);
   if (act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL(allreduce_oneshot_kernel<f16>, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(allreduce_oneshot_kernel<f16>, grid, dim3(kArThreads), 0, st, a);
   else
-    hipLaunchKernelGGL(allreduce_oneshot_kernel<bf16>, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(allreduce_oneshot_kernel<bf16>, grid, dim3(kArThreads), 0, st, a);
   return check_launch("paro_allreduce_oneshot");
 }
 
