@@ -72,5 +72,7 @@ if [ -f paroquant_amd/_lib_diag/libparo_mi355x.so ]; then
     PARO_LIB_DIR=_lib_diag PARO_GEMV_PD=31 timeout 100 python tools/timeline_gemv.py --model qwen3-4b --linear $1 --tpw $2 --waves $3 2>> $OUT/vendor.err | grep -v amdgpu.ids >> $P/${R}_gemv_timeline.txt
   done
 fi
+# ---- tensor parallel: what one rank of llama3-70b costs per token at TP = 1 / 2 / 4 / 8 (upper bound of the node's tokens/s)
+timeout 400 python tools/tp_rank_projection.py 2>> $OUT/vendor.err | grep '^{' > $P/${R}_tp_rank_projection.jsonl
 mkdir -p $ROOT/gpurun_out/$R/profiles_copy && cp $P/${R}_* $ROOT/gpurun_out/$R/profiles_copy/
 tail -1 $P/${R}_bench_qwen3-4b.jsonl | cut -c1-400; head -1 $P/${R}_bench_qwen3-4b.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['roofline'], d.get('end_to_end'), d.get('cpu_baseline'))"
