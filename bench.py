@@ -445,7 +445,7 @@ def run(args, rank: int, local_rank: int, world: int):
                     stack.step(stack.x)
                 torch.cuda.current_stream(dev).wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
                     stack.step(stack.x)
                 graph.replay()
                 torch.cuda.synchronize(dev)

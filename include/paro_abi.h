@@ -309,7 +309,8 @@ int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);
  *   residual: optional vector added to the sum before the one rounding (y = sum_r x_r + residual: the decoder's residual
  *             stream after o_proj / down_proj), or NULL.
  * A peer that never arrives makes the call give up after a bounded spin: word 1 of the buffer becomes
- * PARO_WS_STATUS_GIVEUP (sticky) and the sum is garbage -- the host checks that word at teardown / after warm-up. */
+ * PARO_WS_STATUS_GIVEUP (sticky) and the sum is garbage -- the host checks that word at teardown / after warm-up; calls
+ * on a buffer that has given up poll once instead of waiting again (ranks out of step cost the bound once, not per call). */
 int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems);
 /* Setup-time helpers (they allocate and synchronise): the buffer must be FINE-GRAINED device memory -- peers write into it
  * and the owner polls it within one kernel, and ordinary device memory is coherent across GPUs only at kernel boundaries.

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
   unsigned* my_epoch = (unsigned*)(mine + kArEpochOff) + blockIdx.x;
   unsigned epoch = __hip_atomic_load(my_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   if (epoch == 0u) epoch = 2u;        // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
+  // a buffer that has given up once stops waiting (one poll per call): the ranks are out of step for good, the host falls
+  // back to the library collective, and until it does a token must not cost `spin_limit` naps per all-reduce
+  const int spin_limit = __hip_atomic_load((const unsigned*)mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PARO_WS_STATUS_GIVEUP ? 0 : a.spin_limit;
   const long long slot0 = (long long)((int)(epoch & 1u) * a.world) * a.slot_granules;
   if (g < a.ng) {
     const unsigned mydata = a.x[g];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
       for (int r = 0; r < kArMaxWorld; ++r)
         if (r < a.world && r != a.rank) all = all && (unsigned)(got[r] >> 32) == epoch;
       if (all) break;
-      if (spin >= a.spin_limit) {
+      if (spin >= spin_limit) {
         ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
         break;
       }

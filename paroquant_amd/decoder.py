@@ -318,7 +318,7 @@ class ParoDecoderLM:
         torch.cuda.current_stream(self.device).wait_stream(s)
         self.tok.copy_(tok0); self.pos.copy_(pos0)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # a collective library's watchdog thread must not void the capture
             self.decode_step()
         self.tok.copy_(tok0); self.pos.copy_(pos0)
         self._graph = g

@@ -1417,3 +1417,44 @@ def test_tp_decoder_ranks_share_one_gpu(dev, world):
                           "--master-port", str(29620 + world), os.path.join(root, "tests", "_tp_decoder_worker.py")],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "TP_DECODER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_oneshot_allreduce_absent_peer_gives_up_once(dev):
+    """A peer that never arrives: the call gives up after its bounded wait (sticky status word, reported by
+    paro_allreduce_status), and every LATER call polls once instead of waiting again -- an out-of-step rank costs seconds
+    once, not seconds per all-reduce."""
+    import ctypes
+    import time
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+    n = 4096
+    nbytes = lib.paro_allreduce_buffer_bytes(2, n)
+    bufs = []
+    for _ in range(2):                      # both "ranks'" buffers live in this process; rank 1 never calls
+        p, h = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        nat.check(lib.paro_allreduce_buffer_create(nbytes, ctypes.byref(p), h))
+        bufs.append(p.value)
+    try:
+        peers = torch.tensor(bufs, dtype=torch.int64, device=dev)
+        x = torch.randn(n, device=dev, dtype=torch.float16)
+        y = torch.empty_like(x)
+        st = nat.current_stream_ptr(dev)
+        call = lambda: nat.check(lib.paro_allreduce_oneshot(x.data_ptr(), None, y.data_ptr(), n, nat.dtype_code(x.dtype), peers.data_ptr(), 2, 0, n, st))
+        assert lib.paro_allreduce_status(bufs[0], st) == 0
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize(dev)
+        first = time.perf_counter() - t0
+        assert lib.paro_allreduce_status(bufs[0], st) != 0          # gave up, and says so
+        assert 0.05 < first < 60.0, first                           # a bounded wait of seconds
+        t0 = time.perf_counter()
+        for _ in range(20):
+            call()
+        torch.cuda.synchronize(dev)
+        later = time.perf_counter() - t0
+        assert later < 0.05 * max(first, 1.0), (first, later)       # no second wait
+        assert lib.paro_allreduce_status(bufs[0], st) != 0          # sticky
+    finally:
+        torch.cuda.synchronize(dev)
+        for b in bufs:
+            lib.paro_allreduce_buffer_destroy(b)
