@@ -289,7 +289,7 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     return {"value": round(tps, 1), "unit": "tokens/s", "ms_per_token": round(ms, 4),
             "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
             "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
-            "launches_per_token": (5 if tp_world == 1 else 7) * lm.cfg.n_layers + 3,
+            "launches_per_token": (5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3,
             "parallelism": f"tp{tp_world}" + (" (bytes_per_token and GBps are per rank)" if tp_world > 1 else ""),
             "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),
             "GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),

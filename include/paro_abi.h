@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 8
+#define PARO_ABI_VERSION 9
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -198,6 +198,12 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
  *   prologue PARO_PROLOGUE_SILU_MUL  x_k = silu(gate_k) * up_k, gate = x[row][0..K), up = x[row][K..2K) (the merged
  *            gate_up projection's output), evaluated in fp32 before the rotation.
  *   residual                          y[row][col] += residual[row][col]  (act_dtype, row stride N), or NULL.
+ *   all-reduce (v9)                   ar_peers != NULL: the linear is a ROW-PARALLEL shard and y becomes
+ *            the sum of the world's partial outputs (+ bias + residual, added once, after the sum): the output threads
+ *            exchange {fp32 partial, epoch} granules through the ranks' paro_allreduce buffers (sized with
+ *            ar_max_elems >= N) and sum them in rank order -- one rounding, bit-identical on every rank, no separate
+ *            all-reduce launch.  One row, not with the RMSNorm prologue (a norm over a K shard is not the layer's norm)
+ *            nor with expert slots.  Every rank must issue the same sequence of such launches on its buffer.
  * rows <= 4, krot <= 8 (in-kernel rotation); the launch shape is chosen automatically. */
 #define PARO_PROLOGUE_NONE 0
 #define PARO_PROLOGUE_RMSNORM 1
@@ -207,6 +213,12 @@ typedef struct paro_fusion {
   float eps;             /* RMSNorm epsilon */
   int64_t x_stride;      /* elements between rows of x; 0 = dense (K, or 2 K for SILU_MUL) */
   const void* residual;
+  const void* const* ar_peers; /* DEVICE array [ar_world] of the ranks' buffers as mapped in this process, or NULL */
+  void* ar_own;                /* this rank's buffer (== ar_peers[ar_rank]) */
+  void* ar_state;              /* (16 + ar_max_elems / 16) u32 of ORDINARY device memory, zero when the buffers are created,
+                                  never touched by the caller afterwards: give-up flag + one epoch per 16-column tile */
+  int32_t ar_world, ar_rank;
+  int64_t ar_max_elems;        /* the element count the buffers were sized with */
 } paro_fusion_t;
 int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                           int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream);

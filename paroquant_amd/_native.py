@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 8
+PARO_ABI_VERSION = 9
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
@@ -86,7 +86,8 @@ class ParoLinearDesc(Structure):
 class ParoFusion(Structure):
     """``paro_fusion_t`` (include/paro_abi.h)."""
 
-    _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p)]
+    _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p),
+                ("ar_peers", c_void_p), ("ar_own", c_void_p), ("ar_state", c_void_p), ("ar_world", c_int32), ("ar_rank", c_int32), ("ar_max_elems", c_int64)]
 
 
 class ParoExperts(Structure):

@@ -7,6 +7,8 @@
 //   [4]                     u32 status (0 / PARO_WS_STATUS_GIVEUP)
 //   [64 + 4 * wg]           u32 epoch of workgroup wg's last completed call
 //   [4096 + (set, r) * S]   slot of rank r: 8-byte granules {two activations, u32 epoch tag}             set = epoch & 1
+//   (behind it: the {fp32 partial, tag} region of the row-parallel GEMV's all-reduce EPILOGUE, which runs this same
+//   exchange from the GEMV's output threads -- layout and words in common.hpp, code in gemv_impl.hpp)
 // The data IS the flag (the K-split hand-off's recipe, gemv_impl.hpp, stretched over the links): a rank stores each pair
 // of activations together with the call's epoch as ONE 8-byte system-scope store into its slot in every peer, and polls
 // the granules of its own buffer until their tags read the epoch.  No fence, no flag round trip, no barrier on the data
@@ -19,8 +21,6 @@
 
 namespace paro {
 
-constexpr int kArEpochOff = 64, kArDataOff = 4096, kArMaxWorld = 16, kArThreads = 1024;
-constexpr int kArMaxWgs = (kArDataOff - kArEpochOff) / 4;
 
 struct ArArgs {
   const unsigned* x;             // two activations per word
@@ -96,13 +96,11 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
   if (tid == 0) __hip_atomic_store(my_epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-static long long ar_slot_granules(int64_t max_elems) { return ((max_elems / 2 + 31) / 32) * 32; }
-
 }  // namespace paro
 
 extern "C" int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems) {
   if (world < 1 || world > paro::kArMaxWorld || max_elems < 8 || max_elems > (int64_t)paro::kArMaxWgs * paro::kArThreads * 2) return -1;
-  return paro::kArDataOff + 2 * (int64_t)world * paro::ar_slot_granules(max_elems) * 8;
+  return paro::ar_buffer_bytes(world, max_elems);
 }
 
 extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype,
@@ -121,7 +119,7 @@ extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void*
   a.world = world;
   a.rank = rank;
   a.ng = (int)(n / 2);
-  a.slot_granules = ar_slot_granules(max_elems);
+  a.slot_granules = ar_slot_a(max_elems);
   a.spin_limit = 1 << 22;   // ~4 s of ~1 us naps (callers barrier before phases in which ranks can be seconds apart)
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((a.ng + kArThreads - 1) / kArThreads);

@@ -49,6 +49,19 @@ struct PartTable {
   }
 };
 
+// ---- the one-shot all-reduce buffer (allreduce.hip; shared with the GEMV's all-reduce epilogue, gemv_impl.hpp):
+//   u32 words: [1] status   [16 + wg] epoch of workgroup wg of the standalone kernel (the GEMV epilogue keeps its give-up
+//   flag and one epoch per 16-column tile in ORDINARY device memory: paro_fusion_t.ar_state, kArStateTiles + max_elems / 16 words);   region A at 4096: (set, rank) slots of {two activations, tag} granules,
+//   max_elems / 2 per slot;   region B behind it: (set, rank) slots of {fp32 partial, tag} granules, max_elems per slot.
+//   The two users keep separate regions AND separate epochs: a tag is only ever compared with its own user's sequence.
+constexpr int kArEpochOff = 64, kArDataOff = 4096, kArMaxWorld = 16, kArThreads = 1024;
+constexpr int kArMaxWgs = (kArDataOff - kArEpochOff) / 4;
+constexpr int kArStateTiles = 16;   // first tile epoch word of paro_fusion_t.ar_state
+inline long long ar_slot_a(long long max_elems) { return ((max_elems / 2 + 31) / 32) * 32; }
+inline long long ar_slot_b(long long max_elems) { return ((max_elems + 31) / 32) * 32; }
+inline long long ar_region_b_off(int world, long long max_elems) { return kArDataOff + 2ll * world * ar_slot_a(max_elems) * 8; }
+inline long long ar_buffer_bytes(int world, long long max_elems) { return ar_region_b_off(world, max_elems) + 2ll * world * ar_slot_b(max_elems) * 8; }
+
 // quantisation group of a layer: 128 (also for 0 = unset) or 64; -1 = unsupported
 inline int quant_group(int group_size) { return (group_size == 0 || group_size == 128) ? 128 : (group_size == 64 ? 64 : -1); }
 

@@ -198,8 +198,9 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
-  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E;
-  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr};
+  const bool ar = F && F->ar_peers && F->ar_world >= 1;
+  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar;
+  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   if (E) {
     if (!F) F = &no_fusion;
     if (!E->expert_idx || E->n_slots < 1 || E->n_slots > 65535) return fail(PARO_ERR_INVALID, "bad expert slot table");
@@ -218,6 +219,14 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (F->prologue == PARO_PROLOGUE_RMSNORM) {
       if (ksplit > 1) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
       ksplit = 1;
+    }
+    if (ar) {
+      if (E) return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is not defined for expert slots");
+      if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is a batch-1 decode path (got %lld rows)", (long long)rows);
+      if (F->prologue == PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot feed a row-parallel shard (a norm over a K slice is not the layer's norm)");
+      if (F->ar_world > kArMaxWorld || F->ar_rank < 0 || F->ar_rank >= F->ar_world) return fail(PARO_ERR_INVALID, "bad all-reduce world / rank (%d / %d)", F->ar_world, F->ar_rank);
+      if (!F->ar_own || !F->ar_state) return fail(PARO_ERR_INVALID, "all-reduce epilogue: ar_own / ar_state is null");
+      if (L->N > F->ar_max_elems) return fail(PARO_ERR_INVALID, "all-reduce buffers sized for %lld elements, the layer has %lld outputs", (long long)F->ar_max_elems, (long long)L->N);
     }
     const int64_t min_stride = (F->prologue == PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
@@ -265,6 +274,13 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.x_sstride = E ? E->x_slot_stride : 0;
   a.y_sstride = E ? E->y_slot_stride : 0;
   a.x_div = E ? E->x_slot_div : 1;
+  a.ar_peers = ar ? (unsigned char* const*)F->ar_peers : nullptr;
+  a.ar_mine = ar ? (unsigned char*)F->ar_own : nullptr;
+  a.ar_state = ar ? (unsigned*)F->ar_state : nullptr;
+  a.ar_world = ar ? F->ar_world : 0;
+  a.ar_rank = ar ? F->ar_rank : 0;
+  a.ar_slot = ar ? ar_slot_b(F->ar_max_elems) : 0;
+  a.ar_off = ar ? ar_region_b_off(F->ar_world, F->ar_max_elems) : 0;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
   auto repack_hot = [&]() {
     return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride);

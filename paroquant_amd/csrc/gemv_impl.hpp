@@ -76,6 +76,14 @@ struct GemvArgs {
   long long wq_estride, sz_estride;      // bytes between experts in wq / sz
   long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
   int x_div;
+  // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
+  // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
+  unsigned char* const* ar_peers;   // device array [world]: every rank's buffer as mapped in this process, or null
+  unsigned char* ar_mine;           // == ar_peers[ar_rank]
+  unsigned* ar_state;               // ordinary device memory, zero at creation: [0] gave up once, [kArStateTiles + t] epoch of column tile t
+  int ar_world, ar_rank;
+  long long ar_slot;                // granules per (set, rank) slot of the fp32 region
+  long long ar_off;                 // byte offset of that region inside a buffer
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
@@ -107,7 +115,8 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 // tools/ablate_gemv.py, tools/timeline_gemv.py): 11 skips schedule + stages, 21 also the unpack + MFMA (pure
 // stream), 41 fetches the schedule but does not run the stages, 51 runs the stages without the cross-lane
 // fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps.
-// FUSED (1: RMSNorm prologue and / or residual epilogue, 2: SiLU*mul prologue (+ residual)): the decode-layer
+// FUSED (1: RMSNorm prologue and / or residual epilogue, 2: SiLU*mul prologue (+ residual); | 4: + the all-reduce
+// epilogue of a row-parallel shard, one row): the decode-layer
 // fusions either side of the linear, in extra instantiations so that the plain kernel's code is
 // untouched:
 //   prologue RMSNORM   y = GEMV(x) * rsqrt(mean(x^2) + eps): the norm WEIGHT is folded into channel_scales at load
@@ -121,6 +130,8 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 // words per tile and column, the tile's first two / last two MFMA k-steps accumulated separately).
 template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0, int QS = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
+  constexpr int FMODE = FUSED & 3;          // 0 plain, 1 RMSNorm prologue and / or residual, 2 SiLU*mul prologue (+ residual)
+  constexpr bool AREP = (FUSED & 4) != 0;   // + all-reduce epilogue (its own instantiations: the code costs the others ~5 % otherwise)
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int RED_FLOATS = WAVES * TPW * MRT * 64;
   constexpr int WORK_BYTES = WAVES * XH_BYTES;
   constexpr int EX_BYTES = (PD / 10 == 6) ? WAVES * 256 : 0;   // diagnostic exchange slots
-  constexpr int SS_BYTES = FUSED ? WAVES * MB * 4 : 0;        // per-wave sum(x^2) partials (RMSNorm prologue)
+  constexpr int SS_BYTES = FMODE ? WAVES * MB * 4 : 0;        // per-wave sum(x^2) partials (RMSNorm prologue)
   constexpr int LDS_BYTES = (WORK_BYTES > RED_FLOATS * 4 ? WORK_BYTES : RED_FLOATS * 4) + EX_BYTES + 16 + SS_BYTES;
   // scale/zero words of a unit: one aligned vector load per 4 tiles when TPW is a power of two, else one
   // dword load per tile (TPW = 3, 5, 6, 7 exist so that wide outputs can be cut into ~256 column blocks)
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   GP<unsigned> sz_p = h.sz;
   GP<unsigned short> x_p = h.x;
   int slot = 0;
-  if constexpr (FUSED != 0) {
+  if constexpr (FMODE != 0) {
     if (h.experts) {
       slot = blockIdx.z;
       // the id is the same for the whole workgroup: pulled back into a scalar register so that the pointers derived
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
-    unsigned xu[FUSED == 2 ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
+    unsigned xu[FMODE == 2 ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
@@ -319,10 +330,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         const int rr = r < h.rows ? r : 0;  // clamp instead of branching: keeps the load count static
-        if constexpr (FUSED) {
+        if constexpr (FMODE) {
           GP<unsigned short> xr = x_p + ((unsigned)rr * (unsigned)h.xstride + (unsigned)(g * 128 + 2 * lane));
           b.xv[r] = *(GP<unsigned>)xr;
-          if constexpr (FUSED == 2) b.xu[r] = *(GP<unsigned>)(xr + h.K);
+          if constexpr (FMODE == 2) b.xu[r] = *(GP<unsigned>)(xr + h.K);
         } else {
           b.xv[r] = *(GP<unsigned>)(x_p + (unsigned)(rr * h.K + g * 128 + 2 * lane));
         }
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // for the first coefficients then becomes a wait for the HBM tiles as well (measured: +0.6 us per fused launch).
   unsigned short res_raw = 0;
   bool res_valid = false;
-  if constexpr (FUSED) {
+  if constexpr (FMODE) {
     const int el = tid & 63, q = (tid >> 6) % MRT, j = tid / (MRT * 64);
     const int b = (q / MR) * 16 + (el >> 4) * MR + (q % MR);
     const bool has_res = h.residual != nullptr;
@@ -404,23 +415,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // residual epilogue: the value this thread will add to its FIRST output is requested here, at kernel entry, not
   // as a dependent load after the reduction (a global access at the tail is ~1 us of pure latency)
   // (the residual value of this thread's first output was requested above, unconditionally: res_raw / res_valid)
-  float ssq[FUSED ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
+  float ssq[FMODE ? MB : 1];   // RMSNorm prologue: this lane's share of sum(x^2), per row
 #pragma unroll
-  for (int r = 0; r < (FUSED ? MB : 1); ++r) ssq[r] = 0.f;
+  for (int r = 0; r < (FMODE ? MB : 1); ++r) ssq[r] = 0.f;
   auto seed = [&](const PBuf& b, float (&sa)[MB], float (&sb)[MB]) {
     const float c0 = f16_bits_to_f32(b.csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(b.csv >> 16) * 0x1p-63f;
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
       const unsigned xv = r < h.rows ? b.xv[r] : 0u;
       float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
-      if constexpr (FUSED == 2) {
+      if constexpr (FMODE == 2) {
         {
           const unsigned uv = r < h.rows ? b.xu[r] : 0u;
           // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x
           x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x0));
           x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x1));
         }
-      } else if constexpr (FUSED == 1) {
+      } else if constexpr (FMODE == 1) {
         if (h.prologue == PARO_PROLOGUE_RMSNORM) ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
       }
       sa[r] = x0 * c0;
@@ -644,6 +655,52 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   }
 
   if constexpr (DIAG == 3) ts[5] = stamp_after(acc[0][0]);  // all units done
+  // all-reduce epilogue: the epoch of this thread's first output tile (and whether the buffer has given up before),
+  // requested ahead of the barriers that hide the round trip.  Epochs are kept PER 16-COLUMN TILE in ordinary L2-cached
+  // memory: whatever launch shape owns a tile, its tag sequence grows by one per launch, on every rank alike; no arrival
+  // count, no atomic (256 workgroups taking a ticket on one word cost more than the launch this epilogue saves).
+  unsigned ar_first = 0;
+  int ar_limit = 0;
+  if constexpr (AREP) {
+    if (a.ar_peers) {
+      ar_first = a.ar_state[kArStateTiles + tile0 + min(tid / (MRT * 64), max(nt - 1, 0))];
+      ar_limit = a.ar_state[0] != 0u ? 0 : (1 << 22);
+    }
+  }
+  // every rank's partial of output column `col` -> the world's sum (rank order, fp32: bit-identical on all ranks)
+  auto ar_exchange = [&](float v, int col, unsigned ar_epoch) -> float {
+    const long long set0 = a.ar_off + (long long)((int)(ar_epoch & 1u) * a.ar_world) * a.ar_slot * 8;
+    const unsigned long long gran = ((unsigned long long)ar_epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    for (int p = 0; p < a.ar_world; ++p) {
+      if (p == a.ar_rank) continue;
+      unsigned long long* dst = (unsigned long long*)(a.ar_peers[p] + set0) + (long long)a.ar_rank * a.ar_slot + col;
+      __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long* src = (const unsigned long long*)(a.ar_mine + set0) + col;
+    unsigned long long got[kArMaxWorld];
+    bool all = false;
+    for (int spin = 0; !all; ++spin) {
+#pragma unroll
+      for (int r = 0; r < kArMaxWorld; ++r)
+        if (r < a.ar_world && r != a.ar_rank) got[r] = __hip_atomic_load(src + (long long)r * a.ar_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      all = true;
+#pragma unroll
+      for (int r = 0; r < kArMaxWorld; ++r)
+        if (r < a.ar_world && r != a.ar_rank) all = all && (unsigned)(got[r] >> 32) == ar_epoch;
+      if (all) break;
+      if (spin >= ar_limit) {
+        ((unsigned*)a.ar_mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
+        a.ar_state[0] = 1u;                                  // ... and by later launches, which poll once instead of waiting again
+        break;
+      }
+      if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kArMaxWorld; ++r)
+      if (r < a.ar_world) s += r == a.ar_rank ? v : __builtin_bit_cast(float, (unsigned)got[r]);
+    return s;
+  };
   // ---- reduce the workgroup's waves (different groups, same columns) through LDS
   __syncthreads();
   if constexpr (DIAG == 3) ts[7] = __builtin_amdgcn_s_memtime();   // every wave of the workgroup has finished its units
@@ -653,7 +710,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < MRT; ++r) red[((wave * TPW + j) * MRT + r) * 64 + lane] = acc[j][r];
   float* ssl = (float*)(lds + LDS_BYTES - SS_BYTES);   // [wave][row]
-  if constexpr (FUSED == 1) {
+  if constexpr (FMODE == 1) {
     if (h.prologue == PARO_PROLOGUE_RMSNORM) {
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
@@ -678,7 +735,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   if constexpr (DIAG == 3) ts[8] = __builtin_amdgcn_s_memtime();   // partials staged
 
   unsigned short* y_p = a.y;
-  if constexpr (FUSED != 0) {
+  if constexpr (FMODE != 0) {
     if (h.experts) y_p = a.y + (long long)slot * a.y_sstride;
   }
   const bool direct = (h.ksplit == 1);
@@ -691,7 +748,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int w = 0; w < WAVES; ++w) v += red[e + w * TPW * MRT * 64];
     const int col = (tile0 + j) * 16 + (el & 15);
     if (direct) {
-      if constexpr (FUSED == 1) {
+      if constexpr (FMODE == 1) {
         if (h.prologue == PARO_PROLOGUE_RMSNORM) {
           float ss = 0.f;
 #pragma unroll
@@ -699,8 +756,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           v *= __builtin_amdgcn_rsqf(ss / (float)h.K + a.eps);
         }
       }
+      if constexpr (AREP) {
+        if (a.ar_peers) {
+          unsigned ep = (e == tid ? ar_first : a.ar_state[kArStateTiles + (col >> 4)]) + 1u;
+          if (ep == 0u) ep = 2u;   // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
+          v = ar_exchange(v, col, ep);
+          if ((col & 15) == 0) a.ar_state[kArStateTiles + (col >> 4)] = ep;   // the tile's 16 lanes read it in one instruction, before this store
+        }
+      }
       if (a.bias) v += A::to_f32(a.bias[col]);
-      if constexpr (FUSED) {
+      if constexpr (FMODE) {
         if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
       y_p[(int64_t)b * h.N + col] = A::from_f32(v);
@@ -747,8 +812,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           }
         }
       }
+      if constexpr (AREP) {
+        if (a.ar_peers) {
+          unsigned ep = (e == tid ? ar_first : a.ar_state[kArStateTiles + (col >> 4)]) + 1u;
+          if (ep == 0u) ep = 2u;   // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
+          v = ar_exchange(v, col, ep);
+          if ((col & 15) == 0) a.ar_state[kArStateTiles + (col >> 4)] = ep;   // the tile's 16 lanes read it in one instruction, before this store
+        }
+      }
       if (a.bias) v += A::to_f32(a.bias[col]);
-      if constexpr (FUSED) {
+      if constexpr (FMODE) {
         if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       }
       y_p[(int64_t)b * h.N + col] = A::from_f32(v);
@@ -824,6 +897,13 @@ int launch_waves_fused_mode(const GemvArgs& a, int waves, dim3 grid, hipStream_t
 }
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if (a.ar_peers) {   // + all-reduce epilogue (FUSED | 4): one row only
+    if constexpr (MB == 1) {
+      if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 6>(a, waves, grid, st);
+      return launch_waves_fused_mode<AT, TPW, MB, PREROT, 5>(a, waves, grid, st);
+    }
+    return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is built for one row");
+  }
   if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
   return launch_waves_fused_mode<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
@@ -860,7 +940,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_peers) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

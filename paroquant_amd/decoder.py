@@ -101,6 +101,8 @@ class ParoDecoderLM:
         token (the all-reduce sums in rank order, bit-identical on all ranks)."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.tp_rank, self.tp_world, self.allreduce = int(tp_rank), int(tp_world), allreduce
+        # a one-shot all-reduce object can also run inside the row-parallel GEMV's epilogue (no launch of its own)
+        self.fused_allreduce = hasattr(allreduce, "fusion_args") and os.environ.get("PARO_FUSED_ALLREDUCE", "1") != "0"
         self.tp_group = getattr(allreduce, "group", None)       # the prefill's [T, hidden] all-reduce goes through the process group
         if cfg.n_heads % self.tp_world or cfg.n_kv_heads % self.tp_world or cfg.inter % self.tp_world:
             raise ValueError(f"heads {cfg.n_heads} / kv heads {cfg.n_kv_heads} / intermediate {cfg.inter} do not split {self.tp_world}-way")
@@ -289,6 +291,10 @@ class ParoDecoderLM:
                 ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2)                 # h2 = h + o(attn)
                 ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
                 ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h)                # h = h2 + down(act)
+            elif self.fused_allreduce:   # row-parallel o / down exchange their partial outputs in their own epilogue: five launches
+                ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, residual=h, out=h2, allreduce=self.allreduce)
+                ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu_buf)
+                ops.w4a16_gemv_fused(self.gu_buf, L.down, S, residual=h2, out=h, allreduce=self.allreduce)
             else:   # row-parallel o / down: partial sums, one all-reduce each with the residual added in its summation
                 ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, out=self.part)
                 self.allreduce(self.part, residual=h, out=h2)

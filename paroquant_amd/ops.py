@@ -300,12 +300,14 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
 
 
 def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
     """Decode-layer fusions around one fused linear (``paro_w4a16_gemv_fused``; rows <= 4):
     ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
     ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
     gate_up output ``[rows, 2 K]`` and the linear consumes ``silu(gate) * up``; ``residual [rows, N]`` is added to
-    the output.  ``out`` may be given (e.g. a static buffer of a captured decode step)."""
+    the output.  ``out`` may be given (e.g. a static buffer of a captured decode step).  ``allreduce`` (a
+    ``paroquant_amd.tp.OneShotAllReduce``): ``pk`` is a row-parallel shard and the output becomes the sum over the ranks
+    (+ bias + residual, once), exchanged inside this launch -- one row, every rank issuing the same launches."""
     lib = nat.load()
     K, N = pk.K, pk.N
     width = 2 * K if prologue == nat.PROLOGUE_SILU_MUL else K
@@ -325,6 +327,8 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     f = nat.ParoFusion()
     f.prologue, f.eps, f.x_stride = int(prologue), float(eps), int(x2.stride(0))
     f.residual = residual.data_ptr() if residual is not None else None
+    if allreduce is not None:
+        f.ar_peers, f.ar_own, f.ar_state, f.ar_world, f.ar_rank, f.ar_max_elems = allreduce.fusion_args()
     ws = pk.workspace
     with torch.cuda.device(x.device):
         nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),

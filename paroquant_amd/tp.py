@@ -127,6 +127,8 @@ class OneShotAllReduce:
                             self._opened.append(p.value)
                             ptrs.append(p.value)
                     self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+                    # launch state of the GEMV's all-reduce epilogue (give-up flag, one epoch per 16-column tile): ordinary cached memory
+                    self._gemv_state = torch.zeros(16 + (self.max_elems + 15) // 16, dtype=torch.int32, device=self.device)
                     torch.cuda.synchronize(self.device)
                 except Exception as e:                        # e.g. IPC mapping refused on this rank
                     err = e
@@ -166,6 +168,11 @@ class OneShotAllReduce:
                                                            self.nat.dtype_code(y.dtype), self.peers.data_ptr(), self.world, self.rank,
                                                            self.max_elems, self.nat.current_stream_ptr(y.device)))
         return out
+
+    def fusion_args(self):
+        """(peers, own, state, world, rank, max_elems) for ``paro_fusion_t``'s all-reduce epilogue (``ops.w4a16_gemv_fused(...,
+        allreduce=self)``): the row-parallel GEMV exchanges its partial outputs itself, no separate launch."""
+        return self.peers.data_ptr(), self._own, self._gemv_state.data_ptr(), self.world, self.rank, self.max_elems
 
     def gave_up(self) -> bool:
         """True when a call timed out waiting for a peer (sticky status word; synchronises the current stream)."""

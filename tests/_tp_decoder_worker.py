@@ -47,11 +47,38 @@ def main():
             toks.append(int(lm.tok.item()))
         return torch.cat(logits), toks
 
+    assert lm_tp.fused_allreduce                             # the row-parallel GEMVs exchange their partials in their epilogue
     lg_tp, tk_tp = teacher_forced(lm_tp, 8)
     lg_ref, tk_ref = teacher_forced(lm_ref, 8)
     err = float((lg_tp - lg_ref).abs().max()) / float(lg_ref.abs().max())
-    assert err < 2e-2, err                                   # row-parallel partial sums are rounded per rank before the all-reduce
+    assert err < 2e-2, err
     assert tk_tp == tk_ref, (tk_tp, tk_ref)
+    # the same model with the all-reduce as its own launch (partial sums rounded per rank before the exchange)
+    lm_sep = ParoDecoderLM.from_raw(cfg(), raw, shared, dev, tp_rank=rank, tp_world=world, allreduce=allreduce)
+    lm_sep.fused_allreduce = False
+    lg_sep, tk_sep = teacher_forced(lm_sep, 8)
+    err_sep = float((lg_sep - lg_ref).abs().max()) / float(lg_ref.abs().max())
+    assert err_sep < 2e-2 and tk_sep == tk_ref, (err_sep, tk_sep, tk_ref)
+    del lm_sep
+    # one row-parallel linear, directly: fused exchange == sum of the ranks' fp32-accumulated partials, bit-identical on all ranks
+    from paroquant_amd import ops, tp as ptp
+    lay = po.make_layer(77, 512, [H])
+    keys = ("qweight", "qzeros", "scales", "theta", "pairs", "channel_scales")
+    xs = torch.randn(1, 512, device=dev, dtype=torch.float16, generator=torch.Generator(device=dev).manual_seed(5))
+    res = torch.randn(1, H, device=dev, dtype=torch.float16, generator=torch.Generator(device=dev).manual_seed(6))
+    from paroquant_amd.linear import PackedParoWeights
+    sh = ptp.shard_row_parallel({**{k: torch.from_numpy(np.ascontiguousarray(lay[k])) for k in keys}, "bias": None}, rank, world)
+    pk_r = PackedParoWeights(*[sh[k].to(dev) for k in keys], [H])
+    k0 = 512 // world * rank
+    x_r = xs[:, k0:k0 + 512 // world].contiguous()
+    y_f = ops.w4a16_gemv_fused(x_r, pk_r, 0, residual=res, allreduce=allreduce)
+    part = ops.w4a16_gemv_fused(x_r, pk_r, 0).float()
+    dist.all_reduce(part)
+    want = part + res.float()
+    assert float((y_f.float() - want).abs().max()) <= 2e-2 * float(want.abs().max()), float((y_f.float() - want).abs().max())
+    ys = [torch.empty_like(y_f) for _ in range(world)]
+    dist.all_gather(ys, y_f)
+    assert all(torch.equal(ys[0], t) for t in ys)
     # the sharded prefill (local heads / MLP columns through the GEMM path, [T, hidden] all-reduced over the process group)
     pl_tp, pl_ref = lm_tp.prefill(ids).float(), lm_ref.prefill(ids).float()
     perr = float((pl_tp - pl_ref).abs().max()) / float(pl_ref.abs().max())

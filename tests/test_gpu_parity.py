@@ -1386,7 +1386,7 @@ def test_tp_bench_end_to_end_leg(dev):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     e = r["end_to_end"]
     assert "error" not in e, e
-    assert e["value"] > 0 and e["parallelism"].startswith("tp2") and e["launches_per_token"] == 7 * 28 + 3
+    assert e["value"] > 0 and e["parallelism"].startswith("tp2") and e["launches_per_token"] == 5 * 28 + 3
 
 
 # ---------------------------------------------------------------- e: one-shot all-reduce of the row-parallel outputs

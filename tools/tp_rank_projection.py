@@ -42,11 +42,12 @@ def main():
             if i >= 1:
                 stats.append(st)
         ms = float(np.median([s["ms_per_token"] for s in stats]))
-        launches = (5 if tp == 1 else 7) * lm.cfg.n_layers + 3
+        launches = (5 if tp == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3
         print(json.dumps({"model": a.model, "tp": tp, "rank_ms_per_token": round(ms, 4), "rank_tokens_per_s_upper_bound": round(1e3 / ms, 1),
                           "launches_per_token": launches, "us_per_launch": round(ms * 1e3 / launches, 3),
                           "rank_weight_bytes_per_token": int(lm.bytes_per_token),
                           "rank_GBps": round(lm.bytes_per_token / ms / 1e6, 1),
+                          "allreduce": ("in the row-parallel GEMV's epilogue" if lm.fused_allreduce else "separate launch") if tp > 1 else None,
                           "note": "one rank on one GPU; one-shot all-reduce against a world of one (no peer stores, no xGMI)" if tp > 1 else "unsharded"}), flush=True)
         del lm, ar
         torch.cuda.empty_cache()
