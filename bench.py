@@ -123,8 +123,12 @@ class DecodeStack:
 
     def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0, allreduce=None):
         self.model, self.tp, self.rank = model, tp, rank
+        from paroquant_amd import ops
+        self.ops = ops
         # the collective after the row-parallel linears: the one-shot kernel (paroquant_amd.tp.OneShotAllReduce) or dist.all_reduce
         self.allreduce = allreduce or (lambda y: (dist.all_reduce(y), y)[1])
+        # the one-shot object can also run inside the row-parallel GEMV's epilogue (paro_fusion_t.ar_*): no launch of its own
+        self.fused_ar = allreduce if (hasattr(allreduce, "fusion_args") and os.environ.get("PARO_FUSED_ALLREDUCE", "1") != "0") else None
         h, inter, q, kv, L = MODELS[model]
         self.n_layers = n_layers or L
         self.hidden, self.q_local, self.inter_local = h, q // tp, inter // tp
@@ -143,13 +147,19 @@ class DecodeStack:
         tp = self.tp
         for qkv, o, gu, down in self.layers:
             a = qkv.apply(h)[:, : self.q_local]            # attention stand-in: a view, no kernel
-            h = o.apply(a)
-            if tp > 1:
-                h = self.allreduce(h)                       # RowParallelLinear all-reduce (one-shot xGMI kernel, or RCCL)
+            if tp > 1 and self.fused_ar is not None:       # RowParallelLinear: the all-reduce runs in the GEMV's epilogue
+                h = self.ops.w4a16_gemv_fused(a, o, 0, allreduce=self.fused_ar)
+            else:
+                h = o.apply(a)
+                if tp > 1:
+                    h = self.allreduce(h)                   # ... or as its own launch (one-shot xGMI kernel, or RCCL)
             d = gu.apply(h)[:, : self.inter_local]         # SiLU*mul stand-in: a view, no kernel
-            h = down.apply(d)
-            if tp > 1:
-                h = self.allreduce(h)
+            if tp > 1 and self.fused_ar is not None:
+                h = self.ops.w4a16_gemv_fused(d, down, 0, allreduce=self.fused_ar)
+            else:
+                h = down.apply(d)
+                if tp > 1:
+                    h = self.allreduce(h)
         return h
 
 
@@ -471,6 +481,7 @@ def run(args, rank: int, local_rank: int, world: int):
                 print(f"[bench] the one-shot all-reduce gave up waiting for a peer; re-measuring with {args.tp_backend}", file=sys.stderr, flush=True)
             allreduce_name = args.tp_backend
             stack.allreduce = lambda y: (dist.all_reduce(y), y)[1]
+            stack.fused_ar = None
             if args.tp_backend == "gloo":
                 args.no_graph = True
             wall, ev_ms, use_graph = measure()
@@ -503,7 +514,7 @@ def run(args, rank: int, local_rank: int, world: int):
         "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f16 activations x int4 weights (fp32 accumulate)",
         "data": "synthetic (random INT4 AWQ-format weights, random fp16 activations, random perfect-matching pairs)",
         "config": {"workload": f"{model}-PARO batch-1 decode: {stack.n_layers} layers x (qkv[P=3], o, gate_up[P=2], down) "
-                               f"W4A16 g128 krot8, {('TP=%d (%s all-reduce after o / down)' % (tp, {'oneshot': 'one-shot xGMI kernel', 'nccl': 'RCCL'}.get(allreduce_name, allreduce_name))) if tp_mode else 'replica per GPU'}",
+                               f"W4A16 g128 krot8, {('TP=%d (%s all-reduce after o / down)' % (tp, {'oneshot': 'one-shot over xGMI' + (' in the GEMV epilogue' if stack.fused_ar is not None else ' kernel'), 'nccl': 'RCCL'}.get(allreduce_name, allreduce_name))) if tp_mode else 'replica per GPU'}",
                    "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
                    "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
