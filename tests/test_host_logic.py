@@ -296,3 +296,38 @@ def test_hf_checkpoint_discovery_and_surgery(tmp_path):
     assert swapped == found and isinstance(model.lm_head, torch.nn.Linear)
     q = model.model.layers[1].self_attn.k_proj
     assert (q.in_features, q.out_features) == (256, 128) and q.qweight.shape == (256, 16)
+
+
+def test_allreduce_epilogue_host_checks(lib):
+    """ABI v9: the row-parallel GEMV's all-reduce epilogue is validated on the host before any launch, and the buffer
+    holds both granule regions (pairs of activations for the standalone kernel, fp32 partials for the epilogue)."""
+    from paroquant_amd import _native as nat
+    one = ctypes.c_void_p(1)
+    d = nat.ParoLinearDesc()
+    d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.group_size = 256, 512, 1, 8, nat.dtype_code(torch.float16), 128
+    d.part_cols[0] = 512
+    for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+        setattr(d, f, 1)
+
+    def call(rows=1, prologue=0, world=2, rank=0, max_elems=512, own=1, state=1):
+        f = nat.ParoFusion()
+        f.prologue, f.eps, f.x_stride = prologue, 1e-6, 0
+        f.ar_peers, f.ar_own, f.ar_state, f.ar_world, f.ar_rank, f.ar_max_elems = 1, own, state, world, rank, max_elems
+        rc = lib.paro_w4a16_gemv_fused(ctypes.byref(d), one, one, rows, one, 1 << 20, ctypes.byref(f), None)
+        return rc, lib.paro_last_error().decode()
+
+    rc, msg = call(rows=2)
+    assert rc == -2 and "batch-1" in msg
+    rc, msg = call(prologue=nat.PROLOGUE_RMSNORM)
+    assert rc == -1 and "row-parallel" in msg
+    rc, msg = call(world=17)
+    assert rc == -1 and "world" in msg
+    rc, msg = call(rank=2)
+    assert rc == -1 and "world" in msg
+    rc, msg = call(max_elems=256)
+    assert rc == -1 and "sized for 256" in msg
+    rc, msg = call(state=None)
+    assert rc == -1 and "ar_state" in msg
+    # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
+    assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
+    assert lib.paro_allreduce_buffer_bytes(17, 8192) == -1 and lib.paro_allreduce_buffer_bytes(2, 4) == -1
