@@ -213,7 +213,8 @@ typedef struct paro_fusion {
   float eps;             /* RMSNorm epsilon */
   int64_t x_stride;      /* elements between rows of x; 0 = dense (K, or 2 K for SILU_MUL) */
   const void* residual;
-  const void* const* ar_peers; /* DEVICE array [ar_world] of the ranks' buffers as mapped in this process, or NULL */
+  const void* const* ar_peers; /* HOST array [ar_world] of the ranks' buffers as mapped in this process (copied into the
+                                  launch arguments), or NULL */
   void* ar_own;                /* this rank's buffer (== ar_peers[ar_rank]) */
   void* ar_state;              /* (16 + ar_max_elems / 16) u32 of ORDINARY device memory, zero when the buffers are created,
                                   never touched by the caller afterwards: give-up flag + one epoch per 16-column tile */
@@ -316,7 +317,9 @@ int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);
  * ranks.
  *   buffer: paro_allreduce_buffer_bytes(world, max_elems) bytes per rank of fine-grained device memory
  *           (paro_allreduce_buffer_create), mapped into every peer (paro_allreduce_buffer_open on the 64-byte handle);
- *           peers_dev = DEVICE array of the world's buffer addresses as mapped in the calling process, own buffer at [rank].
+ *           peers = HOST array of the world's buffer addresses as mapped in the calling process, own buffer at [rank]
+ *           (v9: copied into the launch arguments -- a pointer fetched from device memory per peer was a dependent round
+ *           trip in front of every store).
  *   n: elements, a multiple of 8, <= max_elems (the value the buffer was sized with).  x and y may alias.
  *   residual: optional vector added to the sum before the one rounding (y = sum_r x_r + residual: the decoder's residual
  *             stream after o_proj / down_proj), or NULL.
@@ -334,7 +337,7 @@ int paro_allreduce_buffer_open(const void* handle64, void** out_ptr);
 int paro_allreduce_buffer_close(void* peer_ptr);
 int paro_allreduce_buffer_destroy(void* own_ptr);
 int paro_allreduce_status(const void* own_ptr, void* stream);
-int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype, const void* const* peers_dev,
+int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype, const void* const* peers,
                            int world, int rank, int64_t max_elems, void* stream);
 
 #ifdef __cplusplus

@@ -26,7 +26,8 @@ struct ArArgs {
   const unsigned* x;             // two activations per word
   const unsigned* residual;      // added to the sum (the decoder's residual stream), or null
   unsigned* y;
-  unsigned char* const* peers;   // device array [world]: every rank's buffer as mapped in THIS process
+  unsigned char* mine;           // == peers[rank]
+  unsigned char* peers[kArMaxWorld];   // every rank's buffer as mapped in THIS process, by value (scalar registers, no fetch per peer)
   int world, rank, ng;           // ng = granules = n / 2
   long long slot_granules;
   int spin_limit;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
   typedef Act<AT> A;
   const int tid = threadIdx.x;
   const int g = blockIdx.x * kArThreads + tid;
-  unsigned char* mine = a.peers[a.rank];
+  unsigned char* mine = a.mine;
   unsigned* my_epoch = (unsigned*)(mine + kArEpochOff) + blockIdx.x;
   unsigned epoch = __hip_atomic_load(my_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   if (epoch == 0u) epoch = 2u;        // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
@@ -49,10 +50,12 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
     const unsigned mydata = a.x[g];
     const unsigned long long gran = ((unsigned long long)epoch << 32) | mydata;
     // 1. my granule into slot (set, rank) of every peer: one 8-byte store each, data and tag together
-    for (int p = 0; p < a.world; ++p) {
-      if (p == a.rank) continue;
-      unsigned long long* dst = (unsigned long long*)(a.peers[p] + kArDataOff) + slot0 + (long long)a.rank * a.slot_granules + g;
-      __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int p = 0; p < kArMaxWorld; ++p) {
+      if (p < a.world && p != a.rank) {
+        unsigned long long* dst = (unsigned long long*)(a.peers[p] + kArDataOff) + slot0 + (long long)a.rank * a.slot_granules + g;
+        __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     const unsigned res = a.residual ? a.residual[g] : 0u;
     // 2. the peers' granules of this epoch: every poll of a round is issued before any is looked at; fast polls first
@@ -104,9 +107,9 @@ extern "C" int64_t paro_allreduce_buffer_bytes(int world, int64_t max_elems) {
 }
 
 extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void* y, int64_t n, int act_dtype,
-                                      const void* const* peers_dev, int world, int rank, int64_t max_elems, void* stream) {
+                                      const void* const* peers, int world, int rank, int64_t max_elems, void* stream) {
   using namespace paro;
-  if (!x || !y || !peers_dev) return fail(PARO_ERR_INVALID, "null pointer");
+  if (!x || !y || !peers) return fail(PARO_ERR_INVALID, "null pointer");
   if (world < 1 || world > kArMaxWorld || rank < 0 || rank >= world) return fail(PARO_ERR_INVALID, "bad world / rank (%d / %d)", world, rank);
   if (max_elems > (int64_t)kArMaxWgs * kArThreads * 2) return fail(PARO_ERR_INVALID, "max_elems out of range");
   if (n < 8 || n % 8 != 0 || n > max_elems) return fail(PARO_ERR_INVALID, "element count must be a multiple of 8 in 8..%lld (got %lld)", (long long)max_elems, (long long)n);
@@ -115,7 +118,9 @@ extern "C" int paro_allreduce_oneshot(const void* x, const void* residual, void*
   a.x = (const unsigned*)x;
   a.residual = (const unsigned*)residual;
   a.y = (unsigned*)y;
-  a.peers = (unsigned char* const*)peers_dev;
+  for (int r = 0; r < kArMaxWorld; ++r) a.peers[r] = r < world ? (unsigned char*)peers[r] : nullptr;
+  a.mine = a.peers[rank];
+  if (!a.mine) return fail(PARO_ERR_INVALID, "peers[rank] is null");
   a.world = world;
   a.rank = rank;
   a.ng = (int)(n / 2);

@@ -226,6 +226,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
       if (F->prologue == PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot feed a row-parallel shard (a norm over a K slice is not the layer's norm)");
       if (F->ar_world > kArMaxWorld || F->ar_rank < 0 || F->ar_rank >= F->ar_world) return fail(PARO_ERR_INVALID, "bad all-reduce world / rank (%d / %d)", F->ar_world, F->ar_rank);
       if (!F->ar_own || !F->ar_state) return fail(PARO_ERR_INVALID, "all-reduce epilogue: ar_own / ar_state is null");
+      if (F->ar_peers[F->ar_rank] != F->ar_own) return fail(PARO_ERR_INVALID, "all-reduce epilogue: ar_peers[ar_rank] must be ar_own");
       if (L->N > F->ar_max_elems) return fail(PARO_ERR_INVALID, "all-reduce buffers sized for %lld elements, the layer has %lld outputs", (long long)F->ar_max_elems, (long long)L->N);
     }
     const int64_t min_stride = (F->prologue == PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
@@ -274,7 +275,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.x_sstride = E ? E->x_slot_stride : 0;
   a.y_sstride = E ? E->y_slot_stride : 0;
   a.x_div = E ? E->x_slot_div : 1;
-  a.ar_peers = ar ? (unsigned char* const*)F->ar_peers : nullptr;
+  for (int r = 0; r < kArMaxWorld; ++r) a.ar_peer[r] = (ar && r < F->ar_world) ? (unsigned char*)F->ar_peers[r] : nullptr;
   a.ar_mine = ar ? (unsigned char*)F->ar_own : nullptr;
   a.ar_state = ar ? (unsigned*)F->ar_state : nullptr;
   a.ar_world = ar ? F->ar_world : 0;

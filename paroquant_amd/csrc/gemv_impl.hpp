@@ -78,8 +78,9 @@ struct GemvArgs {
   int x_div;
   // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
   // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
-  unsigned char* const* ar_peers;   // device array [world]: every rank's buffer as mapped in this process, or null
-  unsigned char* ar_mine;           // == ar_peers[ar_rank]
+  unsigned char* ar_peer[kArMaxWorld];   // every rank's buffer as mapped in this process, BY VALUE: a pointer fetched from device
+                                         // memory per peer is a dependent ~0.5 us round trip in front of every store
+  unsigned char* ar_mine;           // == ar_peer[ar_rank]; null = no all-reduce epilogue
   unsigned* ar_state;               // ordinary device memory, zero at creation: [0] gave up once, [kArStateTiles + t] epoch of column tile t
   int ar_world, ar_rank;
   long long ar_slot;                // granules per (set, rank) slot of the fp32 region
@@ -354,6 +355,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int nt = min(TPW, p_t1 - tile0);
   const int ts0 = p_sz0 + ltile0;
   const unsigned szrow = (unsigned)(h.tsz >> 2) * 64u;  // words per group row of the scale/zero array
+  // all-reduce epilogue (its own instantiations): the epoch of this thread's first output tile, whether the buffer has
+  // given up before, and -- lane p -- rank p's buffer address, requested FIRST: after a kernel boundary they are misses
+  // like x and the coefficients, and the whole kernel hides them.  Everything the epilogue needs is read through a
+  // LAUNDERED kernarg pointer, here into vector registers and again at the epilogue: the kernel sits at the scalar-
+  // register limit, and argument fields the compiler fetches at entry and keeps live spilled ~400 v_readlane into
+  // the main loop (+2.5 us per launch).  Epochs are kept PER 16-COLUMN TILE in ordinary L2-cached memory: whatever
+  // launch shape owns a tile, its tag sequence grows by one per launch, on every rank alike; no arrival count, no atomic
+  // (256 workgroups taking a ticket on one word cost more than the launch this epilogue saves).
+  typedef const __attribute__((address_space(4))) unsigned char* KArgP;
+  typedef __attribute__((address_space(1))) unsigned* GWP;
+  unsigned ar_first = 0, ar_gaveup = 0;
+  unsigned long long ar_ptr = 0;
+  if constexpr (AREP) {
+    KArgP ka = (KArgP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    GP<unsigned> st = (GP<unsigned>)*(const __attribute__((address_space(4))) unsigned long long*)(ka + offsetof(GemvArgs, ar_state));
+    ar_first = st[kArStateTiles + tile0 + min(tid / (MRT * 64), max(nt - 1, 0))];
+    ar_gaveup = st[0];
+    ar_ptr = *(GP<unsigned long long>)((unsigned long long)ka + offsetof(GemvArgs, ar_peer) + 8u * (unsigned)(lane & (kArMaxWorld - 1)));
+  }
 
   // Every load is unconditional (ragged column blocks re-read their last tile and mask it later; waves
   // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
@@ -655,50 +676,63 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   }
 
   if constexpr (DIAG == 3) ts[5] = stamp_after(acc[0][0]);  // all units done
-  // all-reduce epilogue: the epoch of this thread's first output tile (and whether the buffer has given up before),
-  // requested ahead of the barriers that hide the round trip.  Epochs are kept PER 16-COLUMN TILE in ordinary L2-cached
-  // memory: whatever launch shape owns a tile, its tag sequence grows by one per launch, on every rank alike; no arrival
-  // count, no atomic (256 workgroups taking a ticket on one word cost more than the launch this epilogue saves).
-  unsigned ar_first = 0;
-  int ar_limit = 0;
+  // the epilogue's scalars, fetched here (a second laundered pointer: nothing of it is live in the main loop)
+  int ar_world = 0, ar_rank = 0;
+  long long ar_slot = 0, ar_off = 0;
+  GWP ar_st = nullptr;
   if constexpr (AREP) {
-    if (a.ar_peers) {
-      ar_first = a.ar_state[kArStateTiles + tile0 + min(tid / (MRT * 64), max(nt - 1, 0))];
-      ar_limit = a.ar_state[0] != 0u ? 0 : (1 << 22);
-    }
+    KArgP kb = (KArgP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kb));
+    ar_st = (GWP)*(const __attribute__((address_space(4))) unsigned long long*)(kb + offsetof(GemvArgs, ar_state));
+    ar_world = *(const __attribute__((address_space(4))) int*)(kb + offsetof(GemvArgs, ar_world));
+    ar_rank = *(const __attribute__((address_space(4))) int*)(kb + offsetof(GemvArgs, ar_rank));
+    ar_slot = *(const __attribute__((address_space(4))) long long*)(kb + offsetof(GemvArgs, ar_slot));
+    ar_off = *(const __attribute__((address_space(4))) long long*)(kb + offsetof(GemvArgs, ar_off));
   }
+  auto ar_peer_base = [&](int r) -> unsigned char* {   // rank r's buffer: lane r of ar_ptr
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ar_ptr, r);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(ar_ptr >> 32), r);
+    return (unsigned char*)(((unsigned long long)hi << 32) | lo);
+  };
   // every rank's partial of output column `col` -> the world's sum (rank order, fp32: bit-identical on all ranks)
+  // (kept small: this code runs once per launch from a cold instruction cache -- the first version, unrolled 16 ways at
+  // two call sites, was 2000 instructions of mostly skipped blocks, every skip a taken branch into an unfetched line)
   auto ar_exchange = [&](float v, int col, unsigned ar_epoch) -> float {
-    const long long set0 = a.ar_off + (long long)((int)(ar_epoch & 1u) * a.ar_world) * a.ar_slot * 8;
+    const long long set0 = ar_off + (long long)((int)(ar_epoch & 1u) * ar_world) * ar_slot * 8;
     const unsigned long long gran = ((unsigned long long)ar_epoch << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
-    for (int p = 0; p < a.ar_world; ++p) {
-      if (p == a.ar_rank) continue;
-      unsigned long long* dst = (unsigned long long*)(a.ar_peers[p] + set0) + (long long)a.ar_rank * a.ar_slot + col;
+    for (int p = 0; p < ar_world; ++p) {
+      if (p == ar_rank) continue;
+      unsigned long long* dst = (unsigned long long*)(ar_peer_base(p) + set0) + (long long)ar_rank * ar_slot + col;
       __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const unsigned long long* src = (const unsigned long long*)(a.ar_mine + set0) + col;
-    unsigned long long got[kArMaxWorld];
-    bool all = false;
-    for (int spin = 0; !all; ++spin) {
-#pragma unroll
-      for (int r = 0; r < kArMaxWorld; ++r)
-        if (r < a.ar_world && r != a.ar_rank) got[r] = __hip_atomic_load(src + (long long)r * a.ar_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      all = true;
-#pragma unroll
-      for (int r = 0; r < kArMaxWorld; ++r)
-        if (r < a.ar_world && r != a.ar_rank) all = all && (unsigned)(got[r] >> 32) == ar_epoch;
-      if (all) break;
-      if (spin >= ar_limit) {
-        ((unsigned*)a.ar_mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
-        a.ar_state[0] = 1u;                                  // ... and by later launches, which poll once instead of waiting again
-        break;
-      }
-      if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
-    }
+    unsigned char* mine = ar_peer_base(ar_rank);
+    const unsigned long long* src = (const unsigned long long*)(mine + set0) + col;
+    constexpr int CH = 8;   // peers polled at once: one round for a world of up to 8, two for 16
     float s = 0.f;
+    for (int r0 = 0; r0 < ar_world; r0 += CH) {
+      unsigned long long got[CH];
+      bool all = false;
+      for (int spin = 0; !all; ++spin) {
 #pragma unroll
-    for (int r = 0; r < kArMaxWorld; ++r)
-      if (r < a.ar_world) s += r == a.ar_rank ? v : __builtin_bit_cast(float, (unsigned)got[r]);
+        for (int q = 0; q < CH; ++q)
+          if (r0 + q < ar_world && r0 + q != ar_rank) got[q] = __hip_atomic_load(src + (long long)(r0 + q) * ar_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = true;
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+          if (r0 + q < ar_world && r0 + q != ar_rank) all = all && (unsigned)(got[q] >> 32) == ar_epoch;
+        if (all) break;
+        if (spin >= (ar_gaveup != 0u ? 0 : (1 << 22))) {
+          ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
+          ar_st[0] = 1u;                                  // ... and by later launches, which poll once instead of waiting again
+          ar_gaveup = 1u;
+          break;
+        }
+        if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q)   // rank order, the own partial in its place: the same sum on every rank
+        if (r0 + q < ar_world) s += r0 + q == ar_rank ? v : __builtin_bit_cast(float, (unsigned)got[q]);
+    }
     return s;
   };
   // ---- reduce the workgroup's waves (different groups, same columns) through LDS
@@ -756,24 +790,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           v *= __builtin_amdgcn_rsqf(ss / (float)h.K + a.eps);
         }
       }
-      if constexpr (AREP) {
-        if (a.ar_peers) {
-          unsigned ep = (e == tid ? ar_first : a.ar_state[kArStateTiles + (col >> 4)]) + 1u;
-          if (ep == 0u) ep = 2u;   // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
-          v = ar_exchange(v, col, ep);
-          if ((col & 15) == 0) a.ar_state[kArStateTiles + (col >> 4)] = ep;   // the tile's 16 lanes read it in one instruction, before this store
+      if constexpr (!AREP) {
+        if (a.bias) v += A::to_f32(a.bias[col]);
+        if constexpr (FMODE) {
+          if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
         }
+        y_p[(int64_t)b * h.N + col] = A::from_f32(v);
       }
-      if (a.bias) v += A::to_f32(a.bias[col]);
-      if constexpr (FMODE) {
-        if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
-      }
-      y_p[(int64_t)b * h.N + col] = A::from_f32(v);
     } else if (ks != h.ksplit - 1) {
       // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
       const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
       __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * h.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (AREP) continue;
     } else {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
       // partial in registers, poll the other splits' granules until their tags appear (bounded),
@@ -812,19 +841,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           }
         }
       }
-      if constexpr (AREP) {
-        if (a.ar_peers) {
-          unsigned ep = (e == tid ? ar_first : a.ar_state[kArStateTiles + (col >> 4)]) + 1u;
-          if (ep == 0u) ep = 2u;   // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
-          v = ar_exchange(v, col, ep);
-          if ((col & 15) == 0) a.ar_state[kArStateTiles + (col >> 4)] = ep;   // the tile's 16 lanes read it in one instruction, before this store
+      if constexpr (!AREP) {
+        if (a.bias) v += A::to_f32(a.bias[col]);
+        if constexpr (FMODE) {
+          if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
         }
+        y_p[(int64_t)b * h.N + col] = A::from_f32(v);
       }
+    }
+    if constexpr (AREP) {
+      // the world's sum of this column (ONE call site), then bias and residual once, the store, and the tile's next epoch
+      unsigned ep = (e == tid ? ar_first : ar_st[kArStateTiles + (col >> 4)]) + 1u;
+      if (ep == 0u) ep = 2u;   // tag 0 is "never written"; 2 keeps the set parity alternating across the wrap
+      v = ar_exchange(v, col, ep);
       if (a.bias) v += A::to_f32(a.bias[col]);
-      if constexpr (FMODE) {
-        if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
-      }
+      if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
       y_p[(int64_t)b * h.N + col] = A::from_f32(v);
+      // (after the output store: a store in front of the residual read would be waited for -- vmcnt counts stores;
+      // the tile's 16 lanes read the word in one instruction, before this store)
+      if ((col & 15) == 0) ar_st[kArStateTiles + (col >> 4)] = ep;
     }
   }
   if constexpr (DIAG == 3) {
@@ -897,7 +932,7 @@ int launch_waves_fused_mode(const GemvArgs& a, int waves, dim3 grid, hipStream_t
 }
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if (a.ar_peers) {   // + all-reduce epilogue (FUSED | 4): one row only
+  if (a.ar_mine) {   // + all-reduce epilogue (FUSED | 4): one row only
     if constexpr (MB == 1) {
       if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 6>(a, waves, grid, st);
       return launch_waves_fused_mode<AT, TPW, MB, PREROT, 5>(a, waves, grid, st);
@@ -940,7 +975,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_peers) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

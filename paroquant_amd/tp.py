@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Sequence
 
+import ctypes
 import torch
 import torch.distributed as dist
 
@@ -126,7 +127,7 @@ class OneShotAllReduce:
                             nat.check(self.lib.paro_allreduce_buffer_open(gathered[r], ctypes.byref(p)))
                             self._opened.append(p.value)
                             ptrs.append(p.value)
-                    self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+                    self.peers = (ctypes.c_void_p * self.world)(*ptrs)     # HOST array: the library copies it into the launch arguments
                     # launch state of the GEMV's all-reduce epilogue (give-up flag, one epoch per 16-column tile): ordinary cached memory
                     self._gemv_state = torch.zeros(16 + (self.max_elems + 15) // 16, dtype=torch.int32, device=self.device)
                     torch.cuda.synchronize(self.device)
@@ -165,14 +166,14 @@ class OneShotAllReduce:
             raise ValueError("residual / out must match y (contiguous, same dtype and size)")
         with torch.cuda.device(y.device):
             self.nat.check(self.lib.paro_allreduce_oneshot(y.data_ptr(), None if residual is None else residual.data_ptr(), out.data_ptr(), n,
-                                                           self.nat.dtype_code(y.dtype), self.peers.data_ptr(), self.world, self.rank,
+                                                           self.nat.dtype_code(y.dtype), ctypes.cast(self.peers, ctypes.c_void_p), self.world, self.rank,
                                                            self.max_elems, self.nat.current_stream_ptr(y.device)))
         return out
 
     def fusion_args(self):
         """(peers, own, state, world, rank, max_elems) for ``paro_fusion_t``'s all-reduce epilogue (``ops.w4a16_gemv_fused(...,
         allreduce=self)``): the row-parallel GEMV exchanges its partial outputs itself, no separate launch."""
-        return self.peers.data_ptr(), self._own, self._gemv_state.data_ptr(), self.world, self.rank, self.max_elems
+        return ctypes.cast(self.peers, ctypes.c_void_p), self._own, self._gemv_state.data_ptr(), self.world, self.rank, self.max_elems
 
     def gave_up(self) -> bool:
         """True when a call timed out waiting for a peer (sticky status word; synchronises the current stream)."""

@@ -1435,11 +1435,11 @@ def test_oneshot_allreduce_absent_peer_gives_up_once(dev):
         nat.check(lib.paro_allreduce_buffer_create(nbytes, ctypes.byref(p), h))
         bufs.append(p.value)
     try:
-        peers = torch.tensor(bufs, dtype=torch.int64, device=dev)
+        peers = (ctypes.c_void_p * 2)(*bufs)                    # host array of the two buffers
         x = torch.randn(n, device=dev, dtype=torch.float16)
         y = torch.empty_like(x)
         st = nat.current_stream_ptr(dev)
-        call = lambda: nat.check(lib.paro_allreduce_oneshot(x.data_ptr(), None, y.data_ptr(), n, nat.dtype_code(x.dtype), peers.data_ptr(), 2, 0, n, st))
+        call = lambda: nat.check(lib.paro_allreduce_oneshot(x.data_ptr(), None, y.data_ptr(), n, nat.dtype_code(x.dtype), ctypes.cast(peers, ctypes.c_void_p), 2, 0, n, st))
         assert lib.paro_allreduce_status(bufs[0], st) == 0
         t0 = time.perf_counter()
         call()

@@ -312,7 +312,8 @@ def test_allreduce_epilogue_host_checks(lib):
     def call(rows=1, prologue=0, world=2, rank=0, max_elems=512, own=1, state=1):
         f = nat.ParoFusion()
         f.prologue, f.eps, f.x_stride = prologue, 1e-6, 0
-        f.ar_peers, f.ar_own, f.ar_state, f.ar_world, f.ar_rank, f.ar_max_elems = 1, own, state, world, rank, max_elems
+        peers = (ctypes.c_void_p * 16)(*([1] * 16))             # host array; every "buffer" at the fake address 1
+        f.ar_peers, f.ar_own, f.ar_state, f.ar_world, f.ar_rank, f.ar_max_elems = ctypes.cast(peers, ctypes.c_void_p), own, state, world, rank, max_elems
         rc = lib.paro_w4a16_gemv_fused(ctypes.byref(d), one, one, rows, one, 1 << 20, ctypes.byref(f), None)
         return rc, lib.paro_last_error().decode()
 
@@ -328,6 +329,8 @@ def test_allreduce_epilogue_host_checks(lib):
     assert rc == -1 and "sized for 256" in msg
     rc, msg = call(state=None)
     assert rc == -1 and "ar_state" in msg
+    rc, msg = call(own=2)
+    assert rc == -1 and "ar_peers[ar_rank]" in msg
     # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
     assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
     assert lib.paro_allreduce_buffer_bytes(17, 8192) == -1 and lib.paro_allreduce_buffer_bytes(2, 4) == -1
