@@ -50,44 +50,48 @@ __global__ __launch_bounds__(kArThreads) void allreduce_oneshot_kernel(const ArA
     const unsigned mydata = a.x[g];
     const unsigned long long gran = ((unsigned long long)epoch << 32) | mydata;
     // 1. my granule into slot (set, rank) of every peer: one 8-byte store each, data and tag together
-#pragma unroll
-    for (int p = 0; p < kArMaxWorld; ++p) {
-      if (p < a.world && p != a.rank) {
-        unsigned long long* dst = (unsigned long long*)(a.peers[p] + kArDataOff) + slot0 + (long long)a.rank * a.slot_granules + g;
-        __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+    for (int p = 0; p < a.world; ++p) {
+      if (p == a.rank) continue;
+      unsigned long long* dst = (unsigned long long*)(a.peers[p] + kArDataOff) + slot0 + (long long)a.rank * a.slot_granules + g;
+      __hip_atomic_store(dst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const unsigned res = a.residual ? a.residual[g] : 0u;
-    // 2. the peers' granules of this epoch: every poll of a round is issued before any is looked at; fast polls first
-    // (the common case: the peers are a few microseconds apart), then ~1 us naps -- ranks may be far apart once (a peer
-    // still capturing its graph while this one already replays), so the bound is seconds, not milliseconds
+    // 2. the peers' granules of this epoch, 8 peers per round (one round for a world of up to 8): every poll of a round
+    // is issued before any is looked at; fast polls first (the common case: the peers are a few microseconds apart), then
+    // ~1 us naps -- ranks may be far apart once (a peer still capturing its graph while this one already replays), so the
+    // bound is seconds, not milliseconds.  3. summed in rank order (the same order on every rank: bit-identical results).
+    // (Compact on purpose: 16-way unrolled, mostly skipped blocks cost this launch-latency-bound kernel microseconds.)
     const unsigned long long* src = (const unsigned long long*)(mine + kArDataOff) + slot0 + g;
-    unsigned long long got[kArMaxWorld];
-    bool all = false;
-    for (int spin = 0; !all; ++spin) {
-#pragma unroll
-      for (int r = 0; r < kArMaxWorld; ++r)
-        if (r < a.world && r != a.rank) got[r] = __hip_atomic_load(src + (long long)r * a.slot_granules, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      all = true;
-#pragma unroll
-      for (int r = 0; r < kArMaxWorld; ++r)
-        if (r < a.world && r != a.rank) all = all && (unsigned)(got[r] >> 32) == epoch;
-      if (all) break;
-      if (spin >= spin_limit) {
-        ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
-        break;
-      }
-      if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
-    }
-    // 3. sum in rank order (the same order on every rank: bit-identical results), one rounding
+    constexpr int CH = 8;
     float lo = 0.f, hi = 0.f;
+    bool gave_up = spin_limit == 0;
+    for (int r0 = 0; r0 < a.world; r0 += CH) {
+      unsigned long long got[CH];
+      bool all = false;
+      for (int spin = 0; !all; ++spin) {
 #pragma unroll
-    for (int r = 0; r < kArMaxWorld; ++r)
-      if (r < a.world) {
-        const unsigned v = r == a.rank ? mydata : (unsigned)got[r];
-        lo += A::to_f32(v & 0xffffu);
-        hi += A::to_f32(v >> 16);
+        for (int q = 0; q < CH; ++q)
+          if (r0 + q < a.world && r0 + q != a.rank) got[q] = __hip_atomic_load(src + (long long)(r0 + q) * a.slot_granules, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = true;
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+          if (r0 + q < a.world && r0 + q != a.rank) all = all && (unsigned)(got[q] >> 32) == epoch;
+        if (all) break;
+        if (gave_up || spin >= spin_limit) {
+          ((unsigned*)mine)[1] = PARO_WS_STATUS_GIVEUP;   // a peer never arrived: sticky, read by the host
+          gave_up = true;
+          break;
+        }
+        if (spin < 4096) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
       }
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+        if (r0 + q < a.world) {
+          const unsigned v = r0 + q == a.rank ? mydata : (unsigned)got[q];
+          lo += A::to_f32(v & 0xffffu);
+          hi += A::to_f32(v >> 16);
+        }
+    }
     if (a.residual) {
       lo += A::to_f32(res & 0xffffu);
       hi += A::to_f32(res >> 16);
