@@ -67,7 +67,14 @@ def _worker(rank, world, port, q):
         tgt = torch.zeros(8, K // world, dtype=torch.int16)
         sl = _maybe_shard_input(tgt, layer["pairs"][0])
         ok_loader = torch.equal(sl, layer["pairs"][0][:, rank * (K // world):(rank + 1) * (K // world)])
-        q.put((rank, bool(ok_col), bool(ok_row), bool(ok_loader)))
+        # the collective a TP decode step asks for: without a GPU the one-shot buffers cannot be set up -- on EVERY rank
+        # alike (no rank is left waiting in a collective the others skipped) -- and the backend's all-reduce takes over,
+        # with the residual added after the sum
+        fn, name = tp.make_allreduce(torch.device("cuda", 0), 256)
+        part = torch.full((256,), float(rank + 1))
+        out = fn(part.clone(), residual=torch.ones(256))
+        ok_fallback = name == "gloo" and torch.equal(out, torch.full((256,), float(world * (world + 1) // 2 + 1)))
+        q.put((rank, bool(ok_col), bool(ok_row), bool(ok_loader and ok_fallback)))
     finally:
         dist.destroy_process_group()
 
