@@ -64,6 +64,7 @@ timeout 200 python tools/bench_attn.py --tmax 2048 >> $P/${R}_attn_decode.jsonl 
 timeout 300 python tools/bench_vendor.py --model llama3-8b > $P/${R}_vendor_llama3-8b.jsonl 2>> $OUT/vendor.err
 timeout 200 python tools/bench_vendor.py --model qwen3-4b --rows 1,8192 > $P/${R}_vendor_qwen3-4b.jsonl 2>> $OUT/vendor.err
 [ -x tools/probes/barrier_probe ] && timeout 100 tools/probes/barrier_probe > $P/${R}_grid_barrier_probe.jsonl 2>> $OUT/vendor.err
+[ -x tools/probes/coldcode_probe ] && timeout 60 tools/probes/coldcode_probe > $P/${R}_coldcode_probe.jsonl 2>> $OUT/vendor.err
 [ -x tools/probes/kernarg_probe_sload ] && { timeout 60 tools/probes/kernarg_probe_sload; timeout 60 tools/probes/kernarg_probe_preload; } > $P/${R}_kernarg_probe.jsonl 2>> $OUT/vendor.err
 if [ -f paroquant_amd/_lib_diag/libparo_mi355x.so ]; then
   rm -f $P/${R}_gemv_timeline.txt
@@ -72,6 +73,7 @@ if [ -f paroquant_amd/_lib_diag/libparo_mi355x.so ]; then
     PARO_LIB_DIR=_lib_diag PARO_GEMV_PD=31 timeout 100 python tools/timeline_gemv.py --model qwen3-4b --linear $1 --tpw $2 --waves $3 2>> $OUT/vendor.err | grep -v amdgpu.ids >> $P/${R}_gemv_timeline.txt
   done
 fi
+timeout 200 python tools/bench_fused.py --model llama3-70b --tp 8 2>> $OUT/vendor.err | grep '^{' > $P/${R}_fused_tp8.jsonl
 # ---- tensor parallel: what one rank of llama3-70b costs per token at TP = 1 / 2 / 4 / 8 (upper bound of the node's tokens/s)
 timeout 400 python tools/tp_rank_projection.py 2>> $OUT/vendor.err | grep '^{' > $P/${R}_tp_rank_projection.jsonl
 mkdir -p $ROOT/gpurun_out/$R/profiles_copy && cp $P/${R}_* $ROOT/gpurun_out/$R/profiles_copy/
