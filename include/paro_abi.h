@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 9
+#define PARO_ABI_VERSION 10
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -183,7 +183,10 @@ int paro_workspace_status(const void* workspace, void* stream);
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in 1..8 (3, 5, 6, 7: fused mode, <= 4 rows, 8 waves);
  * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
- * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above). */
+ * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above),
+ * 2 (v10) = x IS ALREADY ROTATED by the caller: [n_parts][rows][K] in the activation type, partition p rotated with
+ * partition p's pairs / theta / channel_scales (rotation::rotate, or the epilogue of whatever kernel produced x) -- the
+ * same pre-rotated kernels as mode 1 without the pre-pass launch. */
 /* The launch shape paro_w4a16_gemv resolves the knobs to (in: 0 / -1 = auto, out: final values) -- host-only,
  * touches no device memory: for tooling, logs and tests of the heuristics. */
 int paro_gemv_launch_shape(const paro_linear_t* L, int64_t rows, int* tiles_per_wave, int* ksplit, int* waves, int* mode);

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 9
+PARO_ABI_VERSION = 10
 PARO_MAX_PARTS = 8
 PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384

@@ -129,8 +129,9 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
-  if (mode != 0 && mode != 1) return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused) or 1 (rotate pre-pass)");
-  if (L->krot > 8 || rows > 16) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
+  if (mode != 0 && mode != 1 && mode != 2)
+    return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused), 1 (rotate pre-pass) or 2 (x is already rotated)");
+  if (mode != 2 && (L->krot > 8 || rows > 16)) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
   // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
   // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
   // front with the stage kernel is cheaper (measured, Llama-3-8B shapes, us fused / pre-pass:
@@ -213,7 +214,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (F->prologue < PARO_PROLOGUE_NONE || F->prologue > PARO_PROLOGUE_SILU_MUL) return fail(PARO_ERR_INVALID, "unknown prologue %d", F->prologue);
     if (rows > 4) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue is a decode path: at most 4 rows (got %lld)", (long long)rows);
     if (L->krot > 8) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue needs the in-kernel rotation (krot <= 8)");
-    if (mode == 1) return fail(PARO_ERR_INVALID, "fused prologue / epilogue needs mode 0 (in-kernel rotation)");
+    if (mode == 1 || mode == 2) return fail(PARO_ERR_INVALID, "fused prologue / epilogue needs mode 0 (in-kernel rotation)");
     mode = 0;
     // sum(x^2) of the RMSNorm prologue is collected per workgroup: every workgroup must cover all of K
     if (F->prologue == PARO_PROLOGUE_RMSNORM) {
@@ -300,6 +301,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   }
   if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
+  // mode 2: the caller hands over rotated activations, [n_parts][rows][K] in the activation type (whoever produced x
+  // rotated it -- rotation::rotate per partition, or a producer kernel's epilogue): the pre-rotated kernels, no pre-pass
   if (mode == 1) {
     unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);
     // ONE launch rotates x with every merged partition's parameters (blockIdx.z = partition)
@@ -318,7 +321,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
       {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, launch_gemv_bf16_0_t3, launch_gemv_bf16_0_t4, launch_gemv_bf16_0_t5,
         launch_gemv_bf16_0_t6, launch_gemv_bf16_0_t7, launch_gemv_bf16_0_t8},
        {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, nullptr, launch_gemv_bf16_1_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_1_t8}}};
-  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode == 1 ? 1 : 0][tpw - 1] : nullptr;
+  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode >= 1 ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
   rc = fn(a, wv, grid, st);
   if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1) {

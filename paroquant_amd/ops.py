@@ -240,10 +240,26 @@ def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_si
 def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int = 0, mode: int = 0,
                      bias=None) -> torch.Tensor:
     """Direct call of ``paro_w4a16_gemv`` with explicit launch-shape knobs (benchmarks / tuning sweeps).
-    ``pk`` is a :class:`paroquant_amd.linear.PackedParoWeights`."""
+    ``pk`` is a :class:`paroquant_amd.linear.PackedParoWeights`.  ``mode = 2``: ``x`` is ``[n_parts, rows, K]``, already
+    rotated per partition by the caller (``rotation::rotate`` or a producer kernel); returns ``[rows, N]``."""
     lib = nat.load()
     _check_linear_args(x, pk.pairs, pk.theta, pk.channel_scales, bias, pk.partition_sizes)
     K, N = pk.K, pk.N
+    if mode == 2:
+        P = len(pk.partition_sizes)
+        if x.dim() != 3 or x.size(0) != P or x.size(-1) != K:
+            raise ValueError(f"mode 2 takes pre-rotated activations [n_parts = {P}, rows, K = {K}], got {tuple(x.shape)}")
+        x2 = x.contiguous()
+        rows = x2.size(1)
+        y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
+        d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                      pk.channel_scales, bias, pk.wq_order)
+        ws = pk.workspace
+        with torch.cuda.device(x.device):
+            nat.check(lib.paro_w4a16_gemv(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+                                          ws.numel() * ws.element_size(), tiles_per_wave, ksplit, waves, 2,
+                                          nat.current_stream_ptr(x.device)))
+        return y
     x2 = x.reshape(-1, K).contiguous()
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)

@@ -275,6 +275,31 @@ def test_gemv_matches_oracle(dev, K, sizes, rows):
     assert np.isfinite(got).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,sizes", [(1536, [400, 112]), (2560, [4096, 1024, 1024]), (1024, [256])])
+def test_gemv_on_caller_rotated_activations(dev, dtype, K, sizes):
+    """mode 2 (ABI v10): x arrives already rotated, [n_parts][rows][K] -- here by rotation::rotate with each partition's
+    parameters, as a producer kernel's epilogue would -- and the GEMV runs the pre-rotated kernels without a pre-pass:
+    bit-identical to the library's own pre-pass route (mode 1), and within tolerance of the float64 oracle."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + len(sizes), K, sizes, bias=True)
+    pk = _packed(L, dev)
+    bias = _t(L["bias"], dev, dtype)
+    rng = np.random.default_rng(K)
+    for rows in (1, 3, 8, 16):
+        x = _t(rng.standard_normal((rows, K)).astype(np.float32), dev, dtype)
+        xr = torch.stack([torch.ops.rotation.rotate(x, pk.pairs[p], pk.theta[p], pk.channel_scales.reshape(len(sizes), 1, K)[p])
+                          for p in range(len(sizes))])
+        y2 = ops.w4a16_gemv_tuned(xr, pk, 0, 0, 0, 2, bias)
+        y1 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 1, bias)
+        assert y2.shape == (rows, sum(sizes)) and torch.equal(y2, y1)
+        ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                      L["channel_scales"], sizes, _np(bias), ideal=True)
+        assert po.rel_err(_np(y2), ideal) < (TIGHT_F16 if dtype == torch.float16 else TIGHT_BF16)
+    with pytest.raises(ValueError, match="pre-rotated"):
+        ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 2, bias)              # [rows, K] is not the pre-rotated layout
+
+
 @pytest.mark.parametrize("tpw", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("ksplit,waves,mode", [(1, 4, 0), (2, 4, 0), (3, 8, 0), (0, 0, 0), (1, 16, 0), (2, 16, 0),
                                                (1, 0, 1), (2, 4, 1)])

@@ -331,6 +331,12 @@ def test_allreduce_epilogue_host_checks(lib):
     assert rc == -1 and "ar_state" in msg
     rc, msg = call(own=2)
     assert rc == -1 and "ar_peers[ar_rank]" in msg
+    # ABI v10: mode 2 (caller-rotated activations) is a launch-shape mode like 0 and 1; fused prologues need mode 0
+    t, k, w, m = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(2)
+    assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == 0 and m.value == 2
+    assert t.value in (1, 2, 4, 8)
+    m = ctypes.c_int(3)
+    assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == -1
     # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
     assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
     assert lib.paro_allreduce_buffer_bytes(17, 8192) == -1 and lib.paro_allreduce_buffer_bytes(2, 4) == -1
