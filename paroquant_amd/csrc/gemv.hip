@@ -94,6 +94,11 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   if (tpw <= 0) {
     if (tiles >= 1024)
       tpw = rows > 8 ? 4 : 8;
+    else if (tiles >= 768 && G >= 64 && rows <= 4)
+      // a caller that fixes ksplit (the RMSNorm prologue: 1) on a deep-K, almost-wide output -- TP = 4 gate_up,
+      // 8192 -> 14336: unsplit 4 x 16 waves 15.0 us, 2 x 16 waves 18.7 (profiles/r02_sweep_llama3-70b_tp4.jsonl;
+      // the fused launch read 19.0 with the 2-tile shape, profiles/r02_fused_tp4.jsonl)
+      tpw = 4;
     else if (tiles >= 320)
       tpw = 2;
     else
@@ -101,7 +106,9 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   }
   if (ksplit <= 0) ksplit = 1;
   if (waves <= 0) {
-    if (rows > 4 || tpw > 2 || G < 16)
+    if (tpw == 4 && tiles >= 768 && tiles < 1024 && G >= 64 && rows <= 4)
+      waves = 16;
+    else if (rows > 4 || tpw > 2 || G < 16)
       waves = G >= 8 ? 8 : 4;
     else
       waves = 16;

@@ -241,6 +241,11 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*l8["qkv_proj"], 8)[3] == 0 and shape(*l8["qkv_proj"], 9)[3] == 1
     assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 5)[3] == 1
     assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
+    # a caller that fixes ksplit = 1 (the RMSNorm prologue) gets the best UNSPLIT shape of the sweeps, not a 2-tile default:
+    # TP = 4 gate_up shard (8192 -> 2 x 7168) 4 tiles x 16 waves; narrow deep-K shards 1 tile x 16 waves
+    assert shape(8192, [7168, 7168], 1, ksplit=1) == (4, 1, 16, 0) == shape(8192, [7168, 7168], 1)
+    assert shape(8192, [2048, 256, 256], 1, ksplit=1) == (1, 1, 16, 0)
+    assert shape(*l8["qkv_proj"], 1, ksplit=1) == (2, 1, 16, 0) and shape(*q4["gate_up_proj"], 1, ksplit=1) == (8, 1, 8, 0)
     # explicit knobs are respected, empty K-splits dropped
     assert shape(1536, [512], 1, tpw=2, ksplit=5, waves=8, mode=0) == (2, 4, 8, 0)
     with pytest.raises(RuntimeError):
