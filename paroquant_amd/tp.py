@@ -81,9 +81,12 @@ def row_parallel_forward(apply_fn, x_full: torch.Tensor, rank: int, world: int, 
 
 class OneShotAllReduce:
     """All-reduce(SUM) of the row-parallel linears' small decode outputs in ONE kernel launch per rank
-    (``paro_allreduce_oneshot``, csrc/allreduce.hip): every rank stores its vector straight into a slot of every peer's
-    buffer over xGMI, flags it, waits for the world's flags in its own buffer and sums in rank order.  No host work per
-    call, so a tensor-parallel decode step stays one HIP graph whatever the collective library can or cannot capture.
+    (``paro_allreduce_oneshot``, csrc/allreduce.hip): every rank stores its vector -- pairs of activations tagged with
+    the call's epoch, 8 bytes at a time -- straight into a slot of every peer's buffer over xGMI, polls the granules of
+    its own buffer until their tags read the epoch, and sums in rank order.  No host work per call, so a tensor-parallel
+    decode step stays one HIP graph whatever the collective library can or cannot capture.  The same object also feeds
+    the row-parallel GEMV's all-reduce EPILOGUE (``ops.w4a16_gemv_fused(..., allreduce=self)``, :meth:`fusion_args`):
+    the exchange then runs inside the GEMV launch and the separate kernel disappears.
 
     The per-rank buffers are FINE-GRAINED device memory allocated by the library (peers write into them and the owner
     polls them inside one kernel: ordinary device memory is coherent across GPUs only at kernel boundaries) and exchanged
