@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 10
+#define PARO_ABI_VERSION 11
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -299,13 +299,56 @@ int paro_lm_head(const void* x, const void* norm_weight, const void* W, void* lo
 int paro_argmax_advance(const void* workspace, int64_t vocab, int64_t* token, int32_t* pos, int64_t* out_tokens,
                         int64_t out_len, void* stream);
 
-/* Weight prefetch for decode harnesses that know the NEXT layer (no reference counterpart -- the
- * reference leaves scheduling to vLLM / HF generate).  Touches one dword per 128-byte line of up to
- * PARO_MAX_PREFETCH buffers (128-byte aligned) with `workgroups` x 256 threads and discards the data, pulling the
- * lines into the memory-side Infinity Cache.  Meant for a side branch of a captured decode step; purely a
- * performance hint: nothing is written (checksum, if non-NULL, receives the XOR of the touched dwords -- tests). */
-#define PARO_MAX_PREFETCH 16
-int paro_prefetch(const void* const* ptrs, const int64_t* bytes, int n, int workgroups, void* checksum, void* stream);
+/* ---------------------------------------------------------------------------
+ * Decode chain (v11): the same linear on activations that ARRIVE rotated, with the NEXT linear's rotation applied by
+ * the launch that produces its input.  The reference runs `rotate -> GEMM` per linear (transformers/modules.py:57-71,
+ * vllm/plugin.py:281-311); the rotation is block-diagonal over 128 channels, so the workgroup that finishes a
+ * 128-column block of linear i can apply linear i+1's pairs / theta / channel_scales to it once, instead of every
+ * workgroup of linear i+1 rotating all of x again:
+ *     y       = x_rot @ dequant(W) * rstd + bias + residual          (rstd from ssq_in, or 1)
+ *     next_x_rot[p'] = rotate_{next, p'}(act(y[:, col0 : col0 + next.K]) * next.channel_scales[p'])
+ *   x_rot        act_dtype [n_parts][rows][K]: partition p rotated with L's partition-p parameters
+ *                (paro_rotate_parts, rotation::rotate per partition, or a producer's next_x_rot)
+ *   y            act_dtype [rows][N], or NULL when only the consumer reads the result
+ *   residual     act_dtype [rows][N] added before the one rounding, or NULL
+ *   ssq_in       fp32 [rows][ssq_in_blocks]: partial sums of squares of the un-normalised vector that was rotated into
+ *                x_rot (a producer's ssq_out): y is scaled by rsqrt(sum / norm_dim + eps) -- the RMSNorm in front of
+ *                this linear, its weight folded into channel_scales (paro_fusion_t, PARO_PROLOGUE_RMSNORM); or NULL
+ *   ssq_out      fp32 [rows][N / 128]: sum of squares of each 128-column block of the rounded y, or NULL
+ *   next         the consuming linear (its rot / channel_scales / n_parts / K are read), or NULL
+ *   next_x_rot   act_dtype [next.n_parts][rows][next.K]
+ *   next_col0    first column of y the consumer reads (multiple of 128)
+ *   next_act     PARO_CHAIN_ACT_NONE, or PARO_CHAIN_ACT_SILU_MUL: L is the merged gate|up projection (two partitions of
+ *                next.K columns) and the consumer reads silu(gate) * up (mlx/modules.py:204-207 rotates the activation
+ *                output before down_proj the same way)
+ * rows 1..16; group_size 128; every partition a multiple of 128 columns; ksplit / waves: 0 = automatic.  The K-split of
+ * this family tags its granules with (block, per-block epoch) -- the epochs live in the first PARO_WS_COUNTER_BYTES of
+ * the workspace (zero-filled once by the caller, like the counters of paro_w4a16_gemv, with which the workspace can be
+ * shared); workspace >= paro_chain_workspace_bytes(L, rows). */
+#define PARO_CHAIN_ACT_NONE 0
+#define PARO_CHAIN_ACT_SILU_MUL 1
+typedef struct paro_chain {
+  const void* x_rot;
+  void* y;
+  const void* residual;
+  const float* ssq_in;
+  int32_t ssq_in_blocks;
+  float eps;
+  int64_t norm_dim;
+  float* ssq_out;
+  const struct paro_linear* next;
+  void* next_x_rot;
+  int64_t next_col0;
+  int32_t next_act;
+  int32_t reserved0;
+} paro_chain_t;
+int64_t paro_chain_workspace_bytes(const paro_linear_t* L, int64_t rows);
+int paro_chain_launch_shape(const paro_linear_t* L, const paro_chain_t* C, int64_t rows, int* ksplit, int* waves);
+int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t* C, int64_t rows, void* workspace,
+                          int64_t workspace_bytes, int ksplit, int waves, void* stream);
+/* Head of a chain: x [rows][K] rotated with every partition's parameters of L into x_rot [n_parts][rows][K] in ONE
+ * launch (the stage kernel behind rotation::rotate, rotation.cu:10-43). */
+int paro_rotate_parts(const paro_linear_t* L, const void* x, void* x_rot, int64_t rows, void* stream);
 
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */

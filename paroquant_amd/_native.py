@@ -14,9 +14,8 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 10
+PARO_ABI_VERSION = 11
 PARO_MAX_PARTS = 8
-PARO_MAX_PREFETCH = 16
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
 PARO_WS_STATUS_GIVEUP = 0xDEAD
@@ -48,7 +47,10 @@ EXPORTS = (
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
     "paro_dequant_packed",
-    "paro_prefetch",
+    "paro_chain_workspace_bytes",
+    "paro_chain_launch_shape",
+    "paro_w4a16_gemv_chain",
+    "paro_rotate_parts",
     "paro_allreduce_buffer_bytes",
     "paro_allreduce_buffer_create",
     "paro_allreduce_buffer_open",
@@ -97,7 +99,16 @@ class ParoExperts(Structure):
                 ("sz_stride_bytes", c_int64), ("x_slot_stride", c_int64), ("y_slot_stride", c_int64)]
 
 
+class ParoChain(Structure):
+    """``paro_chain_t`` (include/paro_abi.h)."""
+
+    _fields_ = [("x_rot", c_void_p), ("y", c_void_p), ("residual", c_void_p), ("ssq_in", c_void_p), ("ssq_in_blocks", c_int32),
+                ("eps", ctypes.c_float), ("norm_dim", c_int64), ("ssq_out", c_void_p), ("next", POINTER(ParoLinearDesc)),
+                ("next_x_rot", c_void_p), ("next_col0", c_int64), ("next_act", c_int32), ("reserved0", c_int32)]
+
+
 PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_MUL = 0, 1, 2
+CHAIN_ACT_NONE, CHAIN_ACT_SILU_MUL = 0, 1
 
 _lib = None
 
@@ -171,8 +182,15 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_linear.restype = c_int
     lib.paro_w4a16_linear.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p]
-    lib.paro_prefetch.restype = c_int
-    lib.paro_prefetch.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]
+    lib.paro_chain_workspace_bytes.restype = c_int64
+    lib.paro_chain_workspace_bytes.argtypes = [POINTER(ParoLinearDesc), c_int64]
+    lib.paro_chain_launch_shape.restype = c_int
+    lib.paro_chain_launch_shape.argtypes = [POINTER(ParoLinearDesc), POINTER(ParoChain), c_int64, POINTER(c_int), POINTER(c_int)]
+    lib.paro_w4a16_gemv_chain.restype = c_int
+    lib.paro_w4a16_gemv_chain.argtypes = [POINTER(ParoLinearDesc), POINTER(ParoChain), c_int64, c_void_p, c_int64, c_int, c_int,
+                                          c_void_p]
+    lib.paro_rotate_parts.restype = c_int
+    lib.paro_rotate_parts.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p]
     lib.paro_allreduce_buffer_bytes.restype = c_int64
     lib.paro_allreduce_buffer_bytes.argtypes = [c_int, c_int64]
     lib.paro_allreduce_buffer_create.restype = c_int

@@ -166,7 +166,7 @@ class PackedParoWeights:
         return self
 
     def stream_buffers(self):
-        """The buffers a decode launch streams from HBM (what ``ops.prefetch`` should touch for this layer)."""
+        """The buffers a decode launch streams from HBM ."""
         return [self.wq, self.sz, self.rot]
 
     def nbytes(self) -> int:

@@ -352,6 +352,90 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     return y
 
 
+def pk_desc(pk, act_dtype: torch.dtype, bias=None) -> nat.ParoLinearDesc:
+    """``paro_linear_t`` of a :class:`paroquant_amd.linear.PackedParoWeights`."""
+    return make_desc(pk.K, pk.partition_sizes, int(pk.pairs.size(1)), act_dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                     pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order)
+
+
+def rotate_parts(x: torch.Tensor, pk, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Head of a decode chain: ``x [rows, K]`` rotated with every merged partition's parameters of ``pk`` in one launch
+    -> ``[n_parts, rows, K]`` (``paro_rotate_parts``; the stage kernel behind ``rotation::rotate``)."""
+    lib = nat.load()
+    K, P = pk.K, len(pk.partition_sizes)
+    x2 = x.reshape(-1, K).contiguous()
+    rows = x2.size(0)
+    if out is None:
+        out = torch.empty((P, rows, K), dtype=x.dtype, device=x.device)
+    elif out.numel() != P * rows * K or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{P}, {rows}, {K}] tensor of {x.dtype}")
+    d = pk_desc(pk, x.dtype)
+    with torch.cuda.device(x.device):
+        nat.check(lib.paro_rotate_parts(ctypes.byref(d), x2.data_ptr(), out.data_ptr(), rows, nat.current_stream_ptr(x.device)))
+    return out
+
+
+def chain_gemv(x_rot: torch.Tensor, pk, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               ssq_in: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6, ssq_out: Optional[torch.Tensor] = None,
+               next_pk=None, next_x: Optional[torch.Tensor] = None, next_col0: int = 0, act: int = 0, write_y: bool = True,
+               ksplit: int = 0, waves: int = 0, bias: Optional[torch.Tensor] = None):
+    """One linear of a decode chain (``paro_w4a16_gemv_chain``): ``x_rot [n_parts, rows, K]`` arrives rotated;
+    ``y = x_rot @ dequant(W) * rstd + bias + residual`` with ``rstd = rsqrt(sum(ssq_in) / norm_dim + eps)`` when
+    ``ssq_in [rows, blocks]`` (a producer's ``ssq_out``) is given; ``ssq_out [rows, N / 128]`` receives the blocks' sums of
+    squares of y; with ``next_pk`` the launch also writes ``next_x [next.n_parts, rows, next.K]`` =
+    ``rotate_next(act(y[:, next_col0 : next_col0 + next.K]))`` (``act`` = nat.CHAIN_ACT_SILU_MUL: ``pk`` is the merged
+    gate|up projection and the consumer reads ``silu(gate) * up``).  Returns ``(y, next_x)``; ``y`` is None when
+    ``write_y`` is False (only the consumer reads the result).  rows <= 16."""
+    lib = nat.load()
+    K, N, P = pk.K, pk.N, len(pk.partition_sizes)
+    if x_rot.dim() != 3 or x_rot.size(0) != P or x_rot.size(2) != K or not x_rot.is_contiguous():
+        raise ValueError(f"x_rot must be a contiguous [n_parts = {P}, rows, K = {K}] tensor, got {tuple(x_rot.shape)}")
+    if x_rot.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"expected float16 or bfloat16 activations, got {x_rot.dtype}")
+    rows = x_rot.size(1)
+    dt, dev = x_rot.dtype, x_rot.device
+    y = None
+    if write_y:
+        y = out if out is not None else torch.empty((rows, N), dtype=dt, device=dev)
+        if y.numel() != rows * N or y.dtype != dt or not y.is_contiguous():
+            raise ValueError(f"out must be a contiguous [{rows}, {N}] tensor of {dt}")
+    if residual is not None and (residual.dtype != dt or residual.numel() != rows * N or not residual.is_contiguous()):
+        raise ValueError("residual must be a contiguous [rows, N] tensor of the activation dtype")
+    c = nat.ParoChain()
+    c.x_rot = x_rot.data_ptr()
+    c.y = y.data_ptr() if y is not None else None
+    c.residual = residual.data_ptr() if residual is not None else None
+    if ssq_in is not None:
+        if ssq_in.dtype != torch.float32 or ssq_in.dim() != 2 or ssq_in.size(0) != rows or not ssq_in.is_contiguous():
+            raise ValueError("ssq_in must be a contiguous fp32 [rows, blocks] tensor")
+        c.ssq_in, c.ssq_in_blocks, c.norm_dim, c.eps = ssq_in.data_ptr(), int(ssq_in.size(1)), int(norm_dim), float(eps)
+    if ssq_out is not None:
+        if ssq_out.dtype != torch.float32 or ssq_out.numel() != rows * (N // 128) or not ssq_out.is_contiguous():
+            raise ValueError(f"ssq_out must be a contiguous fp32 [rows, {N // 128}] tensor")
+        c.ssq_out = ssq_out.data_ptr()
+    d = pk_desc(pk, dt, bias)
+    dn = None
+    if next_pk is not None:
+        Pn, Kn = len(next_pk.partition_sizes), next_pk.K
+        if next_x is None:
+            next_x = torch.empty((Pn, rows, Kn), dtype=dt, device=dev)
+        elif next_x.numel() != Pn * rows * Kn or next_x.dtype != dt or not next_x.is_contiguous():
+            raise ValueError(f"next_x must be a contiguous [{Pn}, {rows}, {Kn}] tensor of {dt}")
+        dn = pk_desc(next_pk, dt)
+        c.next = ctypes.pointer(dn)
+        c.next_x_rot, c.next_col0, c.next_act = next_x.data_ptr(), int(next_col0), int(act)
+    elif act:
+        raise ValueError("act without next_pk")
+    ws = pk.workspace
+    need = lib.paro_chain_workspace_bytes(ctypes.byref(d), rows)
+    if ws.numel() * ws.element_size() < need:
+        ws = get_workspace(dev, need)
+    with torch.cuda.device(dev):
+        nat.check(lib.paro_w4a16_gemv_chain(ctypes.byref(d), ctypes.byref(c), rows, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                            int(ksplit), int(waves), nat.current_stream_ptr(dev)))
+    return y, (next_x if next_pk is not None else None)
+
+
 _attn_ws: dict = {}
 
 
@@ -424,24 +508,6 @@ def argmax_advance(workspace: torch.Tensor, vocab: int, token: torch.Tensor, pos
         nat.check(lib.paro_argmax_advance(workspace.data_ptr(), int(vocab), token.data_ptr(), pos.data_ptr(),
                                           None if out_tokens is None else out_tokens.data_ptr(),
                                           0 if out_tokens is None else out_tokens.numel(), nat.current_stream_ptr(token.device)))
-
-
-def prefetch(tensors, workgroups: int = 64, checksum: Optional[torch.Tensor] = None) -> None:
-    """Pull the given device buffers into the Infinity Cache on the CURRENT stream (``paro_prefetch``): one dword per
-    128-byte line is touched and discarded.  Call it on a side stream of a captured decode step for the packed
-    weights of a LATER layer; it changes no results."""
-    lib = nat.load()
-    ts = [t for t in tensors if t is not None and t.numel() > 0]
-    if not ts:
-        return
-    dev = ts[0].device
-    with torch.cuda.device(dev):
-        for i in range(0, len(ts), nat.PARO_MAX_PREFETCH):
-            chunk = ts[i:i + nat.PARO_MAX_PREFETCH]
-            ptrs = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
-            sizes = (ctypes.c_int64 * len(chunk))(*[t.numel() * t.element_size() for t in chunk])
-            nat.check(lib.paro_prefetch(ptrs, sizes, len(chunk), int(workgroups),
-                                        None if checksum is None else checksum.data_ptr(), nat.current_stream_ptr(dev)))
 
 
 _workspaces: dict = {}
