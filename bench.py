@@ -55,6 +55,33 @@ MODELS = {
 }
 
 
+# Qwen3.5: hybrid decoders (transformers models/qwen3_5): every `full_interval`-th layer is full attention with a GATED
+# q_proj (2 x heads x head_dim outputs, head_dim 256), the others are gated delta nets whose quantised linears are
+# in_proj_qkv (hidden -> 2 key_dim + value_dim), in_proj_z (hidden -> value_dim) and out_proj (value_dim -> hidden);
+# in_proj_a / in_proj_b stay dense (reference experiments/optimize/4bit.sh:17-20).  "qwen3.5-9b" is the transformers
+# default text config ("Qwen3.5-9B style", configuration_qwen3_5.py); the 4B / 27B dimensions are NOT knowable offline
+# (SURVEY 8d): the "-class" entries keep the family's structure at roughly that parameter count -- use --model-config
+# <config.json> for a real checkpoint.
+HYBRID = {
+    #                    hidden, inter, heads, kv_heads, head_dim, lin_k_heads, lin_v_heads, layers, full_interval
+    "qwen3.5-9b": (4096, 12288, 16, 4, 256, 16, 32, 32, 4),
+    "qwen3.5-4b-class": (2560, 9216, 16, 4, 256, 16, 32, 32, 4),
+    "qwen3.5-27b-class": (5120, 17408, 24, 4, 256, 16, 48, 64, 4),
+}
+
+
+def n_layers_of(model: str) -> int:
+    return HYBRID[model][7] if model in HYBRID else MODELS[model][4]
+
+
+def hidden_of(model: str) -> int:
+    return HYBRID[model][0] if model in HYBRID else MODELS[model][0]
+
+
+def known_models():
+    return sorted(list(MODELS) + list(HYBRID))
+
+
 def register_model_from_config(path: str) -> str:
     """Add a model read from an HF `config.json` (hidden_size, intermediate_size, num_attention_heads,
     num_key_value_heads, head_dim, num_hidden_layers) -- e.g. a Qwen3.5-27B checkpoint whose dimensions are
@@ -64,6 +91,16 @@ def register_model_from_config(path: str) -> str:
     c = c.get("text_config", c)
     hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
     name = os.path.basename(os.path.dirname(os.path.abspath(path))) or "custom"
+    if "linear_num_value_heads" in c:      # Qwen3.5-style hybrid
+        lt = c.get("layer_types")
+        interval = c.get("full_attention_interval", 4)
+        if lt and "full_attention" in lt:
+            interval = lt.index("full_attention") + 1
+        HYBRID[name] = (c["hidden_size"], c["intermediate_size"], c["num_attention_heads"], c.get("num_key_value_heads", c["num_attention_heads"]),
+                        hd, c["linear_num_key_heads"], c["linear_num_value_heads"], c["num_hidden_layers"], interval)
+        if c.get("linear_key_head_dim", 128) != 128 or c.get("linear_value_head_dim", 128) != 128:
+            raise SystemExit("linear-attention head dims other than 128 are not modelled here")
+        return name
     MODELS[name] = (c["hidden_size"], c["intermediate_size"], c["num_attention_heads"] * hd,
                     c.get("num_key_value_heads", c["num_attention_heads"]) * hd, c["num_hidden_layers"])
     return name
@@ -73,6 +110,38 @@ def alg_bytes(K: int, N: int, P: int) -> int:
     """Algorithmic bytes of one fused GEMV call in the REFERENCE format."""
     G = K // 128
     return K * N // 2 + G * N * 2 + G * N // 2 + 2 * K + 2 * N + P * (16 * K + 8 * K + 2 * K)
+
+
+def hybrid_layer_shapes(model: str, full: bool):
+    """Quantised linears of one Qwen3.5 decoder layer, merged where the inputs coincide (q|k|v, in_proj_qkv|in_proj_z, gate|up)."""
+    h, inter, nh, nkv, hd, lk, lv, _, _ = HYBRID[model]
+    mlp = [("gate_up_proj", h, [inter, inter], "col"), ("down_proj", inter, [h], "row")]
+    if full:
+        return [("qkv_proj(gated q)", h, [2 * nh * hd, nkv * hd, nkv * hd], "col"), ("o_proj", nh * hd, [h], "row")] + mlp
+    return [("in_proj_qkvz", h, [2 * lk * 128 + lv * 128, lv * 128], "col"), ("out_proj", lv * 128, [h], "row")] + mlp
+
+
+def layer_plan(model: str, tp: int = 1, n_layers=None):
+    """Per decoder layer, the list of its quantised linears [(name, K, partition sizes, kind)]."""
+    L = n_layers or n_layers_of(model)
+    if model in HYBRID:
+        if tp != 1:
+            raise SystemExit("the hybrid (Qwen3.5) workloads run unsharded here")
+        iv = HYBRID[model][8]
+        return [hybrid_layer_shapes(model, (l + 1) % iv == 0) for l in range(L)]
+    return [layer_shapes(model, tp) for _ in range(L)]
+
+
+def distinct_shapes(model: str):
+    """Every distinct linear of the model once (per-shape tables)."""
+    if model in HYBRID:
+        seen, out = set(), []
+        for sh in hybrid_layer_shapes(model, False) + hybrid_layer_shapes(model, True):
+            if sh[0] not in seen:
+                seen.add(sh[0])
+                out.append(sh)
+        return out
+    return layer_shapes(model)
 
 
 def layer_shapes(model: str, tp: int = 1):
@@ -119,48 +188,82 @@ def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None, gain_k
 
 
 class DecodeStack:
-    """All quantised linears of `n_layers` decoder layers, chained for one batch-1 decode token."""
+    """All quantised linears of `n_layers` decoder layers, chained for one decode token (`rows` sequences)."""
 
-    def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0, allreduce=None):
-        self.model, self.tp, self.rank = model, tp, rank
+    def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0, allreduce=None, rows: int = 1,
+                 route: str = "auto"):
+        self.model, self.tp, self.rank, self.rows = model, tp, rank, rows
         from paroquant_amd import ops
         self.ops = ops
         # the collective after the row-parallel linears: the one-shot kernel (paroquant_amd.tp.OneShotAllReduce) or dist.all_reduce
         self.allreduce = allreduce or (lambda y: (dist.all_reduce(y), y)[1])
         # the one-shot object can also run inside the row-parallel GEMV's epilogue (paro_fusion_t.ar_*): no launch of its own
         self.fused_ar = allreduce if (hasattr(allreduce, "fusion_args") and os.environ.get("PARO_FUSED_ALLREDUCE", "1") != "0") else None
-        h, inter, q, kv, L = MODELS[model]
-        self.n_layers = n_layers or L
-        self.hidden, self.q_local, self.inter_local = h, q // tp, inter // tp
+        self.n_layers = n_layers or n_layers_of(model)
+        self.hidden = hidden_of(model)
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed + 1000 * rank)
-        self.shapes = layer_shapes(model, tp)
+        self.plan = layer_plan(model, tp, self.n_layers)
+        self.shapes = self.plan[0]
         self.layers = []
-        for _ in range(self.n_layers):
-            self.layers.append([synth_packed(K, sizes, dev, gen, gain_k=K * tp if kind == "row" else 0) for (_, K, sizes, kind) in self.shapes])
-        self.x = torch.randn(1, h, device=dev, dtype=torch.float16, generator=gen)
-        self.launches_per_step = 4 * self.n_layers
-        self.bytes_per_step = self.n_layers * sum(alg_bytes(K, sum(s), len(s)) for (_, K, s, _) in self.shapes)
+        for shapes in self.plan:
+            self.layers.append([synth_packed(K, sizes, dev, gen, gain_k=K * tp if kind == "row" else 0) for (_, K, sizes, kind) in shapes])
+        self.x = torch.randn(rows, self.hidden, device=dev, dtype=torch.float16, generator=gen)
+        self.launches_per_step = sum(len(sh) for sh in self.plan)
+        self.bytes_per_step = sum(alg_bytes(K, sum(s), len(s)) for sh in self.plan for (_, K, s, _) in sh)
+        # route: "fused" = one paro_w4a16_gemv per linear (rotation inside the consuming kernel); "chain" = the decode-chain
+        # family (activations handed over rotated: the consumer's rotation runs in the producer's epilogue, csrc/chain_impl.hpp).
+        # Measured (profiles/r03_chain_rows_sweep.jsonl): one row -> fused, 2..16 rows -> chain.
+        if route == "auto":
+            route = "chain" if (rows > 1 and tp == 1) else "fused"
+        if route == "chain" and tp != 1:
+            raise SystemExit("the chain route is single-GPU")
+        self.route = route
+        if route == "chain":
+            self.launches_per_step += 1        # the head's rotate_parts
+            flat = [pk for lay in self.layers for pk in lay]
+            self._flat = flat
+            # static hand-over buffers, one per consumer geometry
+            self._xr = {}
+            for pk in flat:
+                key = (len(pk.partition_sizes), pk.K)
+                if key not in self._xr:
+                    self._xr[key] = torch.empty(key[0], rows, key[1], device=dev, dtype=torch.float16)
+            self._y = {pk.N: torch.empty(rows, pk.N, device=dev, dtype=torch.float16) for pk in flat}
 
     def step(self, x: torch.Tensor) -> torch.Tensor:
+        if self.route == "chain":
+            return self._step_chain(x)
         h = x
         tp = self.tp
+        if tp == 1:
+            # every linear consumes the first K columns of its predecessor's output (attention / SiLU*mul stand-ins: views)
+            for lay in self.layers:
+                for pk in lay:
+                    h = pk.apply(h[:, : pk.K])
+            return h
         for qkv, o, gu, down in self.layers:
-            a = qkv.apply(h)[:, : self.q_local]            # attention stand-in: a view, no kernel
-            if tp > 1 and self.fused_ar is not None:       # RowParallelLinear: the all-reduce runs in the GEMV's epilogue
+            a = qkv.apply(h)[:, : o.K]                      # attention stand-in: a view, no kernel
+            if self.fused_ar is not None:                  # RowParallelLinear: the all-reduce runs in the GEMV's epilogue
                 h = self.ops.w4a16_gemv_fused(a, o, 0, allreduce=self.fused_ar)
             else:
-                h = o.apply(a)
-                if tp > 1:
-                    h = self.allreduce(h)                   # ... or as its own launch (one-shot xGMI kernel, or RCCL)
-            d = gu.apply(h)[:, : self.inter_local]         # SiLU*mul stand-in: a view, no kernel
-            if tp > 1 and self.fused_ar is not None:
+                h = self.allreduce(o.apply(a))              # ... or as its own launch (one-shot xGMI kernel, or RCCL)
+            d = gu.apply(h)[:, : down.K]                    # SiLU*mul stand-in: a view, no kernel
+            if self.fused_ar is not None:
                 h = self.ops.w4a16_gemv_fused(d, down, 0, allreduce=self.fused_ar)
             else:
-                h = down.apply(d)
-                if tp > 1:
-                    h = self.allreduce(h)
+                h = self.allreduce(down.apply(d))
         return h
+
+    def _step_chain(self, x: torch.Tensor) -> torch.Tensor:
+        ops, flat = self.ops, self._flat
+        xr = ops.rotate_parts(x, flat[0], out=self._xr[(len(flat[0].partition_sizes), flat[0].K)])
+        y = None
+        for i, pk in enumerate(flat):
+            nxt = flat[i + 1] if i + 1 < len(flat) else None
+            nx = self._xr[(len(nxt.partition_sizes), nxt.K)] if nxt is not None else None
+            y, xr = ops.chain_gemv(xr, pk, out=self._y[pk.N], next_pk=nxt, next_x=nx, next_col0=0)
+        return y
 
 
 def time_steps(fn, steps: int, warmup: int, world: int, dev):
@@ -197,7 +300,7 @@ def per_shape_table(model: str, dev, reps: int = 400):
     rows = []
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
-    for name, K, sizes, _ in layer_shapes(model):
+    for name, K, sizes, _ in distinct_shapes(model):
         nb = alg_bytes(K, sum(sizes), len(sizes))
         copies = max(2, min(64, int((1 << 30) // nb) + 1))
         packs = [synth_packed(K, sizes, dev, gen) for _ in range(copies)]
@@ -227,10 +330,13 @@ def per_shape_table(model: str, dev, reps: int = 400):
 def cpu_baseline(model: str, budget_s: float = 20.0):
     """Time the C port of the reference algorithm on ONE decoder layer (1/n_layers of a step)."""
     from oracle import paro_cpu as pc   # the ONLY use of oracle/ in this file: the CPU baseline leg
-    _, _, _, _, L = MODELS[model]
+    L = n_layers_of(model)
     rng = np.random.default_rng(0)
+    # the sample: the distinct linears of the model once; a hybrid's two layer kinds are weighted by their counts below
+    kinds = [(hybrid_layer_shapes(model, False), L - L // HYBRID[model][8]), (hybrid_layer_shapes(model, True), L // HYBRID[model][8])] \
+        if model in HYBRID else [(layer_shapes(model), L)]
     layers = []
-    for name, K, sizes, _ in layer_shapes(model):
+    for name, K, sizes, _ in [sh for shapes, _ in kinds for sh in shapes]:
         N, P, G = sum(sizes), len(sizes), K // 128
         layers.append(dict(
             qweight=rng.integers(-2**31, 2**31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32),
@@ -244,19 +350,26 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
     # one socket's worth of physical cores at most: on the 2 x 64-core / 256-thread MI355X host the default
     # 128-thread team is 1.4-8x slower and erratic (oversubscribed SMT siblings, cross-socket traffic)
     pc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
-    times = []
+    per_kind = [len(shapes) for shapes, _ in kinds]
+    times = []          # per run: seconds of each layer kind
     t_start = time.perf_counter()
     while True:
-        t0 = time.perf_counter()
-        for l, x in zip(layers, xs):
-            pc.linear_f16(x, l)
-        times.append(time.perf_counter() - t0)
+        run, i = [], 0
+        for n_lin in per_kind:
+            t0 = time.perf_counter()
+            for l, x in zip(layers[i:i + n_lin], xs[i:i + n_lin]):
+                pc.linear_f16(x, l)
+            run.append(time.perf_counter() - t0)
+            i += n_lin
+        times.append(run)
         if len(times) >= 3 and (time.perf_counter() - t_start > budget_s or len(times) >= 20):
             break
-    t_layer = float(np.median(times))
-    out = {"value": round(1.0 / (t_layer * L), 4), "unit": "tokens/s", "cores": pc.threads(), "kind": "port",
-           "sample": f"1 of {L} decoder layers (4 fused linears, M=1) x {len(times)} runs, median {t_layer * 1e3:.1f} ms/layer; "
-                     f"tokens/s = 1 / (ms_per_layer * {L})"}
+    med = np.median(np.asarray(times), axis=0)
+    t_token = float(sum(m * cnt for m, (_, cnt) in zip(med, kinds)))
+    t_layer = t_token / L
+    out = {"value": round(1.0 / t_token, 4), "unit": "tokens/s", "cores": pc.threads(), "kind": "port",
+           "sample": f"{len(kinds)} of {L} decoder layers ({sum(per_kind)} fused linears, M=1) x {len(times)} runs, median {t_layer * 1e3:.1f} ms/layer; "
+                     f"tokens/s = 1 / (sum over layer kinds of ms_per_layer x count)"}
     # BASELINE config 0 ("single ParoLinear layer 4096 x 4096, group 128, CPU dequant + matmul path"): the same one
     # layer as torch-CPU dequant -> fp32 matmul (what AutoAWQ's WQLinearMMFunction does off-GPU), M = 1, for context
     try:
@@ -307,12 +420,36 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
 
 
 def newest_pmc_file(model: str, explicit: str = ""):
-    """profiles/rNN_pmc_bench_<model>.json of the latest round (or the file named on the command line)."""
+    """(path, reason): profiles/rNN_pmc_bench_<model>.json of the latest round (or the file named on the command line).
+    A summary that is OLDER than the kernel sources it would describe is refused (path None + the reason): a stale constant
+    is worse than `traffic: null`.  The check uses the `kernel_sources_sha` the summary records
+    (tools/pmc_summary.py) -- file times do not survive a checkout."""
     import glob
     if explicit:
-        return explicit if os.path.exists(explicit) else None
+        return (explicit, None) if os.path.exists(explicit) else (None, f"{explicit} not found")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_bench_{model}.json")))
-    return files[-1] if files else None
+    if not files:
+        return None, "no PMC summary under profiles/ for this model"
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f).get("kernel_sources_sha")
+    except Exception as e:
+        return None, f"{os.path.basename(files[-1])}: {e}"
+    now = kernel_sources_sha()
+    if rec != now:
+        return None, (f"{os.path.basename(files[-1])} was collected on kernel sources {str(rec)[:12]}, the tree has {now[:12]}: "
+                      "re-run tools/profile_round.sh (PMC passes last)")
+    return files[-1], None
+
+
+def kernel_sources_sha() -> str:
+    """sha256 over the decode GEMV kernel sources (what the PMC traffic figure describes)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for fn in ("gemv_impl.hpp", "gemv.hip", "chain_impl.hpp", "chain.hip", "common.hpp"):
+        with open(os.path.join(ROOT, "paroquant_amd", "csrc", fn), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()
 
 
 def parse_args(argv=None):
@@ -325,6 +462,10 @@ def parse_args(argv=None):
                          "default: qwen3-4b at --gpus 1, llama3-70b-tp above")
     ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
+    ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16)")
+    ap.add_argument("--route", default="auto", choices=["auto", "fused", "chain"],
+                    help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
+                         "launch (decode-chain family); auto = fused at one row, chain at 2..16 (measured: profiles/r03_chain_rows_sweep.jsonl)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end decode leg (fused harness: attention, norms, lm_head)")
@@ -379,8 +520,12 @@ def run(args, rank: int, local_rank: int, world: int):
     workload = args.workload or ("qwen3-4b" if world == 1 else "llama3-70b-tp")
     tp_mode = workload.endswith("-tp")
     model = workload[:-3] if tp_mode else workload
-    if model not in MODELS:
-        raise SystemExit(f"unknown workload {workload!r}; known models: {sorted(MODELS)} (each also as <model>-tp)")
+    if model not in MODELS and model not in HYBRID:
+        raise SystemExit(f"unknown workload {workload!r}; known models: {known_models()} (the dense ones also as <model>-tp)")
+    if tp_mode and model in HYBRID:
+        raise SystemExit("tensor-parallel workloads are defined for the dense models")
+    if not 1 <= args.rows <= 16:
+        raise SystemExit("--rows must be in 1..16")
     tp = world if tp_mode else 1
 
     if args.dry_run:
@@ -433,10 +578,10 @@ def run(args, rank: int, local_rank: int, world: int):
     allreduce, allreduce_name = None, None
     if tp_mode and world > 1:
         from paroquant_amd import tp as ptp
-        allreduce, allreduce_name = ptp.make_allreduce(dev, MODELS[model][0], prefer_oneshot=not args.no_oneshot)
+        allreduce, allreduce_name = ptp.make_allreduce(dev, hidden_of(model), prefer_oneshot=not args.no_oneshot)
         if allreduce_name == "gloo":
             args.no_graph = True          # a gloo collective is a host operation: nothing to capture
-    stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank, allreduce=allreduce)
+    stack = DecodeStack(model, dev, n_layers=args.layers or None, tp=tp, rank=rank, allreduce=allreduce, rows=args.rows, route=args.route)
 
     def measure():
         """Eager warm-up, HIP-graph capture of the step (when the collective allows it), timed region."""
@@ -487,35 +632,40 @@ def run(args, rank: int, local_rank: int, world: int):
             wall, ev_ms, use_graph = measure()
     ms_per_step = wall * 1e3 / args.steps
     replicas = 1 if tp_mode else world
-    tokens_per_s = replicas * args.steps / wall
+    tokens_per_s = replicas * args.rows * args.steps / wall
 
     launches = stack.launches_per_step
     us_per_launch = ev_ms * 1e3 / (args.steps * launches)
     bytes_per_launch = stack.bytes_per_step / launches
     achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s, per rank
     traffic = None   # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, summaries under profiles/)
-    pmc_file = newest_pmc_file(model, args.pmc_file)
-    if pmc_file and not tp_mode and stack.n_layers == MODELS[model][4]:
+    pmc_file, pmc_reason = newest_pmc_file(model, args.pmc_file)
+    if pmc_file and not tp_mode and stack.n_layers == n_layers_of(model) and args.rows == 1 and stack.route == "fused":
         with open(pmc_file) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "paro::gemv_kernel (fused rotate+INT4 GEMV, all launches of the step)",
+    elif pmc_file:
+        pmc_reason = "the PMC summary describes the default one-row workload at full depth"
+    roofline = {"bound": "hbm", "kernel": ("paro::chain_kernel (INT4 GEMV on rotated activations + the consumer's rotation in the epilogue"
+                                           if stack.route == "chain" else "paro::gemv_kernel (fused rotate+INT4 GEMV") + ", all launches of the step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": os.path.relpath(pmc_file, ROOT) if (pmc_file and traffic is not None) else None,
+                "traffic_note": None if traffic is not None else pmc_reason,
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
                 "launches_per_step": launches,
                 "note": "per rank; launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps"
                         + (" and the all-reduces" if tp > 1 else "") + ")"}
 
     result = {
-        "metric": "decode tokens/s through the ParoQuant quantised-linear hot path (fused rotation + INT4 GEMV), batch 1",
+        "metric": "decode tokens/s through the ParoQuant quantised-linear hot path (fused rotation + INT4 GEMV), batch %d" % args.rows,
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "f16 activations x int4 weights (fp32 accumulate)",
         "data": "synthetic (random INT4 AWQ-format weights, random fp16 activations, random perfect-matching pairs)",
-        "config": {"workload": f"{model}-PARO batch-1 decode: {stack.n_layers} layers x (qkv[P=3], o, gate_up[P=2], down) "
+        "config": {"workload": f"{model}-PARO batch-{args.rows} decode: {stack.n_layers} layers x ({', '.join(n + ('[P=%d]' % len(sz) if len(sz) > 1 else '') for n, _, sz, _ in stack.shapes)}"
+                               f"{'; every %d-th layer full attention: ' % HYBRID[model][8] + ', '.join(n for n, _, _, _ in hybrid_layer_shapes(model, True)[:2]) if model in HYBRID else ''}) "
                                f"W4A16 g128 krot8, {('TP=%d (%s all-reduce after o / down)' % (tp, {'oneshot': 'one-shot over xGMI' + (' in the GEMV epilogue' if stack.fused_ar is not None else ' kernel'), 'nccl': 'RCCL'}.get(allreduce_name, allreduce_name))) if tp_mode else 'replica per GPU'}",
-                   "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph,
+                   "layers": stack.n_layers, "hidden": stack.hidden, "hip_graph": use_graph, "rows": args.rows, "route": stack.route,
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
                    "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
                    "collective_backend": (args.tp_backend if world > 1 and tp_mode else None),
@@ -529,7 +679,7 @@ def run(args, rank: int, local_rank: int, world: int):
         ref = None
         if rank == 0:
             try:
-                nl = min(8, MODELS[model][4])
+                nl = min(8, n_layers_of(model))
                 s1 = DecodeStack(model, dev, n_layers=nl, tp=1, rank=0, seed=123)
                 s1.step(s1.x)
                 torch.cuda.synchronize(dev)
@@ -543,7 +693,7 @@ def run(args, rank: int, local_rank: int, world: int):
                     s1.step(s1.x)
                 _, ev1 = time_steps(g1.replay, 20, 3, 1, dev)
                 ms_layer = ev1 / 20 / nl
-                ref = {"tokens_per_s": round(1e3 / (ms_layer * MODELS[model][4]), 2), "layers_measured": nl,
+                ref = {"tokens_per_s": round(1e3 / (ms_layer * n_layers_of(model)), 2), "layers_measured": nl,
                        "note": "same model, TP=1, one GPU; per-layer time x full depth"}
                 del s1, g1
             except Exception as e:
@@ -552,7 +702,7 @@ def run(args, rank: int, local_rank: int, world: int):
         result["config"]["tp1_reference"] = ref
         # the whole model tensor-parallel on the fused harness (attention heads sharded, residual added inside the one-shot
         # all-reduce): every rank runs it, never fatal for the contract line; a one-shot that gave up is reported, not hidden
-        if not args.no_e2e and allreduce_name == "oneshot" and stack.n_layers == MODELS[model][4]:
+        if not args.no_e2e and allreduce_name == "oneshot" and stack.n_layers == n_layers_of(model):
             del stack
             torch.cuda.empty_cache()
             try:
@@ -572,7 +722,7 @@ def run(args, rank: int, local_rank: int, world: int):
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
         else:
             result["cpu_baseline"] = None
-        if not args.no_e2e and world == 1 and not tp_mode and stack is not None and stack.n_layers == MODELS[model][4]:
+        if not args.no_e2e and world == 1 and not tp_mode and stack is not None and stack.n_layers == n_layers_of(model):
             del stack
             torch.cuda.empty_cache()
             try:

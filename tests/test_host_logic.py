@@ -345,3 +345,28 @@ def test_allreduce_epilogue_host_checks(lib):
     # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
     assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
     assert lib.paro_allreduce_buffer_bytes(17, 8192) == -1 and lib.paro_allreduce_buffer_bytes(2, 4) == -1
+
+
+def test_bench_layer_plans_dense_and_hybrid():
+    """bench.py's workload tables: the dense models keep four linears per layer; the Qwen3.5 hybrids interleave gated-delta-net
+    layers (in_proj_qkv|z, out_proj) with a full-attention layer (gated q: 2 x heads x head_dim columns) every 4th, with the
+    linear set of transformers' models/qwen3_5 at the default ("9B style") configuration."""
+    import bench
+    assert bench.n_layers_of("qwen3-4b") == 36 and bench.hidden_of("llama3-8b") == 4096
+    plan = bench.layer_plan("qwen3-4b")
+    assert len(plan) == 36 and [n for n, _, _, _ in plan[0]] == ["qkv_proj", "o_proj", "gate_up_proj", "down_proj"]
+    hp = bench.layer_plan("qwen3.5-9b")
+    assert len(hp) == 32 and bench.n_layers_of("qwen3.5-9b") == 32
+    assert [(l + 1) % 4 == 0 for l in range(32)] == [sh[0][0].startswith("qkv") for sh in hp]
+    lin, full = hp[0], hp[3]
+    assert lin[0][1:3] == (4096, [2 * 16 * 128 + 32 * 128, 32 * 128]) and lin[1][1:3] == (32 * 128, [4096])
+    assert full[0][1:3] == (4096, [2 * 16 * 256, 4 * 256, 4 * 256]) and full[1][1:3] == (16 * 256, [4096])
+    assert full[2][1:3] == (4096, [12288, 12288]) and full[3][1:3] == (12288, [4096])
+    names = [n for n, _, _, _ in bench.distinct_shapes("qwen3.5-9b")]
+    assert len(names) == len(set(names)) == 6
+    # every K is a multiple of the rotation group, every partition of the packed tile
+    for m in bench.known_models():
+        for sh in bench.layer_plan(m, n_layers=4):
+            for _, K, sizes, _ in sh:
+                assert K % 128 == 0 and all(n % 16 == 0 for n in sizes), (m, K, sizes)
+    assert len(bench.kernel_sources_sha()) == 64
