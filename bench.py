@@ -630,6 +630,32 @@ def run(args, rank: int, local_rank: int, world: int):
             if args.tp_backend == "gloo":
                 args.no_graph = True
             wall, ev_ms, use_graph = measure()
+    # TP runs report BOTH collectives: the one-shot xGMI kernel (when it came up and passed its self-test)
+    # and the backend's all-reduce (RCCL), timed on the same shards; the headline is the faster leg that is healthy.
+    allreduce_ab = None
+    if tp_mode and world > 1:
+        allreduce_ab = {allreduce_name: {"ms_per_step": round(wall * 1e3 / args.steps, 4), "hip_graph": use_graph}}
+        if allreduce_name == "oneshot":
+            saved = (stack.allreduce, stack.fused_ar, args.no_graph)
+            stack.allreduce = lambda y: (dist.all_reduce(y), y)[1]
+            stack.fused_ar = None
+            if args.tp_backend == "gloo":
+                args.no_graph = True
+            try:
+                wall2, ev2, graph2 = measure()
+                allreduce_ab[args.tp_backend] = {"ms_per_step": round(wall2 * 1e3 / args.steps, 4), "hip_graph": graph2}
+            except Exception as e:            # the library leg must never take the contract line down
+                wall2, ev2, graph2 = float("inf"), 0.0, False
+                allreduce_ab[args.tp_backend] = {"error": f"{type(e).__name__}: {e}"}
+            faster = torch.tensor([1.0 if wall2 < wall else 0.0], device=dev if args.tp_backend == "nccl" else "cpu")
+            dist.all_reduce(faster, op=dist.ReduceOp.MIN)        # every rank takes the same leg
+            if float(faster.item()) > 0.5:
+                wall, ev_ms, use_graph, allreduce_name = wall2, ev2, graph2, args.tp_backend
+            else:
+                stack.allreduce, stack.fused_ar, args.no_graph = saved
+        else:
+            allreduce_ab["oneshot"] = {"error": "not available on this node (set-up or self-test failed; see the log line above)"
+                                       if not args.no_oneshot else "disabled (--no-oneshot)"}
     ms_per_step = wall * 1e3 / args.steps
     replicas = 1 if tp_mode else world
     tokens_per_s = replicas * args.rows * args.steps / wall
@@ -669,7 +695,7 @@ def run(args, rank: int, local_rank: int, world: int):
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
                    "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
                    "collective_backend": (args.tp_backend if world > 1 and tp_mode else None),
-                   "allreduce": allreduce_name},
+                   "allreduce": allreduce_name, "allreduce_ab": allreduce_ab},
         "roofline": roofline,
     }
 

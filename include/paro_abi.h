@@ -160,11 +160,12 @@ typedef struct paro_linear {
 } paro_linear_t;
 
 /* Bytes of caller-provided scratch the fused ops may need for `rows` rows
- * (split-K slabs + arrival counters for the GEMV path, rotated activations for
- * the GEMM path).  The first PARO_WS_COUNTER_BYTES of the workspace hold
- * arrival counters: the caller zero-fills the workspace ONCE after allocating
- * it (the kernels leave the counters at zero on exit).  A workspace must not be
- * shared by launches that may run concurrently on different streams. */
+ * (split-K granules for the GEMV paths, rotated activations for the GEMM path).  The first PARO_WS_COUNTER_BYTES of the
+ * workspace hold one K-split EPOCH word per column block: the caller zero-fills the workspace ONCE after allocating it;
+ * every launch that splits a block tags its {tag, partial} granules with (block, epoch + 1) and the block's reducer
+ * advances the word, so nothing is re-armed between launches and whatever else was written to the granule area (the
+ * prefill path's rotated activations, a late producer of a launch that gave up) can never be read as a partial sum.
+ * A workspace must not be shared by launches that may run concurrently on different streams. */
 #define PARO_WS_COUNTER_BYTES 16384
 /* Last word of the counter area: sticky status of the in-launch K-split.  0 = healthy.  A reducer that
  * gives up waiting for a partial (bounded spin; cannot happen while the whole grid is resident, which

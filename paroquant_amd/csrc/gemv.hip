@@ -302,7 +302,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (slab_bytes + xrot_bytes > 0) {
     if (!workspace || workspace_bytes < need)
       return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
-    if ((int64_t)pt.cbs * 4 > PARO_WS_COUNTER_BYTES) return fail(PARO_ERR_INVALID, "too many column blocks for the counter area");
+    if ((int64_t)pt.cbs * 4 > PARO_WS_STATUS_OFFSET || pt.cbs > 4096) return fail(PARO_ERR_INVALID, "too many column blocks for the K-split epoch words");
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }

@@ -169,12 +169,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   u32x16 k0;
   int p;
   unsigned p_cb0_u, ent0, ent1;
+  unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words), fetched with the same batch
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned m0_save;
     asm volatile(
         "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
         "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
+        "s_load_dwordx2 %[cnt], %[kp], %[cntoff]\n\t"
         "s_mov_b32 %[m0s], m0\n\t"
         "s_mov_b32 %[p], 0\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         "s_cselect_b32 %[cb0], 0, %[cb0]\n\t"
         "s_mov_b32 m0, %[m0s]\n\t"
         "s_nop 0"
-        : [k0] "=&s"(k0), [p] "=&s"(p), [cb0] "=&s"(p_cb0_u), [e0] "=&s"(ent0), [e1] "=&s"(ent1), [m0s] "=&s"(m0_save)
-        : [kp] "s"(kp), [cb] "s"(cb)
+        : [k0] "=&s"(k0), [p] "=&s"(p), [cb0] "=&s"(p_cb0_u), [e0] "=&s"(ent0), [e1] "=&s"(ent1), [m0s] "=&s"(m0_save), [cnt] "=&s"(cnt_ptr)
+        : [kp] "s"(kp), [cb] "s"(cb), [cntoff] "i"(offsetof(GemvArgs, counters))
         : "memory", "scc", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
           "s98", "s99");
   }
@@ -342,6 +344,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   };
   // ---- first unit's coefficient requests, at priority 3 (see the note at the driver loop), then the bookkeeping
+  // K-split epoch word of this column block (see ks_tag below): the wave's OLDEST vector request -- unconditional (any
+  // readable word when the launch is not split), so it is waited for with the first coefficients, costs no round trip of its
+  // own and keeps the scalar-memory counter out of the rotation's cross-lane waits (a scalar load here sat in front of
+  // every ds_bpermute wait of the first unit: o_proj 4.82 -> 5.02 us)
+  const unsigned ep_raw = *(GP<unsigned>)((h.ksplit > 1 ? (GP<unsigned>)cnt_ptr : (GP<unsigned>)h.cs) + (h.ksplit > 1 ? (unsigned)cb : 0u));
   PBuf pc_first;
   if (h.prio) __builtin_amdgcn_s_setprio(3);
   load_p(pc_first, gf_first);
@@ -426,6 +433,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   load_t(tc_first, gf_first);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (DIAG == 3) ts[1] = __builtin_amdgcn_s_memtime();
+  // K-split tag of this column block: (block, per-block epoch + 1).  The epoch word lives in the workspace's counter area
+  // (zero-filled once), is requested at kernel entry (ep_raw) and advanced by the block's
+  // reducer at its very end: every launch that splits a block uses a tag no granule in memory can carry yet, so nothing is
+  // re-armed and a late or stale granule -- or whatever another kernel left in the granule area -- is never consumed.
+  // (Shared with the chain family, chain_impl.hpp: same words, same tag format.)
+  unsigned ks_tag = 0;
+  if (h.ksplit > 1) {
+    unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ep_raw) + 1u;
+    if ((e & 0xfffffu) == 0u) e += 1u;   // tag 0 is "never written"
+    ks_tag = (e << 12) | ((unsigned)cb & 0xfffu);
+  }
 
   // ---- rotation pieces (state in REGISTERS: lane l holds both members (A, B) of one pair of the stage)
   // The packed coefficients are 16-bit integers in units of 2^-14.  They are used AS integers (two
@@ -808,15 +826,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         y_p[(int64_t)b * h.N + col] = A::from_f32(v);
       }
     } else if (ks != h.ksplit - 1) {
-      // producer: ONE 8-byte {tag = 1, fp32 partial} granule per output, written through (sc1); no
+      // producer: ONE 8-byte {tag, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
-      const unsigned long long gv = (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+      const unsigned long long gv = ((unsigned long long)ks_tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
       __hip_atomic_store(a.slabs + ((int64_t)ks * h.rows + b) * h.N + col, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if constexpr (AREP) continue;
     } else {
       // reducer (the last K-split of this column block; dispatched after the others): keep the own
-      // partial in registers, poll the other splits' granules until their tags appear (bounded),
-      // re-arm them to zero for the next launch, write y once.
+      // partial in registers, poll the other splits' granules until this launch's tag appears (bounded),
+      // write y once; the block's epoch word is advanced below.
       // The first poll of EVERY split is issued before any of them is looked at (up to 4 per batch): a poll is a
       // ~0.6 us round trip to the coherence point, and one after the other they were most of the hand-off's cost.
       const int nsp = h.ksplit - 1;
@@ -833,21 +851,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           if (s >= nsp) break;
           unsigned long long* gp = a.slabs + ((int64_t)s * h.rows + b) * h.N + col;
           unsigned long long gv = gq[q];
-          for (int spin = 0; (gv >> 32) != 1ull && spin < (1 << 17); ++spin) {
+          for (int spin = 0; (unsigned)(gv >> 32) != ks_tag && spin < (1 << 17); ++spin) {
             __builtin_amdgcn_s_sleep(2);
             gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if ((gv >> 32) != 1ull) {
+          if ((unsigned)(gv >> 32) != ks_tag) {
             // give-up: never a silent wrong sum -- the output becomes NaN and the sticky status word of the
-            // workspace is set (paro_workspace_status / ops.check_workspace); the granule is NOT re-armed, so
-            // a producer that arrives late cannot be mistaken for the next launch's partial without the
-            // status word already saying so.  Unreachable while every workgroup of the launch is resident
+            // workspace is set (paro_workspace_status / ops.check_workspace); a producer that arrives late
+            // carries this launch's tag, which no later launch waits for.  Unreachable while every workgroup of the launch is resident
             // (checked on the host before a K-split launch).
             a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
             v = __builtin_nanf("");
           } else {
             v += __builtin_bit_cast(float, (unsigned)gv);
-            __hip_atomic_store(gp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
@@ -872,6 +888,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if ((col & 15) == 0) ar_st[kArStateTiles + (col >> 4)] = ep;
     }
   }
+  if (h.ksplit > 1 && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
   if constexpr (DIAG == 3) {
     ts[6] = __builtin_amdgcn_s_memtime();
     // 80 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], stages done [10], then

@@ -517,9 +517,9 @@ def get_workspace(device: torch.device, nbytes: int, stream=None) -> torch.Tenso
     """Zero-initialised scratch shared by all layers that run on one (device, stream): split-K granules + arrival
     counters + status word, rotated activations of the unfused routes, fp32 partial tiles.
 
-    The GEMV kernels leave counters and granules at zero on exit, so one buffer serves every layer that runs on
-    the same stream; it only ever grows, and always with ``torch.zeros`` (the granule protocol must never see
-    uninitialised memory).  ``stream=None`` is the default workspace of the device: correct for any number of
+    The K-split granules are tagged with per-block epochs kept in the first 16 KiB (see ``paro_abi.h``), so one buffer
+    serves every layer that runs on the same stream, decode and prefill alike; it only ever grows, and always with
+    ``torch.zeros`` (epochs and the status word must start from a known state).  ``stream=None`` is the default workspace of the device: correct for any number of
     streams that use it ONE AT A TIME (eager warm-up stream, then a graph-capture stream).  Launches that may
     overlap in time on different streams must not share granules: give each such stream its own workspace with
     ``get_workspace(device, nbytes, stream)`` / ``PackedParoWeights.bind_stream(stream)``."""

@@ -221,6 +221,7 @@ def make_allreduce(device, max_elems: int, group=None, prefer_oneshot: bool = Tr
             out.copy_(y)
             y = out
         return y
+    _library.group = group          # ParoDecoderLM reads it for the prefill's [T, hidden] all-reduce (same as OneShotAllReduce.group)
     fallback = _library, dist.get_backend(group)
     if not prefer_oneshot or dist.get_world_size(group) == 1:
         return fallback
@@ -234,4 +235,9 @@ def make_allreduce(device, max_elems: int, group=None, prefer_oneshot: bool = Tr
         return ar, "oneshot"
     if dist.get_rank(group) == 0:
         print(f"[paroquant_amd.tp] one-shot all-reduce failed its self-test; using {fallback[1]}", flush=True)
+    try:
+        dist.barrier(group=group)   # no peer may still be storing into a buffer that is about to be unmapped
+        ar.close()                  # the IPC-mapped fine-grained buffers would otherwise leak on every rank
+    except Exception:
+        pass
     return fallback
