@@ -261,6 +261,18 @@ int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int6
 int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int variant, void* stream);
 
+/* Grouped prefill GEMM over expert segments (v11).  The reference's MoE export keeps ONE rotation per
+ * projection shared by all experts (cli/convert.py:280-379) and its MLX back-end rotates the tokens once before the routed
+ * experts (mlx/modules.py:159-212); here the caller rotates once (rotation::rotate), sorts the (token, expert) pairs by
+ * expert ON THE DEVICE, pads every expert's segment to a multiple of block_rows (64, 128 or 256) and passes
+ *   x_rot         act_dtype [padded_rows][K]   rotated rows in that order (padding rows: anything finite)
+ *   block_expert  int32 [padded_rows / block_rows] in DEVICE memory: the expert whose packed weights row block b uses,
+ *                 L->wq + e * wq_stride_bytes / L->sz + e * sz_stride_bytes; -1 = block unused
+ *   y             act_dtype [padded_rows][N]
+ * One launch of GEMM variant 4 for all experts; no host synchronisation; HIP-graph capturable.  L: one rotation partition. */
+int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot, void* y, int64_t padded_rows, int block_rows,
+                            const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, void* stream);
+
 /* Dispatcher used by the Python operator: gemv for rows <= 16, gemm otherwise. */
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                       int64_t workspace_bytes, void* stream);

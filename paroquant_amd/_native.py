@@ -46,6 +46,7 @@ EXPORTS = (
     "paro_argmax_advance",
     "paro_w4a16_gemm",
     "paro_w4a16_linear",
+    "paro_w4a16_gemm_grouped",
     "paro_dequant_packed",
     "paro_chain_workspace_bytes",
     "paro_chain_launch_shape",
@@ -177,6 +178,8 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemm.restype = c_int
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_void_p]
+    lib.paro_w4a16_gemm_grouped.restype = c_int
+    lib.paro_w4a16_gemm_grouped.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]
     lib.paro_workspace_status.restype = c_int
     lib.paro_workspace_status.argtypes = [c_void_p, c_void_p]
     lib.paro_w4a16_linear.restype = c_int

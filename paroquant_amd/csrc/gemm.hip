@@ -537,3 +537,44 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   }
   return check_launch("paro_w4a16_gemm");
 }
+
+// Grouped W4A16 GEMM over expert segments (the reference exports ONE rotation per MoE projection shared by
+// all experts, cli/convert.py:280-379, and rotates the tokens once before the routed experts, mlx/modules.py:159-212):
+// x_rot [padded_rows][K] holds the ROTATED rows of the (token, expert) pairs sorted by expert, every expert's segment
+// padded up to a multiple of block_rows; row block b multiplies by expert block_expert[b]'s packed weights (device
+// memory, -1 = unused block): one launch for all experts, nothing on the host, HIP-graph capturable.
+extern "C" int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot, void* y, int64_t padded_rows, int block_rows,
+                                       const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, void* stream) {
+  using namespace paro;
+  int rc = validate_linear(L);
+  if (rc != PARO_OK) return rc;
+  if (!x_rot || !y || !block_expert) return fail(PARO_ERR_INVALID, "null pointer");
+  if (block_rows != 64 && block_rows != 128 && block_rows != 256) return fail(PARO_ERR_INVALID, "block_rows must be 64, 128 or 256 (got %d)", block_rows);
+  if (padded_rows <= 0 || padded_rows % block_rows) return fail(PARO_ERR_INVALID, "padded_rows must be a positive multiple of block_rows");
+  if (L->n_parts != 1) return fail(PARO_ERR_UNSUPPORTED, "grouped GEMM: one rotation partition per projection (the experts share it)");
+  if (wq_stride_bytes % 16 || sz_stride_bytes % 4) return fail(PARO_ERR_INVALID, "expert strides must keep the packed buffers aligned");
+  if (padded_rows / block_rows > 65535) return fail(PARO_ERR_INVALID, "too many row blocks");
+  GemmArgs a;
+  a.wq = (const u32x4*)L->wq;
+  a.sz = (const unsigned*)L->sz;
+  a.bias = nullptr;
+  a.xrot = (const unsigned short*)x_rot;
+  a.y = (unsigned short*)y;
+  a.K = (int)L->K;
+  a.N = (int)L->N;
+  a.G = (int)(L->K / 128);
+  a.rows = (int)padded_rows;
+  a.tstride = L->wq_order ? 1 : a.G;
+  a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
+  if (!fill_part_table(a.pt, L->n_parts, L->part_cols, 16)) return fail(PARO_ERR_INVALID, "bad partition table");
+  a.ksplit = 1;
+  a.gps = a.G;
+  a.partial = nullptr;
+  a.block_expert = block_expert;
+  a.wq_estride = wq_stride_bytes / 16;
+  a.sz_estride = sz_stride_bytes / 4;
+  dim3 grid((unsigned)a.pt.cbs, (unsigned)(padded_rows / block_rows), 1u);
+  rc = launch_gemm3(a, L->act_dtype, grid, (hipStream_t)stream, 0, 128 / quant_group(L->group_size), block_rows / 32);
+  if (rc != PARO_OK) return rc;
+  return check_launch("paro_w4a16_gemm_grouped");
+}

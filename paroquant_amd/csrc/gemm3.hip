@@ -161,6 +161,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int cb = blockIdx.x;
   const int row0 = blockIdx.y * BMR;
 
+  const u32x4* wq_base = a.wq;
+  const unsigned* sz_base = a.sz;
+  if (a.block_expert) {   // grouped launch: this row block belongs to one expert (or to the padding behind the last one)
+    const int e = a.block_expert[blockIdx.y];
+    if (e < 0) return;
+    wq_base += (int64_t)e * a.wq_estride;
+    sz_base += (int64_t)e * a.sz_estride;
+  }
   const int p = a.pt.part_of_cb(cb);
   const int ltile0 = (cb - a.pt.cb_start[p]) * 16 + wave * 2;   // the wave's two 16-column tiles
   const int tile0 = a.pt.tile_start[p] + ltile0;
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int my_tile = min(tile0 + (jt < nt ? jt : 0), a.pt.tiles - 1);
   const int my_ts = min(a.pt.szt_start[p] + ltile0 + (jt < nt ? jt : 0), a.pt.tsz - 1);
   const int64_t szrow = (int64_t)(a.pt.tsz >> 2) * 64;
-  const unsigned* szp = a.sz + ((int64_t)(my_ts >> 2) * 16 + n) * 4 + (my_ts & 3);
-  const u32x4* wq0 = a.wq + (int64_t)my_tile * a.tstride * 64 + (kh * 16 + n);   // lane' (kb = kh, n): k-steps 0, 2, 4, 6
+  const unsigned* szp = sz_base + ((int64_t)(my_ts >> 2) * 16 + n) * 4 + (my_ts & 3);
+  const u32x4* wq0 = wq_base + (int64_t)my_tile * a.tstride * 64 + (kh * 16 + n);   // lane' (kb = kh, n): k-steps 0, 2, 4, 6
   const int64_t wq_gstride = (int64_t)a.gstride * 64;
 
   // --- activation staging: wave w fills LDS rows 32 w .. 32 w + 31 (8 LDS-DMA pieces of 4 rows).  Lane l lands on

@@ -15,6 +15,10 @@ struct GemmArgs {
   int ksplit, gps;             // K-split (grid.z) of the v2 kernel: groups per split; 1 = none
   float* partial;              // [ksplit][rows][N] fp32 partial sums when ksplit > 1
   PartTable pt;                // column blocks of BN_TILES tiles
+  // grouped (mixture-of-experts) launches of variant 4: row block blockIdx.y multiplies by the weights of expert
+  // block_expert[blockIdx.y] (device memory; -1 = an unused block of the padded row space); null = one weight set
+  const int* block_expert = nullptr;
+  long long wq_estride = 0, sz_estride = 0;   // u32x4 / u32 elements between consecutive experts' packed buffers
 };
 
 }  // namespace paro

@@ -48,6 +48,7 @@ class DecoderConfig:
     rope_theta: float = 10000.0
     qk_norm: bool = False          # Qwen3: per-head RMSNorm on q and k before RoPE
     max_positions: int = 2048
+    rope_scaling: Optional[dict] = None   # HF `rope_scaling` / `rope_parameters`: rope_type default | linear | llama3
 
     def __post_init__(self):
         # the attention kernel reads the position-contiguous V cache 8 positions (16 bytes) at a time
@@ -57,10 +58,17 @@ class DecoderConfig:
     def from_hf(cls, c: dict, max_positions: int = 2048) -> "DecoderConfig":
         c = c.get("text_config", c)
         hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
-        rope_theta = c.get("rope_theta") or (c.get("rope_parameters") or {}).get("rope_theta", 10000.0)
-        return cls(c["hidden_size"], c["intermediate_size"], c["num_attention_heads"],
-                   c.get("num_key_value_heads", c["num_attention_heads"]), hd, c["num_hidden_layers"], c["vocab_size"],
-                   c.get("rms_norm_eps", 1e-6), float(rope_theta), c.get("model_type", "") in ("qwen3",), max_positions)
+        rp = c.get("rope_parameters") or {}
+        rope_theta = c.get("rope_theta") or rp.get("rope_theta", 10000.0)
+        # z-lab/Llama-3.1-8B-Instruct-PARO carries llama3 rope scaling: the low-frequency inv_freq change at EVERY position
+        scaling = c.get("rope_scaling") or ({k: v for k, v in rp.items() if k != "rope_theta"} if rp.get("rope_type", rp.get("type", "default")) != "default" else None)
+        cfg = cls(c["hidden_size"], c["intermediate_size"], c["num_attention_heads"],
+                  c.get("num_key_value_heads", c["num_attention_heads"]), hd, c["num_hidden_layers"], c["vocab_size"],
+                  c.get("rms_norm_eps", 1e-6), float(rope_theta), c.get("model_type", "") in ("qwen3",), max_positions, scaling)
+        rope_inv_freq(cfg, "cpu")      # unsupported scaling types fail HERE, at load time, not as silently wrong rotary angles
+        if float(c.get("partial_rotary_factor", 1.0)) != 1.0:
+            raise NotImplementedError("partial rotary embeddings are not supported by the decode harness")
+        return cfg
 
 
 MODEL_CONFIGS = {
@@ -77,11 +85,37 @@ def named_config(name: str, max_positions: int = 2048) -> DecoderConfig:
     return DecoderConfig(h, i, nh, nkv, hd, L, V, 1e-6, th, qk, max_positions)
 
 
-def rope_table(cfg: DecoderConfig, device) -> torch.Tensor:
-    """fp32 [max_positions, head_dim]: cos(pos * inv_freq) then sin(...), inv_freq[d] = theta^(-2d / head_dim)
-    (the default rotary embedding of HF Llama / Qwen3)."""
+def rope_inv_freq(cfg: DecoderConfig, device) -> torch.Tensor:
+    """inv_freq[d] = theta^(-2d / head_dim), then the checkpoint's rope scaling as HF's ROPE_INIT_FUNCTIONS apply it:
+    "linear" divides by `factor`; "llama3" (Llama-3.1+) divides the low frequencies by `factor`, keeps the high ones and
+    blends in between (transformers/modeling_rope_utils.py, _compute_llama3_parameters).  Anything else raises."""
+    import math
     half = cfg.head_dim // 2
     inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, half, dtype=torch.float32, device=device) * 2.0 / cfg.head_dim))
+    sc = cfg.rope_scaling
+    if not sc:
+        return inv
+    kind = sc.get("rope_type", sc.get("type", "default"))
+    if kind == "default":
+        return inv
+    if kind == "linear":
+        return inv / float(sc["factor"])
+    if kind == "llama3":
+        factor, lo, hi = float(sc["factor"]), float(sc["low_freq_factor"]), float(sc["high_freq_factor"])
+        old = float(sc["original_max_position_embeddings"])
+        wavelen = 2.0 * math.pi / inv
+        scaled = torch.where(wavelen > old / lo, inv / factor, inv)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        blended = (1.0 - smooth) * inv / factor + smooth * inv
+        medium = ~(wavelen < old / hi) & ~(wavelen > old / lo)
+        return torch.where(medium, blended, scaled)
+    raise NotImplementedError(f"rope scaling type {kind!r} is not supported by the decode harness (default, linear, llama3 are)")
+
+
+def rope_table(cfg: DecoderConfig, device) -> torch.Tensor:
+    """fp32 [max_positions, head_dim]: cos(pos * inv_freq) then sin(...) (the rotary embedding of HF Llama / Qwen3, with
+    the checkpoint's rope scaling: `rope_inv_freq`)."""
+    inv = rope_inv_freq(cfg, device)
     ang = torch.arange(cfg.max_positions, dtype=torch.float32, device=device)[:, None] * inv[None, :]
     return torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
 
@@ -225,7 +259,11 @@ class ParoDecoderLM:
             th = torch.stack([g(n, "theta") for n in names])
             pr = torch.stack([g(n, "pairs") for n in names])
             cs = torch.stack([g(n, "channel_scales").reshape(1, -1) for n in names])
-            return PackedParoWeights(qw, qz, sc, th, pr, cs, sizes)
+            has_b = [f"{prefix}.{n}.bias" in t for n in names]
+            if any(has_b) and not all(has_b):
+                raise ValueError(f"{prefix}: some of {names} carry a bias and some do not -- cannot merge them into one linear")
+            bias = torch.cat([g(n, "bias").reshape(-1) for n in names]).to(self.dtype) if all(has_b) else None   # attention_bias models
+            return PackedParoWeights(qw, qz, sc, th, pr, cs, sizes, bias)
 
         for l in range(cfg.n_layers):
             p = f"model.layers.{l}"
@@ -396,6 +434,8 @@ class ParoDecoderLM:
         c = self.cfg
         T = int(ids.numel())
         n_new = min(max_new_tokens, c.max_positions - T)
+        if T < 1 or n_new < 1:
+            raise ValueError(f"nothing to generate: prompt of {T} tokens, max_new_tokens {max_new_tokens}, max_positions {c.max_positions}")
         torch.cuda.synchronize(self.device)
         t0 = time.perf_counter()
         self.prefill(ids)

@@ -10,8 +10,8 @@ the router's weights are applied by the surrounding MoE block.
 Here, for decode-sized inputs (few tokens) the routed experts of all tokens are TWO launches: the merged gate|up
 projection of every (token, expert) slot, then the down projection with the SiLU*mul prologue -- the fused GEMV with
 ``blockIdx.z`` = slot and the slot's expert id read from device memory (``paro_w4a16_gemv_experts``), the shared
-rotation packed once.  Larger token counts group the tokens by expert and run each expert's rows through the
-prefill GEMM path.
+rotation packed once.  Larger token counts rotate the tokens once, sort the (token, expert) pairs by expert on the device
+and run ONE grouped W4A16 GEMM per projection over the expert segments (``paro_w4a16_gemm_grouped``), no host round trip.
 """
 from __future__ import annotations
 
@@ -82,12 +82,65 @@ class ParoMoEExperts:
         x = x.reshape(T, self.H).contiguous()
         out = torch.empty(T, k, self.H, dtype=x.dtype, device=x.device)
         if T * k <= _DECODE_SLOTS:
+            if not torch.cuda.is_current_stream_capturing() and bool((indices.min() < 0) | (indices.max() >= self.E)):
+                raise IndexError(f"expert indices must lie in [0, {self.E})")      # an id >= E would be an out-of-bounds weight read
             idx = indices.reshape(-1).to(torch.int32).contiguous()
             gu = torch.empty(T * k, 2 * self.I, dtype=x.dtype, device=x.device)
             self._slots(self.gate_up[0], self.gu_wq, self.gu_sz, x, gu, idx, k, nat.PROLOGUE_NONE)
             self._slots(self.down[0], self.dn_wq, self.dn_sz, gu, out.view(T * k, self.H), idx, 1, nat.PROLOGUE_SILU_MUL)
             return out
-        # prefill: group the (token, slot) pairs by expert, run each expert's rows through the GEMM path
+        if indices.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            bad = (indices.min() < 0) | (indices.max() >= self.E)      # an id >= E would be an out-of-bounds weight read
+            if bool(bad):
+                raise IndexError(f"expert indices must lie in [0, {self.E})")
+        return self._grouped_prefill(x, indices, out)
+
+    def _grouped_prefill(self, x: torch.Tensor, indices: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Prefill: rotate the tokens ONCE (the experts share the rotation), sort the (token, expert) pairs by expert on the
+        device, one grouped W4A16 GEMM over the expert segments (``paro_w4a16_gemm_grouped``), SiLU*mul and the down rotation
+        once over all rows, a second grouped GEMM, un-sort.  Nothing is read back to the host (shapes depend on T, k, E
+        only), so the whole sequence is HIP-graph capturable."""
+        lib = nat.load()
+        T, k = indices.shape
+        S, E, dev, dt = T * k, self.E, x.device, x.dtype
+        BM = 64 if S // E < 96 else 128                              # row block of the grouped GEMM (static: shapes only)
+        max_rows = (S + E * (BM - 1) + BM - 1) // BM * BM            # every expert's segment padded up to a block
+        flat = indices.reshape(-1).to(torch.int64)
+        counts = torch.zeros(E, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
+        padded = (counts + (BM - 1)) // BM * BM
+        pend = torch.cumsum(padded, 0)
+        pstart, ustart = pend - padded, torch.cumsum(counts, 0) - counts
+        order = torch.argsort(flat, stable=True)
+        es = flat[order]
+        dest = pstart[es] + (torch.arange(S, device=dev) - ustart[es])      # row of sorted pair j in the padded buffer
+        blocks = torch.arange(max_rows // BM, device=dev, dtype=torch.int64) * BM
+        block_expert = torch.where(blocks < pend[-1], torch.searchsorted(pend, blocks, right=True), torch.full_like(blocks, -1)).to(torch.int32)
+        gu0, dn0 = self.gate_up[0], self.down[0]
+        xr = torch.ops.rotation.rotate(x, gu0.pairs[0], gu0.theta[0], gu0.channel_scales[0], 128)       # [T, H], once
+        xs = torch.zeros(max_rows, self.H, dtype=dt, device=dev)
+        xs.index_copy_(0, dest, xr.index_select(0, order // k))
+        gu = torch.empty(max_rows, 2 * self.I, dtype=dt, device=dev)
+
+        def grouped(pk0, wq, sz, xin, yout):
+            d = ops.make_desc(pk0.K, pk0.partition_sizes, int(pk0.pairs.size(1)), dt, wq, sz, pk0.rot, pk0.pairs, pk0.theta,
+                              pk0.channel_scales, None, 0, group_size=pk0.group_size)
+            with torch.cuda.device(dev):
+                nat.check(lib.paro_w4a16_gemm_grouped(ctypes.byref(d), xin.data_ptr(), yout.data_ptr(), max_rows, BM, block_expert.data_ptr(),
+                                                      wq.stride(0) * 4, sz.stride(0) * 4, nat.current_stream_ptr(dev)))
+        grouped(gu0, self.gu_wq, self.gu_sz, xs, gu)
+        act = torch.nn.functional.silu(gu[:, :self.I]) * gu[:, self.I:]
+        ar = torch.ops.rotation.rotate(act.contiguous(), dn0.pairs[0], dn0.theta[0], dn0.channel_scales[0], 128)
+        yd = torch.empty(max_rows, self.H, dtype=dt, device=dev)
+        grouped(dn0, self.dn_wq, self.dn_sz, ar, yd)
+        out.view(S, self.H).index_copy_(0, order, yd.index_select(0, dest))
+        return out
+
+    def per_expert_prefill(self, x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+        """The round-2 prefill route, kept for A/B timing (tools/bench_moe.py): a host loop over the experts (one
+        device->host read of the counts, E x (rotate pre-pass + 2 GEMMs))."""
+        T, k = indices.shape
+        x = x.reshape(T, self.H).contiguous()
+        out = torch.empty(T, k, self.H, dtype=x.dtype, device=x.device)
         flat = indices.reshape(-1)
         order = torch.argsort(flat, stable=True)
         counts = torch.bincount(flat, minlength=self.E).tolist()

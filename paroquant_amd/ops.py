@@ -336,6 +336,8 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     if x.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"expected float16 or bfloat16 activations, got {x.dtype}")
     y = out if out is not None else torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    if out is not None and (out.numel() != rows * N or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device):
+        raise ValueError(f"out must be a contiguous [{rows}, {N}] tensor of {x.dtype} on {x.device} (the kernel writes through its raw pointer)")
     if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N or not residual.is_contiguous()):
         raise ValueError("residual must be a contiguous [rows, N] tensor of the activation dtype")
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
@@ -472,6 +474,10 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
     if tuple(rope.shape) != (T_max, head_dim) or rope.dtype != torch.float32 or pos.dtype != torch.int32:
         raise ValueError("rope must be fp32 [T, head_dim] (cos then sin per position) and pos an int32 device scalar")
     y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    if out is not None and (out.numel() != n_heads * head_dim or out.dtype != qkv.dtype or not out.is_contiguous() or out.device != qkv.device):
+        raise ValueError(f"out must be a contiguous tensor of {n_heads * head_dim} {qkv.dtype} elements on {qkv.device}")
+    if qkv.numel() != (n_heads + 2 * n_kv_heads) * head_dim or not qkv.is_contiguous():
+        raise ValueError(f"qkv must be a contiguous vector of (n_heads + 2 n_kv_heads) * head_dim = {(n_heads + 2 * n_kv_heads) * head_dim} elements")
     ws = workspace if workspace is not None else attn_workspace(qkv.device, n_heads, n_kv_heads, head_dim, T_max)
     with torch.cuda.device(qkv.device):
         nat.check(lib.paro_attn_decode(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(),

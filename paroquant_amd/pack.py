@@ -72,21 +72,80 @@ def quantize_rotated_weight(weight: torch.Tensor, pairs: torch.Tensor, theta: to
     return (q.reshape(N, K).to(torch.int32), scale.reshape(N, K // group_size), zp.reshape(N, K // group_size).to(torch.int32))
 
 
+def state_value(sd: Dict, *keys: str) -> int:
+    """First of `keys` present in an optimiser state dict, as a Python int (0-d tensors are unwrapped) -- the optimiser
+    writes hyper-parameters either flat ("n_bits") or under the quantiser ("quantizer.n_bits"), cli/convert.py:127-132."""
+    for key in keys:
+        if key in sd:
+            val = sd[key]
+            return int(val.item()) if isinstance(val, torch.Tensor) else int(val)
+    raise KeyError(f"None of {keys} found")
+
+
+def stack_if_numbered(sd: Dict, key: str) -> torch.Tensor:
+    """`sd[key]`, or the stack of `sd["key.0"], sd["key.1"], ...` (a ParameterList in the optimiser), cli/convert.py:135-146."""
+    if key in sd:
+        return sd[key]
+    parts, i = [], 0
+    while f"{key}.{i}" in sd:
+        parts.append(sd[f"{key}.{i}"])
+        i += 1
+    if parts:
+        return torch.stack(parts)
+    raise KeyError(key)
+
+
 def quantize_layer(sd: Dict[str, torch.Tensor], device=None) -> Dict[str, torch.Tensor]:
-    """Optimiser state dict of one linear (keys as cli/convert.py:239-262) -> its checkpoint tensors
-    (qweight, qzeros, scales, theta, pairs, channel_scales[, bias]); channel_scales are stored inverted (:264)."""
+    """Optimiser state dict of one linear (keys as cli/convert.py:239-262, both hyper-parameter spellings and numbered
+    `pairs_grouped.N` / `angles_grouped.N` lists accepted) -> its checkpoint tensors (qweight, qzeros, scales, theta, pairs,
+    channel_scales[, bias]); channel_scales are stored inverted (:264)."""
     dev = torch.device(device) if device is not None else sd["weight"].device
     g = lambda k: sd[k].to(dev)
-    bits, gs = int(sd["n_bits"]), int(sd["group_size"])
-    q, s2d, z2d = quantize_rotated_weight(g("weight"), g("pairs_grouped").to(torch.int16), g("angles_grouped"), g("channel_scales"),
+    bits, gs = state_value(sd, "n_bits", "quantizer.n_bits"), state_value(sd, "group_size", "quantizer.group_size")
+    pairs = stack_if_numbered(sd, "pairs_grouped").to(dev, torch.int16)
+    theta = stack_if_numbered(sd, "angles_grouped").to(dev, torch.float32)
+    q, s2d, z2d = quantize_rotated_weight(g("weight"), pairs, theta, g("channel_scales"),
                                           g("quantizer.scale"), g("quantizer.zero_point_float"), bits, gs)
     out = to_awq_buffers(q, s2d, z2d)
-    out["theta"] = g("angles_grouped").to(torch.float16)
-    out["pairs"] = g("pairs_grouped").to(torch.int16)
+    out["theta"] = theta.to(torch.float16)
+    out["pairs"] = pairs
     out["channel_scales"] = (1.0 / g("channel_scales").float()).to(torch.float16).view(1, -1)
     if sd.get("bias") is not None:
         out["bias"] = g("bias").to(torch.float16)
     return out
+
+
+def quantize_moe(sd: Dict[str, torch.Tensor], device=None):
+    """Optimiser state dict of one MoE expert block -> (per-projection AWQ buffers stacked over experts, the shared
+    rotation buffers), cli/convert.py:280-379: gate_up [E, 2 I, H] and down [E, H, I] are each quantised with ONE rotation
+    shared by all experts; rows [:I] of gate_up are gate_proj, rows [I:] up_proj; rotation buffers are named
+    `gate_up_weight_{theta,pairs,channel_scales}` / `down_weight_*` with channel_scales stored inverted."""
+    dev = torch.device(device) if device is not None else sd["gate_up_weight"].device
+    g = lambda k: sd[k].to(dev)
+    bits, gs = state_value(sd, "n_bits", "quantizer.n_bits"), state_value(sd, "group_size", "quantizer.group_size")
+    gate_up, down = g("gate_up_weight").float(), g("down_weight").float()
+    E, two_i, H = gate_up.shape
+    _, H2, I = down.shape
+    if H2 != H:
+        raise ValueError(f"Unexpected MoE shapes: gate_up={tuple(gate_up.shape)} down={tuple(down.shape)}")   # convert.py:292-293
+    rot, q = {}, {}
+    for name, w, K in (("gate_up", gate_up.reshape(-1, H), H), ("down", down.reshape(-1, I), I)):
+        pairs = stack_if_numbered(sd, f"{name}_pairs_grouped").to(dev, torch.int16)
+        theta = stack_if_numbered(sd, f"{name}_angles_grouped").to(dev, torch.float32)
+        cs = g(f"{name}_channel_scales").float()
+        q[name] = quantize_rotated_weight(w, pairs, theta, cs, g(f"{name}_quantizer.scale"), g(f"{name}_quantizer.zero_point_float"), bits, gs)
+        rot[f"{name}_weight_theta"] = theta.to(torch.float16)
+        rot[f"{name}_weight_pairs"] = pairs
+        rot[f"{name}_weight_channel_scales"] = (1.0 / cs).to(torch.float16).view(1, -1)
+    half = two_i // 2
+    gq, gsc, gz = (t.reshape(E, two_i, -1) for t in q["gate_up"])
+    dq, dsc, dz = (t.reshape(E, H, -1) for t in q["down"])
+    out = {}
+    for proj, qq, sc, zp in (("gate_proj", gq[:, :half], gsc[:, :half], gz[:, :half]), ("up_proj", gq[:, half:], gsc[:, half:], gz[:, half:]),
+                             ("down_proj", dq, dsc, dz)):
+        bufs = [to_awq_buffers(qq[e], sc[e], zp[e]) for e in range(E)]
+        out[proj] = {k: torch.stack([b[k] for b in bufs]) for k in ("qweight", "qzeros", "scales")}
+    return out, rot
 
 
 # ----------------------------------------------------------------------------- pre-packed (CDNA4 layout) files
