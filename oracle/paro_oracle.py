@@ -17,14 +17,16 @@ Pinning status
   quantise-after-rotate export formula are PINNED against golden vectors
   captured by importing the reference's own Python
   (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
-* The rotation *outputs* and the INT4 matmul are **parity unpinned**: the
-  reference implements the rotation in CUDA only (``rotation.cu:133-135``
-  registers a CUDA-key kernel, nothing for CPU), ships no tests or golden
-  vectors, and delegates the INT4 matmul to un-vendored third-party packages
-  (AutoAWQ ``WQLinearMMFunction`` -- unpinned in ``pyproject.toml:30``; vLLM
-  ``>=0.19.1,<0.20`` AWQ-Marlin; MLX ``quantized_matmul``).  Their arithmetic
-  is restated here from the reference's own producer / consumer code and from
-  the kernel source, each function citing the lines it follows.
+* The rotation's CONVENTION is pinned to reference-held code: orientation and pair layout of a stage by the analytic
+  d/dtheta expression of ``RotateTensorFunc.backward`` (G7, ``tests/golden/make_golden_g7.py``), the ORDER of the stages by
+  that function's stage-by-stage backward loop (G7b, ``make_golden_g7b.py``: ``<F(d), G> == <grad_x, d>`` holds for stage 0
+  first and fails for the reversed order).
+* What remains **parity unpinned** is the per-stage ROUNDING of the half-precision rotation and the INT4 matmul: the
+  reference implements the rotation in CUDA only (``rotation.cu:133-135`` registers a CUDA-key kernel, nothing for CPU),
+  ships no tests or golden vectors, and delegates the INT4 matmul to un-vendored third-party packages (AutoAWQ
+  ``WQLinearMMFunction`` -- unpinned in ``pyproject.toml:30``; vLLM ``>=0.19.1,<0.20`` AWQ-Marlin; MLX
+  ``quantized_matmul``).  Their arithmetic is restated here from the reference's own producer / consumer code and from the
+  kernel source, each function citing the lines it follows.
 
 Every function cites the reference ``file:line`` it restates (paths relative to
 the reference root).

@@ -370,3 +370,31 @@ def test_bench_layer_plans_dense_and_hybrid():
             for _, K, sizes, _ in sh:
                 assert K % 128 == 0 and all(n % 16 == 0 for n in sizes), (m, K, sizes)
     assert len(bench.kernel_sources_sha()) == 64
+
+
+def test_decoder_rope_scaling_and_unsupported_configs():
+    """`DecoderConfig.from_hf`: llama3 / linear rope scaling reproduce transformers' inv_freq (z-lab/Llama-3.1-8B-Instruct-PARO
+    carries llama3 scaling); scaling types the harness does not implement fail at load time."""
+    import torch
+    from paroquant_amd.decoder import DecoderConfig, rope_inv_freq
+    from transformers import LlamaConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    base = {"hidden_size": 4096, "intermediate_size": 14336, "num_attention_heads": 32, "num_key_value_heads": 8, "num_hidden_layers": 2,
+            "vocab_size": 128, "rope_theta": 500000.0, "model_type": "llama"}
+    sc = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+    mine = rope_inv_freq(DecoderConfig.from_hf({**base, "rope_scaling": sc}), "cpu")
+    ref, _ = ROPE_INIT_FUNCTIONS["llama3"](LlamaConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, rope_theta=500000.0,
+                                                         rope_scaling=sc, max_position_embeddings=131072), "cpu")
+    assert torch.allclose(mine, ref, rtol=1e-6, atol=0)
+    plain = rope_inv_freq(DecoderConfig.from_hf(base), "cpu")
+    assert not torch.allclose(mine, plain) and torch.allclose(mine[:8], plain[:8])       # high frequencies untouched, low ones divided
+    lin = rope_inv_freq(DecoderConfig.from_hf({**base, "rope_scaling": {"rope_type": "linear", "factor": 4.0}}), "cpu")
+    assert torch.allclose(lin, plain / 4.0)
+    # the rope_parameters spelling of newer configs
+    rp = rope_inv_freq(DecoderConfig.from_hf({k: v for k, v in base.items() if k != "rope_theta"} | {"rope_parameters": {"rope_theta": 500000.0, **sc}}), "cpu")
+    assert torch.allclose(rp, mine)
+    import pytest as _pt
+    with _pt.raises(NotImplementedError, match="yarn"):
+        DecoderConfig.from_hf({**base, "rope_scaling": {"rope_type": "yarn", "factor": 4.0}})
+    with _pt.raises(NotImplementedError, match="partial rotary"):
+        DecoderConfig.from_hf({**base, "partial_rotary_factor": 0.25})

@@ -228,6 +228,26 @@ def test_g7_grad_x_and_scale(golden_dir):
     assert float(g["fd_err_as_shipped"]) > 0.5
 
 
+def test_g7b_stage_order_pinned_by_reference_backward_loop(golden_dir):
+    """The ORDER of the krot stages: the reference's backward loop (autograd.py:34-38) undoes the stages last-first, one
+    stage per rotate call, so its grad_x is the transpose of `stage 0 first, stage krot-1 last`.  <F(d), G> must equal
+    <grad_x, d> for the oracle's multi-stage forward F -- and must NOT for the forward with the stages reversed (the fixture
+    uses 8 independent random matchings and angles ~0.7 rad: consecutive stages do not commute)."""
+    g = _load(golden_dir, "rotate_stage_order.npz")
+    fwd = lambda idx, th, mode="ideal": po.rotate(g["d"], idx, th, g["scale"], 128, mode=mode)
+    rhs = float((g["grad_x"] * g["d"]).sum())
+    lhs = float((fwd(g["idx"], g["theta"]) * g["G"]).sum())
+    assert abs(lhs - rhs) < 1e-9 * max(1.0, abs(rhs))
+    wrong = float((fwd(g["idx"][::-1].copy(), g["theta"][::-1].copy()) * g["G"]).sum())
+    assert abs(wrong - rhs) > 1e-2 * max(1.0, abs(rhs))
+    # every precision mode of the oracle applies the stages in the same order (within its rounding)
+    for mode, tol in (("f32", 1e-4), ("f16", 5e-2), ("bf16", 3e-1)):
+        v = float((np.asarray(fwd(g["idx"], g["theta"], mode), dtype=np.float64) * g["G"]).sum())
+        assert abs(v - rhs) < tol * max(1.0, abs(rhs)) and abs(v - wrong) > 10 * tol, mode
+    # the forward the generator stored is the oracle's own multi-stage forward (stubbed in): consistency of the fixture
+    assert np.abs(po.rotate(g["x"], g["idx"], g["theta"], g["scale"], 128, mode="ideal") - g["y"]).max() < 1e-12
+
+
 # ---- K1..K4: rotation KATs / algebra (rotation.cuh:55-56; optim/qlinear.py:110-120) ----
 
 def _single_pair_idx(K=128):
