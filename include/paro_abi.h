@@ -182,7 +182,7 @@ int paro_workspace_status(const void* workspace, void* stream);
 
 /* Decode / small-batch path (rows <= 64; above 16 rows always with the rotate pre-pass): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
- * Launch-shape knobs (0 = auto): tiles_per_wave in 1..8 (3, 5, 6, 7: fused mode, <= 4 rows, 8 waves);
+ * Launch-shape knobs (0 = auto): tiles_per_wave in {1, 2, 4, 8};
  * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
  * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above),
  * 2 (v10) = x IS ALREADY ROTATED by the caller: [n_parts][rows][K] in the activation type, partition p rotated with

@@ -131,8 +131,8 @@ namespace paro {
 // The launch shape a GEMV call ends up with: caller's knobs (0 = auto, mode -1 = auto) -> final values.
 int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ksp, int& wv, int& mode) {
   const int waves_in = wv;
-  if (tpw < 0 || tpw > 8)
-    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto) or 1..8 (got %d)", tpw);
+  if (tpw != 0 && tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8)
+    return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto), 1, 2, 4 or 8 (got %d)", tpw);
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
@@ -150,11 +150,9 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv);
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
-  if ((tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) && waves_in <= 0) wv = 8;   // 3 / 5 / 6 / 7 tiles: 8-wave workgroups only
+  (void)waves_in;
   if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
   if (quant_group(L->group_size) == 64) {   // group_size 64 instantiations: 1 / 2 / 4 / 8 tiles, 4 or 8 waves
-    if (tpw == 3) tpw = 2;
-    if (tpw == 5 || tpw == 6 || tpw == 7) tpw = 4;
     if (wv == 16) wv = 8;
   }
   const int G = (int)(L->K / 128);
@@ -244,7 +242,6 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
   if (rc != PARO_OK) return rc;
   if (fused) {
-    if (tpw == 3 || tpw == 5 || tpw == 6 || tpw == 7) tpw = 4;   // fused instantiations exist for 1 / 2 / 4 / 8 tiles
     if (tpw == 8 && wv == 16) wv = 8;
   }
   const int G = (int)(L->K / 128);
@@ -320,13 +317,12 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   }
   dim3 grid((unsigned)pt.cbs, (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
-  // [type][pre-rotated][tiles per wave - 1]; 3, 5, 6, 7 tiles exist for the fused mode only
+  // [type][pre-rotated][tiles per wave - 1]: 1, 2, 4, 8 tiles per wave (the 3 / 5 / 6 / 7-tile builds of round 2 measured
+  // within +-3 % of their neighbours on every shape and were dropped)
   static const launch_fn table[2][2][8] = {
-      {{launch_gemv_f16_0_t1, launch_gemv_f16_0_t2, launch_gemv_f16_0_t3, launch_gemv_f16_0_t4, launch_gemv_f16_0_t5,
-        launch_gemv_f16_0_t6, launch_gemv_f16_0_t7, launch_gemv_f16_0_t8},
+      {{launch_gemv_f16_0_t1, launch_gemv_f16_0_t2, nullptr, launch_gemv_f16_0_t4, nullptr, nullptr, nullptr, launch_gemv_f16_0_t8},
        {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, nullptr, launch_gemv_f16_1_t4, nullptr, nullptr, nullptr, launch_gemv_f16_1_t8}},
-      {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, launch_gemv_bf16_0_t3, launch_gemv_bf16_0_t4, launch_gemv_bf16_0_t5,
-        launch_gemv_bf16_0_t6, launch_gemv_bf16_0_t7, launch_gemv_bf16_0_t8},
+      {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, nullptr, launch_gemv_bf16_0_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_0_t8},
        {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, nullptr, launch_gemv_bf16_1_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_1_t8}}};
   const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode >= 1 ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);

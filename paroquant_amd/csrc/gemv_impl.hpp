@@ -1031,18 +1031,10 @@ int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   int launch_gemv_##T##_##P##_t2(const GemvArgs&, int, dim3, hipStream_t); \
   int launch_gemv_##T##_##P##_t4(const GemvArgs&, int, dim3, hipStream_t); \
   int launch_gemv_##T##_##P##_t8(const GemvArgs&, int, dim3, hipStream_t);
-#define PARO_DECL_GEMV_ODD(T) \
-  int launch_gemv_##T##_0_t3(const GemvArgs&, int, dim3, hipStream_t); \
-  int launch_gemv_##T##_0_t5(const GemvArgs&, int, dim3, hipStream_t); \
-  int launch_gemv_##T##_0_t6(const GemvArgs&, int, dim3, hipStream_t); \
-  int launch_gemv_##T##_0_t7(const GemvArgs&, int, dim3, hipStream_t);
 PARO_DECL_GEMV(f16, 0)
 PARO_DECL_GEMV(f16, 1)
 PARO_DECL_GEMV(bf16, 0)
 PARO_DECL_GEMV(bf16, 1)
-PARO_DECL_GEMV_ODD(f16)
-PARO_DECL_GEMV_ODD(bf16)
 #undef PARO_DECL_GEMV
-#undef PARO_DECL_GEMV_ODD
 
 }  // namespace paro

@@ -300,7 +300,7 @@ def test_gemv_on_caller_rotated_activations(dev, dtype, K, sizes):
         ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 2, bias)              # [rows, K] is not the pre-rotated layout
 
 
-@pytest.mark.parametrize("tpw", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tpw", [1, 2, 4, 8])
 @pytest.mark.parametrize("ksplit,waves,mode", [(1, 4, 0), (2, 4, 0), (3, 8, 0), (0, 0, 0), (1, 16, 0), (2, 16, 0),
                                                (1, 0, 1), (2, 4, 1)])
 def test_gemv_launch_shapes_agree(dev, tpw, ksplit, waves, mode):
@@ -312,9 +312,7 @@ def test_gemv_launch_shapes_agree(dev, tpw, ksplit, waves, mode):
     rng = np.random.default_rng(5)
     pk = _packed(L, dev, L["bias"])
     for rows in (1, 4, 6, 13):
-        odd = tpw in (3, 5, 6, 7)
-        if (rows > 4 and waves == 16) or (rows > 8 and tpw == 8) or (tpw == 8 and waves == 16) \
-                or (odd and (waves not in (0, 8) or rows > 4 or mode == 1)):
+        if (rows > 4 and waves == 16) or (rows > 8 and tpw == 8) or (tpw == 8 and waves == 16):
             continue   # combinations that are not built (see launch tables in gemv_impl.hpp)
         x = rng.standard_normal((rows, K)).astype(np.float16)
         y = ops.w4a16_gemv_tuned(_t(x, dev), pk, tpw, ksplit, waves, mode, pk.bias)
@@ -1037,10 +1035,10 @@ def test_gemv_group64_matches_oracle(dev, K, sizes, rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tpw,ksplit,waves,mode", [(1, 1, 8, 0), (2, 2, 4, 0), (4, 4, 8, 0), (8, 1, 8, 0), (0, 0, 0, 0), (3, 1, 0, 0),
+@pytest.mark.parametrize("tpw,ksplit,waves,mode", [(1, 1, 8, 0), (2, 2, 4, 0), (4, 4, 8, 0), (8, 1, 8, 0), (0, 0, 0, 0),
                                                    (1, 1, 16, 0), (2, 1, 0, 1), (4, 2, 4, 1)])
 def test_gemv_group64_launch_shapes(dev, tpw, ksplit, waves, mode):
-    """Launch-shape knobs at group_size 64: unsupported combinations (3 / 5 / 6 / 7 tiles, 16 waves) are resolved to a
+    """Launch-shape knobs at group_size 64: unsupported combinations (16 waves) are resolved to a
     built one, never to a wrong answer."""
     from paroquant_amd import ops
     K, sizes = 1536, [400, 112]

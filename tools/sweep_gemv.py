@@ -62,7 +62,7 @@ def main():
         import itertools
         for tpw, ksp, wv, mode in itertools.product(tpws, ksps, wvs, modes):
             if ksp > max(1, G // 2) or (tpw == 8 and wv == 16) or (args.rows > 4 and wv == 16) \
-                    or (tpw in (3, 5, 6, 7) and (wv != 8 or args.rows > 4)):
+                    or tpw not in (1, 2, 4, 8):
                 continue
 
             def run(i, tpw=tpw, ksp=ksp, wv=wv, mode=mode):
