@@ -212,6 +212,8 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
 #define PARO_PROLOGUE_NONE 0
 #define PARO_PROLOGUE_RMSNORM 1
 #define PARO_PROLOGUE_SILU_MUL 2
+#define PARO_PROLOGUE_GELU_TANH_MUL 3   /* v11: x_k = gelu_tanh(gate_k) * up_k -- the Gemma families' MLP activation (the reference lists
+                                           gemma-4 checkpoints, README.md:89-93); same input layout as SILU_MUL */
 typedef struct paro_fusion {
   int32_t prologue;
   float eps;             /* RMSNorm epsilon */
@@ -340,6 +342,7 @@ int paro_argmax_advance(const void* workspace, int64_t vocab, int64_t* token, in
  * shared); workspace >= paro_chain_workspace_bytes(L, rows). */
 #define PARO_CHAIN_ACT_NONE 0
 #define PARO_CHAIN_ACT_SILU_MUL 1
+#define PARO_CHAIN_ACT_GELU_TANH_MUL 2   /* gelu_tanh(gate) * up (Gemma) */
 typedef struct paro_chain {
   const void* x_rot;
   void* y;

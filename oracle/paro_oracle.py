@@ -471,6 +471,13 @@ def silu_mul(gate_up, inter: int):
     return g / (1.0 + np.exp(-g)) * u
 
 
+def gelu_tanh_mul(gate_up, inter: int):
+    """Gemma's MLP activation: gelu(gate, approximate="tanh") * up (HF `GemmaMLP`, hidden_activation gelu_pytorch_tanh)."""
+    gu = np.asarray(gate_up, dtype=np.float64)
+    g, u = gu[..., :inter], gu[..., inter:2 * inter]
+    return 0.5 * g * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (g + 0.044715 * g ** 3))) * u
+
+
 def rope_tables(head_dim: int, positions: int, theta: float = 10000.0):
     half = head_dim // 2
     inv = 1.0 / (theta ** (np.arange(half, dtype=np.float64) * 2.0 / head_dim))

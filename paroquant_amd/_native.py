@@ -108,8 +108,8 @@ class ParoChain(Structure):
                 ("next_x_rot", c_void_p), ("next_col0", c_int64), ("next_act", c_int32), ("reserved0", c_int32)]
 
 
-PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_MUL = 0, 1, 2
-CHAIN_ACT_NONE, CHAIN_ACT_SILU_MUL = 0, 1
+PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_MUL, PROLOGUE_GELU_TANH_MUL = 0, 1, 2, 3
+CHAIN_ACT_NONE, CHAIN_ACT_SILU_MUL, CHAIN_ACT_GELU_TANH_MUL = 0, 1, 2
 
 _lib = None
 

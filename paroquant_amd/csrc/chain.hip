@@ -73,7 +73,7 @@ extern "C" int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t*
   const int G = (int)(L->K / 128);
   const int nblocks_all = (int)(L->N / 128);
   const paro_linear_t* X = C->next;
-  const bool pair = C->next_act == PARO_CHAIN_ACT_SILU_MUL;
+  const bool pair = C->next_act == PARO_CHAIN_ACT_SILU_MUL || C->next_act == PARO_CHAIN_ACT_GELU_TANH_MUL;
   if (C->next_act != PARO_CHAIN_ACT_NONE && !pair) return fail(PARO_ERR_INVALID, "unknown next_act %d", C->next_act);
   ChainArgs a;
   a.nrot = nullptr; a.ncs = nullptr; a.nx = nullptr; a.np = 0; a.Gn = 0; a.nblk0 = 0; a.act = 0; a.blk0 = 0; a.up_off = 0;
@@ -93,7 +93,7 @@ extern "C" int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t*
     a.np = X->n_parts;
     a.Gn = (int)(X->K / 128);
     a.nblk0 = (int)(C->next_col0 / 128);
-    a.act = pair ? 1 : 0;
+    a.act = pair ? C->next_act : 0;
     if (pair) {
       if (C->next_col0 != 0 || 2 * X->K != L->N || L->n_parts != 2 || L->part_cols[0] != X->K)
         return fail(PARO_ERR_UNSUPPORTED, "silu(gate) * up needs the merged gate|up projection: two partitions of the consumer's K columns");
@@ -174,7 +174,7 @@ extern "C" int paro_chain_launch_shape(const paro_linear_t* L, const paro_chain_
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
   if (!C || !ksplit || !waves) return fail(PARO_ERR_INVALID, "null pointer");
-  const bool pair = C->next_act == PARO_CHAIN_ACT_SILU_MUL && C->next;
+  const bool pair = (C->next_act == PARO_CHAIN_ACT_SILU_MUL || C->next_act == PARO_CHAIN_ACT_GELU_TANH_MUL) && C->next;
   const int nblocks = pair ? (int)(C->next->K / 128) : (int)(L->N / 128);
   chain_shape(nblocks, (int)(L->K / 128), pair, (int)rows, *ksplit, *waves);
   return PARO_OK;

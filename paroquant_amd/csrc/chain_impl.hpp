@@ -72,7 +72,7 @@ struct ChainArgs {
   unsigned short* nx;             // rotated output [P'][rows][K']
   int np, Gn;                     // consumer partitions, K' / 128
   int nblk0;                      // first block of this layer's output that the consumer reads (channel 0 of K')
-  int act;                        // 0 identity, 1 silu(gate) * up (PAIR)
+  int act;                        // 0 identity, 1 silu(gate) * up, 2 gelu_tanh(gate) * up (PAIR)
   unsigned long long* dbg;        // PARO_CHAIN_DIAG builds: 16 phase stamps per workgroup (tools/chain_harness.cpp), else null
 };
 
@@ -510,8 +510,13 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
     }
     float z = yf[0];
     if constexpr (PAIR) {
-      // silu(gate) * up in fp32 on the rounded projections
-      if (a.act == 1) z = yf[0] * yf[1] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * yf[0]));
+      // silu(gate) * up -- or gelu_tanh(gate) * up: the same g u / (1 + exp(-a)) with a = 2 sqrt(2 / pi) (g + 0.044715 g^3) --
+      // in fp32 on the rounded projections
+      if (a.act != 0) {
+        const float g = yf[0];
+        const float arg = a.act == 2 ? 1.5957691216057308f * __builtin_fmaf(0.044715f * g * g, g, g) : g;
+        z = g * yf[1] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * arg));
+      }
     }
     if (live) zs[e] = z;
     if (a.ssq_out) {

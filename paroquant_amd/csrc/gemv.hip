@@ -216,7 +216,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     ksplit = 1;
   }
   if (fused) {
-    if (F->prologue < PARO_PROLOGUE_NONE || F->prologue > PARO_PROLOGUE_SILU_MUL) return fail(PARO_ERR_INVALID, "unknown prologue %d", F->prologue);
+    if (F->prologue < PARO_PROLOGUE_NONE || F->prologue > PARO_PROLOGUE_GELU_TANH_MUL) return fail(PARO_ERR_INVALID, "unknown prologue %d", F->prologue);
     if (rows > 4) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue is a decode path: at most 4 rows (got %lld)", (long long)rows);
     if (L->krot > 8) return fail(PARO_ERR_UNSUPPORTED, "fused prologue / epilogue needs the in-kernel rotation (krot <= 8)");
     if (mode == 1 || mode == 2) return fail(PARO_ERR_INVALID, "fused prologue / epilogue needs mode 0 (in-kernel rotation)");
@@ -235,7 +235,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
       if (F->ar_peers[F->ar_rank] != F->ar_own) return fail(PARO_ERR_INVALID, "all-reduce epilogue: ar_peers[ar_rank] must be ar_own");
       if (L->N > F->ar_max_elems) return fail(PARO_ERR_INVALID, "all-reduce buffers sized for %lld elements, the layer has %lld outputs", (long long)F->ar_max_elems, (long long)L->N);
     }
-    const int64_t min_stride = (F->prologue == PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
+    const int64_t min_stride = (F->prologue >= PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
   }
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
@@ -273,7 +273,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.slabs = nullptr;
   a.counters = nullptr;
   a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
-  const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue == PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
+  const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue >= PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.expert_idx = E ? E->expert_idx : nullptr;
   a.wq_estride = E ? E->wq_stride_bytes : 0;
   a.sz_estride = E ? E->sz_stride_bytes : 0;

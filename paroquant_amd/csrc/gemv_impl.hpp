@@ -466,9 +466,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if constexpr (FMODE == 2) {
         {
           const unsigned uv = r < h.rows ? b.xu[r] : 0u;
-          // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x
-          x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x0));
-          x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x1));
+          // silu(g) * u = g * u / (1 + exp(-g)); v_exp_f32 is 2^x.  The tanh form of GELU (Gemma) is the same expression on
+          // another argument: 0.5 g (1 + tanh(t)) = g / (1 + exp(-2 t)),  t = sqrt(2 / pi) (g + 0.044715 g^3)
+          float a0 = x0, a1 = x1;
+          if (h.prologue == PARO_PROLOGUE_GELU_TANH_MUL) {
+            a0 = 1.5957691216057308f * __builtin_fmaf(0.044715f * x0 * x0, x0, x0);
+            a1 = 1.5957691216057308f * __builtin_fmaf(0.044715f * x1 * x1, x1, x1);
+          }
+          x0 = x0 * A::to_f32(uv & 0xffffu) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a0));
+          x1 = x1 * A::to_f32(uv >> 16) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a1));
         }
       } else if constexpr (FMODE == 1) {
         if (h.prologue == PARO_PROLOGUE_RMSNORM) ssq[r] = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq[r]));
@@ -961,12 +967,12 @@ template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if (a.ar_mine) {   // + all-reduce epilogue (FUSED | 4): one row only
     if constexpr (MB == 1) {
-      if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 6>(a, waves, grid, st);
+      if (a.prologue == PARO_PROLOGUE_SILU_MUL || a.prologue == PARO_PROLOGUE_GELU_TANH_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 6>(a, waves, grid, st);
       return launch_waves_fused_mode<AT, TPW, MB, PREROT, 5>(a, waves, grid, st);
     }
     return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is built for one row");
   }
-  if (a.prologue == PARO_PROLOGUE_SILU_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
+  if (a.prologue == PARO_PROLOGUE_SILU_MUL || a.prologue == PARO_PROLOGUE_GELU_TANH_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
   return launch_waves_fused_mode<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

@@ -152,7 +152,7 @@ class PackedParoWeights:
                                            self.channel_scales, b, self.partition_sizes, self.workspace,
                                            self.wq_order, rmat)
 
-    def fold_norm_weight(self, weight: torch.Tensor) -> "PackedParoWeights":
+    def fold_norm_weight(self, weight: torch.Tensor, plus_one: bool = False) -> "PackedParoWeights":
         """Fold the weight of the RMSNorm that feeds this linear into the channel scales
         (``cs'[p, k] = cs[p, k] * w[k]``, fp32 product rounded once): with it the whole norm in front of the linear
         reduces to the scalar ``rsqrt(mean(x^2) + eps)`` that the fused GEMV applies (``ops.w4a16_gemv_fused``,
@@ -160,6 +160,8 @@ class PackedParoWeights:
         if getattr(self, "_norm_folded", False):
             raise RuntimeError("a norm weight has already been folded into these channel scales")
         w = weight.to(self.channel_scales.device).float().view(1, self.K)
+        if plus_one:        # Gemma / Qwen3.5 RMSNorm: y = x_hat * (1 + weight)
+            w = w + 1.0
         self.channel_scales = (self.channel_scales.float() * w).to(torch.float16).contiguous()
         self._norm_folded = True
         self._rmat = {}

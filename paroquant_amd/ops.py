@@ -321,12 +321,12 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
     ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
     gate_up output ``[rows, 2 K]`` and the linear consumes ``silu(gate) * up``; ``residual [rows, N]`` is added to
-    the output.  ``out`` may be given (e.g. a static buffer of a captured decode step).  ``allreduce`` (a
+    the output (nat.PROLOGUE_GELU_TANH_MUL: ``gelu_tanh(gate) * up``, the Gemma MLP).  ``out`` may be given (e.g. a static buffer of a captured decode step).  ``allreduce`` (a
     ``paroquant_amd.tp.OneShotAllReduce``): ``pk`` is a row-parallel shard and the output becomes the sum over the ranks
     (+ bias + residual, once), exchanged inside this launch -- one row, every rank issuing the same launches."""
     lib = nat.load()
     K, N = pk.K, pk.N
-    width = 2 * K if prologue == nat.PROLOGUE_SILU_MUL else K
+    width = 2 * K if prologue in (nat.PROLOGUE_SILU_MUL, nat.PROLOGUE_GELU_TANH_MUL) else K
     if x.size(-1) != width:
         raise ValueError(f"x must have {width} columns for this prologue, got {x.size(-1)}")
     x2 = x.reshape(-1, width)

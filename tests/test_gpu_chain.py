@@ -265,3 +265,30 @@ def test_chain_argument_errors(dev):
     L64 = po.make_layer(5, 256, [128], group_size=64)
     with pytest.raises(RuntimeError, match="group_size 128"):
         ops.chain_gemv(torch.zeros(1, 1, 256, device=dev, dtype=torch.float16), _packed(L64, dev))
+
+
+@pytest.mark.parametrize("rows", [1, 3])
+def test_gelu_tanh_mul_gemma_mlp_both_families(dev, rows):
+    """The Gemma MLP (gelu_tanh(gate) * up, RMSNorm weights stored as w with y = x_hat (1 + w)): the fused family's
+    GELU_TANH_MUL prologue and the chain family's epilogue activation, both against the oracle."""
+    from paroquant_amd import ops, _native as nat
+    h, inter = 512, 1280
+    Lgu, Ld = po.make_layer(31, h, [inter, inter]), po.make_layer(32, inter, [h])
+    rng = np.random.default_rng(rows)
+    w = (0.1 * rng.standard_normal(h)).astype(np.float16)                 # stored weight: the norm multiplies by (1 + w)
+    pgu, pd = _packed(Lgu, dev).fold_norm_weight(_t(w, dev), plus_one=True), _packed(Ld, dev)
+    x = (rng.standard_normal((rows, h)) * 2.0).astype(np.float16)
+    # fused family: gate_up with the RMSNorm prologue, down with the GELU prologue
+    gu = ops.w4a16_gemv_fused(_t(x, dev), pgu, nat.PROLOGUE_RMSNORM, 1e-6)
+    ref_gu = _ideal(Lgu, po.rmsnorm(x, 1.0 + w.astype(np.float64), 1e-6))
+    assert po.rel_err(_np(gu), ref_gu) < TIGHT_F16
+    y = ops.w4a16_gemv_fused(gu, pd, nat.PROLOGUE_GELU_TANH_MUL)
+    ref_y = _ideal(Ld, po.gelu_tanh_mul(_np(gu), inter))
+    assert po.rel_err(_np(y), ref_y) < TIGHT_F16
+    assert po.rel_err(_np(y), _ideal(Ld, po.silu_mul(_np(gu), inter))) > 5e-2        # ... and it is not SiLU
+    # chain family: the same two linears, the activation in gate_up's epilogue
+    xn = po.rmsnorm(x, 1.0 + w.astype(np.float64), 1e-6).astype(np.float16)
+    Lgu_plain = _packed(Lgu, dev)
+    g2, x_d = ops.chain_gemv(ops.rotate_parts(_t(xn, dev), Lgu_plain), Lgu_plain, next_pk=pd, act=nat.CHAIN_ACT_GELU_TANH_MUL)
+    y2, _ = ops.chain_gemv(x_d, pd)
+    assert po.rel_err(_np(y2), _ideal(Ld, po.gelu_tanh_mul(_np(g2), inter))) < TIGHT_F16

@@ -592,6 +592,8 @@ def test_gemm_bf16_native(dev, variant, K, sizes, rows):
 BASELINE_PREFILL = [
     ("qwen3-4b.gate_up", 2560, [9728, 9728]), ("qwen3-4b.down", 9728, [2560]),
     ("llama3-8b.o", 4096, [4096]), ("llama3-8b.qkv", 4096, [4096, 1024, 1024]),
+    # Qwen3.5 (transformers default "9B style" text config): gated-delta-net in_proj_qkv | in_proj_z, gated full-attention q | k | v
+    ("qwen3.5.in_proj_qkvz", 4096, [8192, 4096]), ("qwen3.5.qkv_gated", 4096, [8192, 1024, 1024]),
 ]
 
 
