@@ -26,10 +26,11 @@ timeout 400 python bench.py --workload llama3-70b --layers 8 --per-shape --no-cp
 tail -1 $OUT/bench_l70.json > $P/${R}_bench_llama3-70b_8layers.jsonl; grep us_per_launch $OUT/bench_l70.err >> $P/${R}_bench_llama3-70b_8layers.jsonl
 # ---- batched decode: both routes
 rm -f $P/${R}_rows_bench.jsonl
-for wl in qwen3-4b llama3-8b; do
+for spec in "qwen3-4b:" "llama3-8b:--layers 8"; do
+  wl=${spec%%:*}; la=${spec#*:}
   for rows in 2 4 8 16; do
     for route in chain fused; do
-      timeout 300 python bench.py --workload $wl --rows $rows --route $route --steps 20 --warmup 3 --no-cpu-baseline --no-e2e 2>> $OUT/rows.err | tail -1 >> $P/${R}_rows_bench.jsonl
+      timeout 300 python bench.py --workload $wl $la --rows $rows --route $route --steps 20 --warmup 3 --no-cpu-baseline --no-e2e 2>> $OUT/rows.err | tail -1 >> $P/${R}_rows_bench.jsonl
     done
   done
 done
