@@ -255,7 +255,7 @@ int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int6
  * `variant` selects the kernel: 0 = auto (by rows / grid size / dtype);
  *   1 = 128x128 tile, 4 waves, per-group scale epilogue (f16 / bf16; the small-M fallback);
  *   2 = 256x128 tile, 4 waves, 16x16x32 MFMA, exact fp16 weights in registers (f16 only; K-split at small M);
- *   3 = 256x256 tile, 8 waves as 2 x 4, 16x16x32 MFMA (f16 only);
+ *   (3 = the round-1 256x256 kernel: removed in v11, the value is refused);
  *   4 = 256x256 tile, 8 waves as 1 x 8 (every wave owns 32 distinct columns over all 256 rows: each INT4
  *       word is dequantised exactly once per workgroup), 32x32x16 MFMA, f16 and native bf16.
  * Every variant computes the same function; tests force each one at small sizes through this knob. */

@@ -139,9 +139,10 @@ extern "C" int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t*
   a.N = (int)L->N;
   a.dbg = (unsigned long long*)g_chain_dbg;
   typedef int (*launch_fn)(const ChainArgs&, int, bool, dim3, hipStream_t);
-  static const launch_fn table[2][3] = {{launch_chain_f16_m1, launch_chain_f16_m4, launch_chain_f16_m16},
-                                        {launch_chain_bf16_m1, launch_chain_bf16_m4, launch_chain_bf16_m16}};
-  const launch_fn fn = table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][rows <= 1 ? 0 : (rows <= 4 ? 1 : 2)];
+  // row classes 1 / <= 4 / <= 8 / <= 16: one, one, two, four accumulator registers per tile
+  static const launch_fn table[2][4] = {{launch_chain_f16_m1, launch_chain_f16_m4, launch_chain_f16_m8, launch_chain_f16_m16},
+                                        {launch_chain_bf16_m1, launch_chain_bf16_m4, launch_chain_bf16_m8, launch_chain_bf16_m16}};
+  const launch_fn fn = table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][rows <= 1 ? 0 : (rows <= 4 ? 1 : (rows <= 8 ? 2 : 3))];
   hipStream_t st = (hipStream_t)stream;
   for (;;) {
     const int gps = (G + ks - 1) / ks;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
   constexpr int NH = PAIR ? 2 : 1;                      // column blocks per workgroup
   constexpr int HW = WAVES / NH;                        // waves per column block
   constexpr int EIT = (MB * 128 + THREADS - 1) / THREADS;   // outputs per thread and block
-  constexpr int RR = MB < 4 ? MB : 4;                   // rows per rotation task
+  constexpr int RR = MB < 2 ? MB : 2;                   // rows per rotation task: two chains interleave well, more rows per task only lengthen its stage chain (tasks are dealt to the waves)
   constexpr int RED_FLOATS = WAVES * 8 * MR * 64;
   constexpr int Z_FLOATS = MB * 128;
   constexpr int XS_HALVES = WAVES * RR * 128;
@@ -609,6 +609,7 @@ int chain_launch_mb(const ChainArgs& a, int waves, bool pair, dim3 grid, hipStre
 #define PARO_DECL_CHAIN(T) \
   int launch_chain_##T##_m1(const ChainArgs&, int, bool, dim3, hipStream_t); \
   int launch_chain_##T##_m4(const ChainArgs&, int, bool, dim3, hipStream_t); \
+  int launch_chain_##T##_m8(const ChainArgs&, int, bool, dim3, hipStream_t); \
   int launch_chain_##T##_m16(const ChainArgs&, int, bool, dim3, hipStream_t);
 PARO_DECL_CHAIN(f16)
 PARO_DECL_CHAIN(bf16)

@@ -1,5 +1,5 @@
 // One translation unit per (activation type, row class) of the decode-chain GEMV (chain_impl.hpp), built in parallel:
-//   -DPARO_CHAIN_AT=f16|bf16 -DPARO_CHAIN_MB=1|4|16 -DPARO_CHAIN_NAME=launch_chain_<type>_m<rows>
+//   -DPARO_CHAIN_AT=f16|bf16 -DPARO_CHAIN_MB=1|4|8|16 -DPARO_CHAIN_NAME=launch_chain_<type>_m<rows>
 #include "chain_impl.hpp"
 
 namespace paro {

@@ -4,12 +4,12 @@
 //   1. rotate pre-pass (rotate.hip) writes the rotated activations once per merged partition into the
 //      caller's workspace  xrot[p][rows][K]  (the reference re-launches `rotate` per partition too --
 //      vllm/plugin.py:288-290 -- and then hands fp16 x to a separate Marlin GEMM);
-//   2. one of four GEMM kernels (the `variant` knob of the ABI; 0 = auto):
+//   2. one of three GEMM kernels (the `variant` knob of the ABI; 0 = auto):
 //        1  gemm_kernel<T>          128 x 128 tile, 4 waves, register-staged A, per-group scale epilogue
 //                                   (f16 / bf16; what bf16 runs below 256 rows)
 //        2  gemm2_f16_kernel<2>     256 x 128 tile, 4 waves (2 x 2), A by LDS-DMA, exact fp16 weights in
 //                                   registers, optional K-split over grid.z for small M
-//        3  gemm2_f16_kernel<4>     256 x 256 tile, 8 waves (2 x 4)            -- the round-1 prefill kernel
+//        (3, the round-1 256 x 256 kernel with 2 x 4 waves, was kept for A/B in round 2 and removed in ABI v11)
 //        4  gemm3_kernel<T>         256 x 256 tile, 8 waves (1 x 8), 32x32x16 MFMA (gemm3.hip), f16 / bf16
 //      In all of them the INT4 B tiles are NOT staged through LDS: a lane's 16-byte load of the packed
 //      tile (paro_repack_awq) is its MFMA operand after the in-register dequant.
@@ -444,17 +444,17 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     diag = variant - 40;
     variant = 4;
   }
-  if (variant < 0 || variant > 4) return fail(PARO_ERR_INVALID, "variant must be 0 (auto) or 1..4 (got %d)", variant);
+  if (variant < 0 || variant > 4 || variant == 3)
+    return fail(PARO_ERR_INVALID, "variant must be 0 (auto), 1, 2 or 4 (got %d; 3 -- the round-1 256 x 256 kernel -- was removed in ABI v11)", variant);
   const bool f16in = L->act_dtype == PARO_DTYPE_F16;
-  if ((variant == 2 || variant == 3) && !f16in)
-    return fail(PARO_ERR_UNSUPPORTED, "GEMM variants 2 and 3 are fp16-only; bf16 runs variant 1 or 4");
+  if (variant == 2 && !f16in) return fail(PARO_ERR_UNSUPPORTED, "GEMM variant 2 is fp16-only; bf16 runs variant 1 or 4");
   // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) for 33..192 rows (64- .. 192-row
   // blocks) and when there are >= 256 rows and enough 256 x 256 tiles to cover the CUs; fp16 below that -> 256 x 128 tile with a K-split at small M;
   // bf16 below that -> the 128 x 128 kernel.
   const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
   const int qs = 128 / quant_group(L->group_size);
-  if (qs == 2 && (variant == 2 || variant == 3))
-    return fail(PARO_ERR_UNSUPPORTED, "group_size 64 runs GEMM variant 1 or 4 (variants 2 and 3 are built for group_size 128)");
+  if (qs == 2 && variant == 2)
+    return fail(PARO_ERR_UNSUPPORTED, "group_size 64 runs GEMM variant 1 or 4 (variant 2 is built for group_size 128)");
   int v = variant;
   if (v == PARO_GEMM_AUTO) {
     // 33..192 rows (batched decode, short prefill): variant 4 with 64- .. 192-row blocks (32-row steps) and a K-split -- 256-column
@@ -491,7 +491,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.rows = (int)rows;
   a.tstride = L->wq_order ? 1 : a.G;
   a.gstride = L->wq_order ? (int)(L->N / 16) : 1;
-  const bool wide = v == 3 || v == 4;
+  const bool wide = v == 4;
   if (!fill_part_table(a.pt, L->n_parts, L->part_cols, wide ? 16 : BN_TILES)) return fail(PARO_ERR_INVALID, "bad partition table");
   const int bm = v == 1 ? BM : (v == 4 ? 32 * rt4 : BM2);
   const int64_t rb = (rows + bm - 1) / bm;
@@ -516,8 +516,6 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
       else
         hipLaunchKernelGGL(gemm_reduce_kernel<bf16>, rg, dim3(256), 0, st, a.partial, (const unsigned short*)L->bias, (unsigned short*)y, rows, (int)L->N, a.ksplit);
     }
-  } else if (v == 3) {
-    hipLaunchKernelGGL(gemm2_f16_kernel<4>, grid, dim3(512), 0, st, a);
   } else if (v == 2) {
     hipLaunchKernelGGL(gemm2_f16_kernel<2>, grid, dim3(256), 0, st, a);
     if (a.ksplit > 1) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prefill-path microbench: fused linear at large M (rotate pre-pass + W4A16 MFMA GEMM), TFLOP/s = 2*M*K*N / time.
 
-    python tools/bench_gemm.py [--model llama3-8b] [--rows 2048,8192,65536] [--variants 0,3,4] [--dtype f16] [--rounds 3]
+    python tools/bench_gemm.py [--model llama3-8b] [--rows 2048,8192,65536] [--variants 0,2,4] [--dtype f16] [--rounds 3]
 
 Variants (include/paro_abi.h) are timed INTERLEAVED in one process, `rounds` rounds of `reps` calls each, and the
 median + min are reported (cdna guide rule 24: perf deltas come from within-probe interleaved rounds).
