@@ -214,11 +214,38 @@ class DecodeStack:
         # route: "fused" = one paro_w4a16_gemv per linear (rotation inside the consuming kernel); "chain" = the decode-chain
         # family (activations handed over rotated: the consumer's rotation runs in the producer's epilogue, csrc/chain_impl.hpp).
         # Measured (profiles/r03_chain_rows_sweep.jsonl): one row -> fused, 2..16 rows -> chain.
+        # "parts" (one row, one GPU) = "fused" with the deferred K-split reduction (include/paro_abi.h v12): a K-split linear whose output is
+        # the next linear's whole input (o_proj -> gate_up, down_proj -> the next qkv) leaves its fp32 partial sums and the consumer adds them
+        # while it seeds its rotation (in a decoder: to the residual stream, paroquant_amd/decoder.py).  Measured
+        # (profiles/r03_parts_micro.jsonl): the in-launch hand-off is 1.3 .. 1.45 us of the producer's launch, completing the sums costs
+        # the consumer 0.6 .. 0.8 us (every workgroup reads the four fp32 slots of every channel).
         if route == "auto":
-            route = "chain" if (rows > 1 and tp == 1) else "fused"
-        if route == "chain" and tp != 1:
-            raise SystemExit("the chain route is single-GPU")
+            route = "chain" if (rows > 1 and tp == 1) else "fused"    # (parts: -1.5 % .. +8 % per step on these stacks -- reported next to it, config.route_ab)
+        if route in ("chain", "parts") and tp != 1:
+            raise SystemExit(f"the {route} route is single-GPU")
+        if route == "parts" and rows != 1:
+            raise SystemExit("the parts route is batch-1")
         self.route = route
+        if route == "parts" or (route == "fused" and rows == 1 and tp == 1):     # (the fused stack can also run the parts route: the A/B leg)
+            flat = [pk for lay in self.layers for pk in lay]
+            self._flat = flat
+            # producer i hands partial sums to consumer i + 1 when it K-splits on its own, its output is the consumer's whole input and
+            # the consumer does not itself produce for its successor
+            self._nparts = [0] * len(flat)
+            for i in range(len(flat) - 1):
+                n = ops.gemv_parts_count(flat[i])
+                is_consumer = i > 0 and self._nparts[i - 1] > 0
+                if n >= 2 and len(flat[i].partition_sizes) == 1 and flat[i].N == flat[i + 1].K == self.hidden and not is_consumer:
+                    self._nparts[i] = n
+            n_last = ops.gemv_parts_count(flat[-1])
+            if n_last >= 2 and flat[-1].N == self.hidden and len(flat) > 1 and self._nparts[-2] == 0:
+                self._nparts[-1] = n_last                       # completed by paro_parts_finish (in a decoder: in front of the final norm)
+            self._parts = [torch.zeros(self.hidden, 4, device=dev, dtype=torch.float32) for _ in range(2)]
+            self._stream = torch.zeros(1, self.hidden, device=dev, dtype=torch.float16)
+            self._zeros = torch.zeros(1, self.hidden, device=dev, dtype=torch.float16)
+            self._y = {pk.N: torch.empty(1, pk.N, device=dev, dtype=torch.float16) for pk in flat}
+            if route == "parts":
+                self.launches_per_step += 1 if self._nparts[-1] else 0
         if route == "chain":
             self.launches_per_step += 1        # the head's rotate_parts
             flat = [pk for lay in self.layers for pk in lay]
@@ -234,6 +261,8 @@ class DecodeStack:
     def step(self, x: torch.Tensor) -> torch.Tensor:
         if self.route == "chain":
             return self._step_chain(x)
+        if self.route == "parts":
+            return self._step_parts(x)
         h = x
         tp = self.tp
         if tp == 1:
@@ -254,6 +283,26 @@ class DecodeStack:
             else:
                 h = self.allreduce(down.apply(d))
         return h
+
+    def _step_parts(self, x: torch.Tensor) -> torch.Tensor:
+        """The same chain of linears as the fused route (each consumes the first K columns of its predecessor's output), with the K-split
+        reduction of the narrow linears deferred into their consumer: base = zeros, so x' = sum of the partial sums, rounded once --
+        bit for bit what the in-launch reducer writes (tests/test_gpu_parts.py), hence the same activations all the way down."""
+        ops, flat = self.ops, self._flat
+        cur, pend, k = x, None, 0
+        for i, pk in enumerate(flat):
+            if pend is not None:               # consumer of the predecessor's partial sums
+                cur = ops.w4a16_gemv_fused(self._zeros, pk, 0, parts_in=pend, out=self._y[pk.N])
+                pend = None
+            elif self._nparts[i]:
+                pend = self._parts[k]
+                k ^= 1
+                ops.w4a16_gemv_fused(cur[:, : pk.K], pk, 0, parts_out=pend, parts_n=self._nparts[i])
+            else:
+                cur = pk.apply(cur[:, : pk.K])
+        if pend is not None:
+            cur = ops.parts_finish(pend, out=self._stream.view(-1)).view(1, -1)
+        return cur
 
     def _step_chain(self, x: torch.Tensor) -> torch.Tensor:
         ops, flat = self.ops, self._flat
@@ -412,7 +461,8 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     return {"value": round(tps, 1), "unit": "tokens/s", "ms_per_token": round(ms, 4),
             "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
             "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
-            "launches_per_token": (5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3,
+            "launches_per_token": (5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3 + (1 if lm.deferred else 0),
+            "deferred_ksplit_reduction": bool(lm.deferred),   # o / down leave partial sums, gate_up / the next qkv complete them (decoder.py)
             "parallelism": f"tp{tp_world}" + (" (bytes_per_token and GBps are per rank)" if tp_world > 1 else ""),
             "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),
             "GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),
@@ -463,10 +513,12 @@ def parse_args(argv=None):
     ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
     ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16)")
-    ap.add_argument("--route", default="auto", choices=["auto", "fused", "chain"],
+    ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain"],
                     help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
-                         "launch (decode-chain family); auto = fused at one row, chain at 2..16 (measured: profiles/r03_chain_rows_sweep.jsonl)")
+                         "launch (decode-chain family); parts = fused with the deferred K-split reduction of o / down (one row, one GPU); "
+                         "auto = fused at one row, chain at 2..16 rows (measured: profiles/r03_chain_rows_sweep.jsonl, r03_parts_bench.jsonl)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-route-ab", action="store_true", help="skip the second one-row leg (the other of fused / parts) that `config.route_ab` reports")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end decode leg (fused harness: attention, norms, lm_head)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -630,6 +682,25 @@ def run(args, rank: int, local_rank: int, world: int):
             if args.tp_backend == "gloo":
                 args.no_graph = True
             wall, ev_ms, use_graph = measure()
+    # one row, one GPU: the same stack through the other one-row route as well (in-launch K-split reducer vs deferred reduction)
+    route_ab = None
+    if stack.route in ("parts", "fused") and not tp_mode and args.rows == 1 and not args.no_route_ab:
+        route_ab = {stack.route: {"ms_per_step": round(wall * 1e3 / args.steps, 4)}}
+        other = "fused" if stack.route == "parts" else "parts"
+        try:
+            mine = stack.route
+            if other == "parts" and not hasattr(stack, "_nparts"):
+                raise RuntimeError("stack was not built for the parts route")
+            y_mine = stack.step(stack.x).clone()
+            stack.route = other
+            y_other = stack.step(stack.x).clone()
+            w2, _, _ = measure()
+            route_ab[other] = {"ms_per_step": round(w2 * 1e3 / args.steps, 4)}
+            route_ab["outputs_identical"] = bool(torch.equal(y_mine, y_other))    # same chain, same bits (the deferred sum keeps the reducer's order)
+        except Exception as e:
+            route_ab[other] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            stack.route = mine
     # TP runs report BOTH collectives: the one-shot xGMI kernel (when it came up and passed its self-test)
     # and the backend's all-reduce (RCCL), timed on the same shards; the headline is the faster leg that is healthy.
     allreduce_ab = None
@@ -666,7 +737,7 @@ def run(args, rank: int, local_rank: int, world: int):
     achieved = bytes_per_launch / us_per_launch / 1e3      # GB/s, per rank
     traffic = None   # HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, summaries under profiles/)
     pmc_file, pmc_reason = newest_pmc_file(model, args.pmc_file)
-    if pmc_file and not tp_mode and stack.n_layers == n_layers_of(model) and args.rows == 1 and stack.route == "fused":
+    if pmc_file and not tp_mode and stack.n_layers == n_layers_of(model) and args.rows == 1 and stack.route in ("fused", "parts"):
         with open(pmc_file) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
     elif pmc_file:
@@ -695,7 +766,7 @@ def run(args, rank: int, local_rank: int, world: int):
                    "bytes_per_token": stack.bytes_per_step * (tp if tp_mode else 1),
                    "parallelism": ("tp%d" % tp) if tp_mode else ("dp%d" % world),
                    "collective_backend": (args.tp_backend if world > 1 and tp_mode else None),
-                   "allreduce": allreduce_name, "allreduce_ab": allreduce_ab},
+                   "allreduce": allreduce_name, "allreduce_ab": allreduce_ab, "route_ab": route_ab},
         "roofline": roofline,
     }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 11
+#define PARO_ABI_VERSION 12
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -208,7 +208,23 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
  *            ar_max_elems >= N) and sum them in rank order -- one rounding, bit-identical on every rank, no separate
  *            all-reduce launch.  One row, not with the RMSNorm prologue (a norm over a K shard is not the layer's norm)
  *            nor with expert slots.  Every rank must issue the same sequence of such launches on its buffer.
+ *   deferred K-split reduction (v12)  The narrow, deep linears of a decoder layer (o_proj, down_proj) are K-split, and the
+ *            in-launch hand-off of the partial sums (write-through granules, a polling reducer) is 1.0 .. 1.4 us of a 5 .. 8 us
+ *            launch (profiles/r03_ab_nopoll.txt, r03_parts_micro.jsonl).  With parts_out the splits just leave their fp32 partial sums
+ *                parts_out[col][slot]   fp32 [N][PARO_MAX_PARTIALS]: slot 0 = the LAST split, slot q = split q - 1, the rest zero
+ *            (y is not written and may be NULL; no bias, no residual) and exit; the NEXT launch (the RMSNorm-prologue linear of
+ *            the following block: gate_up after o_proj, the next layer's qkv after down_proj) takes parts_in = that array and
+ *            x = the residual stream BEFORE the producer's output, and completes, while it seeds its rotation,
+ *                x'[k] = round(x[k] + (((parts[k][0] + parts[k][1]) + parts[k][2]) + parts[k][3]))
+ *            -- the summation order and the single rounding of the in-launch reducer, so both routes give the same bits.
+ *            x_out (optional, must not alias x) receives x' (the new residual stream; written by one workgroup).
+ *            One row; in-kernel rotation; the consumer's prologue is NONE or RMSNORM and it does not K-split.
+ *            parts_out_n: paro_gemv_parts_count(L) (the split the automatic launch shape uses; 0 = this layer does not
+ *            split, use the ordinary route), or any 2..PARO_MAX_PARTIALS that K / 128 can be cut into.
+ *            paro_parts_finish completes the sum without a linear behind it (the last layer's down_proj in front of the
+ *            final norm): out[k] = round(x[k] + sum) in the same order; x may be NULL.
  * rows <= 4, krot <= 8 (in-kernel rotation); the launch shape is chosen automatically. */
+#define PARO_MAX_PARTIALS 4
 #define PARO_PROLOGUE_NONE 0
 #define PARO_PROLOGUE_RMSNORM 1
 #define PARO_PROLOGUE_SILU_MUL 2
@@ -226,7 +242,13 @@ typedef struct paro_fusion {
                                   never touched by the caller afterwards: give-up flag + one epoch per 16-column tile */
   int32_t ar_world, ar_rank;
   int64_t ar_max_elems;        /* the element count the buffers were sized with */
+  float* parts_out;            /* v12: fp32 [N][PARO_MAX_PARTIALS], or NULL */
+  const float* parts_in;       /* v12: fp32 [K][PARO_MAX_PARTIALS] left by the producer of x's missing term, or NULL */
+  void* x_out;                 /* v12: act_dtype [K], the completed x (with parts_in), or NULL */
+  int32_t parts_out_n;         /* v12: the K-split of the parts_out launch */
 } paro_fusion_t;
+int paro_gemv_parts_count(const paro_linear_t* L);
+int paro_parts_finish(const void* x, const float* parts, int64_t K, void* out, int act_dtype, void* stream);
 int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                           int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream);
 

@@ -14,11 +14,12 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 11
+PARO_ABI_VERSION = 12
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
 PARO_WS_STATUS_GIVEUP = 0xDEAD
+PARO_MAX_PARTIALS = 4
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
 # PARO_LIB_DIR: directory (relative to the package) of an experiment build of the library (A/B runs of kernel variants)
@@ -52,6 +53,8 @@ EXPORTS = (
     "paro_chain_launch_shape",
     "paro_w4a16_gemv_chain",
     "paro_rotate_parts",
+    "paro_gemv_parts_count",
+    "paro_parts_finish",
     "paro_allreduce_buffer_bytes",
     "paro_allreduce_buffer_create",
     "paro_allreduce_buffer_open",
@@ -90,7 +93,8 @@ class ParoFusion(Structure):
     """``paro_fusion_t`` (include/paro_abi.h)."""
 
     _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p),
-                ("ar_peers", c_void_p), ("ar_own", c_void_p), ("ar_state", c_void_p), ("ar_world", c_int32), ("ar_rank", c_int32), ("ar_max_elems", c_int64)]
+                ("ar_peers", c_void_p), ("ar_own", c_void_p), ("ar_state", c_void_p), ("ar_world", c_int32), ("ar_rank", c_int32), ("ar_max_elems", c_int64),
+                ("parts_out", c_void_p), ("parts_in", c_void_p), ("x_out", c_void_p), ("parts_out_n", c_int32)]
 
 
 class ParoExperts(Structure):
@@ -194,6 +198,10 @@ def load() -> ctypes.CDLL:
                                           c_void_p]
     lib.paro_rotate_parts.restype = c_int
     lib.paro_rotate_parts.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p]
+    lib.paro_gemv_parts_count.restype = c_int
+    lib.paro_gemv_parts_count.argtypes = [POINTER(ParoLinearDesc)]
+    lib.paro_parts_finish.restype = c_int
+    lib.paro_parts_finish.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]
     lib.paro_allreduce_buffer_bytes.restype = c_int64
     lib.paro_allreduce_buffer_bytes.argtypes = [c_int, c_int64]
     lib.paro_allreduce_buffer_create.restype = c_int

@@ -203,10 +203,30 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
-  if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
+  const bool pout = F && F->parts_out;   // deferred K-split reduction (v12): this launch leaves / receives fp32 partial sums
+  const bool pin = F && F->parts_in;
+  if (!x || (!y && !pout)) return fail(PARO_ERR_INVALID, "null pointer");
   const bool ar = F && F->ar_peers && F->ar_world >= 1;
-  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar;
-  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar || pin;
+  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+  if (pout || pin) {
+    if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "partial sums (parts_out / parts_in) are a batch-1 decode path (got %lld rows)", (long long)rows);
+    if (E || ar) return fail(PARO_ERR_UNSUPPORTED, "partial sums are not defined for expert slots or the all-reduce epilogue");
+    if (L->krot > 8 || mode == 1 || mode == 2) return fail(PARO_ERR_UNSUPPORTED, "partial sums need the in-kernel rotation (krot <= 8, mode 0)");
+  }
+  if (pout) {
+    if (pin) return fail(PARO_ERR_UNSUPPORTED, "one launch cannot both receive and leave partial sums (the consumer's RMSNorm needs all of K per workgroup)");
+    if (F->parts_out_n < 2 || F->parts_out_n > PARO_MAX_PARTIALS) return fail(PARO_ERR_INVALID, "parts_out_n must be in 2..%d (got %d): a launch that does not split K writes y itself", PARO_MAX_PARTIALS, F->parts_out_n);
+    if (F->residual || L->bias) return fail(PARO_ERR_UNSUPPORTED, "parts_out: residual and bias are added where the partial sums are completed; this launch takes neither");
+    if (F->prologue == PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
+    if (ksplit != 0 && ksplit != F->parts_out_n) return fail(PARO_ERR_INVALID, "ksplit %d contradicts parts_out_n %d", ksplit, F->parts_out_n);
+  }
+  if (pin) {
+    if (F->prologue != PARO_PROLOGUE_NONE && F->prologue != PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_UNSUPPORTED, "parts_in feeds the plain or the RMSNorm prologue");
+    if (ksplit > 1) return fail(PARO_ERR_INVALID, "parts_in: every workgroup completes all of x, the launch does not K-split");
+    if (F->x_out == x) return fail(PARO_ERR_INVALID, "x_out must not alias x (other workgroups still read it)");
+    ksplit = 1;
+  }
   if (E) {
     if (!F) F = &no_fusion;
     if (!E->expert_idx || E->n_slots < 1 || E->n_slots > 65535) return fail(PARO_ERR_INVALID, "bad expert slot table");
@@ -241,6 +261,13 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
   rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
   if (rc != PARO_OK) return rc;
+  if (pout && ksp != F->parts_out_n) {
+    // the automatic shape splits K differently from what the caller sized its buffers for: the caller's count wins
+    tpw = tiles_per_wave; ksp = F->parts_out_n; wv = waves;
+    rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
+    if (rc != PARO_OK) return rc;
+    if (ksp != F->parts_out_n) return fail(PARO_ERR_INVALID, "parts_out_n = %d: K = %lld splits into %d non-empty slices", F->parts_out_n, (long long)L->K, ksp);
+  }
   if (fused) {
     if (tpw == 8 && wv == 16) wv = 8;
   }
@@ -273,6 +300,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.slabs = nullptr;
   a.counters = nullptr;
   a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
+  a.parts_out = pout ? 1 : 0;
+  a.parts_in = pin ? 1 : 0;
   const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue >= PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.expert_idx = E ? E->expert_idx : nullptr;
   a.wq_estride = E ? E->wq_stride_bytes : 0;
@@ -289,11 +318,11 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.ar_off = ar ? ar_region_b_off(F->ar_world, F->ar_max_elems) : 0;
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
   auto repack_hot = [&]() {
-    return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride);
+    return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride, pout);
   };
   if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 
-  const int64_t slab_bytes = a.ksplit > 1 ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
+  const int64_t slab_bytes = (a.ksplit > 1 && !pout) ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
   const int64_t need = PARO_WS_COUNTER_BYTES + slab_bytes + xrot_bytes;
   if (slab_bytes + xrot_bytes > 0) {
@@ -303,7 +332,12 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
-  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
+  if (pout) a.slabs = (unsigned long long*)F->parts_out;        // float [N][4]
+  if (pin) {
+    a.counters = (unsigned*)const_cast<float*>(F->parts_in);    // float [K][4]
+    a.slabs = (unsigned long long*)F->x_out;                    // the completed x [K], or null
+  }
+  if (a.pd == 31 && a.ksplit == 1 && !pin && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
   // mode 2: the caller hands over rotated activations, [n_parts][rows][K] in the activation type (whoever produced x
   // rotated it -- rotation::rotate per partition, or a producer kernel's epilogue): the pre-rotated kernels, no pre-pass
@@ -327,7 +361,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode >= 1 ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
   rc = fn(a, wv, grid, st);
-  if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1) {
+  if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1 && !pout) {
     // the automatic K-split does not fit this instantiation's real occupancy: run unsplit (always legal)
     a.ksplit = 1;
     gps = G;
@@ -356,4 +390,40 @@ extern "C" int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, vo
                                        void* stream) {
   if (!experts) return paro::fail(PARO_ERR_INVALID, "null expert descriptor");
   return paro::gemv_impl(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 0, fusion, experts, stream);
+}
+
+// ---- deferred K-split reduction: helpers (v12)
+namespace paro {
+template <typename AT>
+__global__ void parts_finish_kernel(const unsigned short* __restrict__ x, const float* __restrict__ parts, int64_t K,
+                                    unsigned short* __restrict__ out) {
+  typedef Act<AT> A;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const f32x4 p = ((const f32x4*)parts)[k];             // slots in the in-launch reducer's order (last split first), unused slots zero
+  float v = ((p[0] + p[1]) + p[2]) + p[3];
+  if (x) v += A::to_f32(x[k]);
+  out[k] = A::from_f32(v);
+}
+}  // namespace paro
+
+extern "C" int paro_gemv_parts_count(const paro_linear_t* L) {
+  using namespace paro;
+  if (validate_linear(L) != PARO_OK) return -1;
+  if (L->krot > 8 || L->bias) return 0;
+  int tpw = 0, ks = 0, wv = 0, mode = 0;
+  if (resolve_launch_shape(L, 1, tpw, ks, wv, mode) != PARO_OK) return -1;
+  return (ks >= 2 && ks <= PARO_MAX_PARTIALS) ? ks : 0;
+}
+
+extern "C" int paro_parts_finish(const void* x, const float* parts, int64_t K, void* out, int act_dtype, void* stream) {
+  using namespace paro;
+  if (!parts || !out || K < 1) return fail(PARO_ERR_INVALID, "paro_parts_finish: bad arguments");
+  if (act_dtype != PARO_DTYPE_F16 && act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  const dim3 grid((unsigned)((K + 255) / 256));
+  if (act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL(parts_finish_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, parts, K, (unsigned short*)out);
+  else
+    hipLaunchKernelGGL(parts_finish_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, parts, K, (unsigned short*)out);
+  return check_launch("paro_parts_finish");
 }

@@ -53,7 +53,7 @@ struct alignas(16) GemvHot {
   const unsigned short* cs;      // 6..7
   const unsigned short* x;       // 8..9   [rows][K], or pre-rotated [nparts][rows][K] when PREROT
   unsigned g_t;                  // 10     G = K / 128 | T = N / 16 << 16   (tile (t, g) = chunk t * G + g, or g * T + t when order)
-  unsigned meta;                 // 11     rows | krot << 8 | ksplit << 16 | skew << 24 | prio << 25 | prologue << 26 | experts << 28 | order << 29
+  unsigned meta;                 // 11     rows (7 bits) | parts_out << 7 | krot << 8 | ksplit << 16 | skew << 24 | prio << 25 | prologue << 26 | experts << 28 | order << 29
   unsigned gps_tsz;              // 12     groups per K-split | scale/zero tiles per group row << 16
   unsigned residual_lo, residual_hi;  // 13, 14 pointer to [rows][N] added to the output, or null (FUSED); two dwords: offset 52 is not pointer-aligned
   unsigned xstride;              // 15     elements between rows of x (SiLU*mul: x = [rows][2 K], gate then up)
@@ -68,8 +68,9 @@ struct GemvArgs {
   float eps;                     // RMSNorm epsilon (FUSED)
   const unsigned short* bias;
   unsigned short* y;
-  unsigned long long* slabs;     // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]
-  unsigned* counters;
+  unsigned long long* slabs;     // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]; parts_out launches: float [N][4] (the
+                                 // caller's partial sums, no hand-off); parts_in launches: the completed x [K] in the activation type, or null
+  unsigned* counters;            // K-split epoch words; parts_in launches: const float [K][4], the producer's partial sums
   // expert slots (FUSED instantiations only; paro_w4a16_gemv_experts): blockIdx.z = slot, the slot's expert id
   // is read from DEVICE memory; all experts share the rotation (cli/convert.py:280-379, mlx/modules.py:159-212)
   const int* expert_idx;         // [slots] or null
@@ -87,6 +88,7 @@ struct GemvArgs {
   long long ar_off;                 // byte offset of that region inside a buffer
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
+  int parts_out, parts_in;       // deferred K-split reduction (paro_fusion_t, v12): this launch writes / reads partial sums
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
@@ -94,11 +96,11 @@ static_assert(offsetof(GemvArgs, hot) == 0, "hot block at kernarg offset 0");
 
 // host: pack the hot block; false when a table entry does not fit 16 bits
 inline bool pack_hot(GemvHot& h, const PartTable& pt, int G, int order, int rows, int krot, int ksplit, int gps, int skew, int prio,
-                     int prologue, bool experts, long long xstride) {
-  if (pt.tiles >= 0xffff || pt.tsz >= 0xffff || gps > 0xffff || G > 0xffff || xstride < 0 || xstride > 0xffffffffll) return false;
+                     int prologue, bool experts, long long xstride, bool parts_out = false) {
+  if (rows > 127 || pt.tiles >= 0xffff || pt.tsz >= 0xffff || gps > 0xffff || G > 0xffff || xstride < 0 || xstride > 0xffffffffll) return false;
   h.g_t = (unsigned)G | ((unsigned)pt.tiles << 16);
   h.meta = (unsigned)rows | ((unsigned)krot << 8) | ((unsigned)ksplit << 16) | ((unsigned)(skew != 0) << 24) |
-           ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28) | ((unsigned)(order != 0) << 29);
+           ((unsigned)(prio != 0) << 25) | ((unsigned)prologue << 26) | ((unsigned)experts << 28) | ((unsigned)(order != 0) << 29) | ((unsigned)parts_out << 7);
   h.gps_tsz = (unsigned)gps | ((unsigned)pt.tsz << 16);
   h.xstride = (unsigned)xstride;
   for (int q = 1; q < PARO_MAX_PARTS; ++q) h.cbs[q - 1] = (q < pt.nparts) ? pt.cb_start[q] : 0x7fffffff;
@@ -127,12 +129,18 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 //                      gate_up projection's output [rows][2 K] (the MLX MoE path rotates the activation output the
 //                      same way before down_proj, mlx/modules.py:204-207).
 //   epilogue residual  y += residual[row][col] (the decoder's residual stream), in the final write.
+// FUSED | 8 (with FUSED & 3 == 1, one row): x arrives INCOMPLETE -- the K-split producer in front (o_proj, down_proj) left its
+//   `n` <= 4 fp32 partial sums [K][4] instead of reducing them in its launch, and this kernel finishes the sum while it seeds the
+//   rotation: x_k = round(base_k + ((p[n-1][k] + p[0][k]) + ... + p[n-2][k])) -- the order and the one rounding of the reducer
+//   below, so both routes give the same bits (the producer stores its splits in that order, four slots per channel, unused ones zero).  Column block 0 also stores the completed x (the decoder's residual stream).
 // QS: quantisation groups per 128-channel rotation span (1: group_size 128, 2: group_size 64 -- two (scale, zero)
 // words per tile and column, the tile's first two / last two MFMA k-steps accumulated separately).
 template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0, int QS = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int FMODE = FUSED & 3;          // 0 plain, 1 RMSNorm prologue and / or residual, 2 SiLU*mul prologue (+ residual)
   constexpr bool AREP = (FUSED & 4) != 0;   // + all-reduce epilogue (its own instantiations: the code costs the others ~5 % otherwise)
+  constexpr bool PARTS_IN = (FUSED & 8) != 0;   // x = base + the producer's partial sums, completed while seeding (see above)
+  static_assert(!PARTS_IN || (FMODE == 1 && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -169,10 +177,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   u32x16 k0;
   int p;
   unsigned p_cb0_u, ent0, ent1;
-  unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words), fetched with the same batch
+  unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words; PARTS_IN: the partial sums), fetched with the same batch
+  unsigned long long aux_ptr = 0;   // PARTS_IN: GemvArgs::slabs (where the completed x goes)
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned m0_save;
+    // (PARTS_IN: one more request in front of the batch below, whose wait covers it; its own statement so that the other
+    // instantiations' prologue is byte for byte what it was)
+    if constexpr (PARTS_IN) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(aux_ptr) : "s"(kp), "i"(offsetof(GemvArgs, slabs)) : "memory");
     asm volatile(
         "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
         "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     GP<unsigned short> cs;
     GP<unsigned short> x;
     GP<unsigned short> residual;
-    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts;
+    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts, parts_out;
     long long xstride;
   } h;
   {
@@ -225,7 +237,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     const int T = (int)(k0[10] >> 16);
     h.N = T * 16;
     const unsigned meta = k0[11];
-    h.rows = (int)(meta & 0xffu);
+    h.rows = (int)(meta & 0x7fu);
+    h.parts_out = (int)((meta >> 7) & 1u);
     h.krot = (int)((meta >> 8) & 0xffu);
     h.ksplit = (int)((meta >> 16) & 0xffu);
     h.skew = (int)((meta >> 24) & 1u);
@@ -240,6 +253,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.residual = (GP<unsigned short>)ptr(k0[13], k0[14]);
     h.xstride = (long long)k0[15];
   }
+  // PARTS_IN: where the completed x goes -- a buffer descriptor whose size is K halves in column block 0 (and when the caller
+  // wants it) and ZERO elsewhere: out-of-range buffer stores are dropped by the hardware, no branch around the store
+  __amdgpu_buffer_rsrc_t xout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)aux_ptr, 0, (PARTS_IN && cb == 0 && aux_ptr != 0) ? h.K * 2 : 0, 0x00020000);
   GP<u32x4> wq_p = h.wq;
   GP<unsigned> sz_p = h.sz;
   GP<unsigned short> x_p = h.x;
@@ -298,6 +314,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
     unsigned xu[FMODE == 2 ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
+    f32x4 xp[PARTS_IN ? 2 : 1];         // PARTS_IN: the producer's partial sums of the same two channels: [channel][slot], slots in summation order
+    int g;                              // PARTS_IN: the group (where the completed x is stored)
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
@@ -325,6 +343,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
             b.xa[rt * 4 + i] = *(GP<u32x4>)(xrot_p + (unsigned)(row * h.K + g * 128 + 32 * i + 8 * mq));
         }
     } else {
+      if constexpr (PARTS_IN) {
+        // [K][4] fp32: the four slots of a channel are one 16-byte load, already in the reducer's summation order (slot 0 = the LAST
+        // split, slot q = split q - 1), unused slots zero -- the producer's epilogue below arranges both
+        b.g = g;
+        GP<f32x4> pp = (GP<f32x4>)cnt_ptr + (unsigned)(g * 128 + 2 * lane);
+        b.xp[0] = pp[0];
+        b.xp[1] = pp[1];
+      }
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
       GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
 #pragma unroll
@@ -348,7 +374,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // readable word when the launch is not split), so it is waited for with the first coefficients, costs no round trip of its
   // own and keeps the scalar-memory counter out of the rotation's cross-lane waits (a scalar load here sat in front of
   // every ds_bpermute wait of the first unit: o_proj 4.82 -> 5.02 us)
-  const unsigned ep_raw = *(GP<unsigned>)((h.ksplit > 1 ? (GP<unsigned>)cnt_ptr : (GP<unsigned>)h.cs) + (h.ksplit > 1 ? (unsigned)cb : 0u));
+  const bool ks_handoff = h.ksplit > 1 && !h.parts_out;   // this launch reduces its K-splits itself (granules + epochs)
+  const unsigned ep_raw = *(GP<unsigned>)((ks_handoff ? (GP<unsigned>)cnt_ptr : (GP<unsigned>)h.cs) + (ks_handoff ? (unsigned)cb : 0u));
   PBuf pc_first;
   if (h.prio) __builtin_amdgcn_s_setprio(3);
   load_p(pc_first, gf_first);
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // re-armed and a late or stale granule -- or whatever another kernel left in the granule area -- is never consumed.
   // (Shared with the chain family, chain_impl.hpp: same words, same tag format.)
   unsigned ks_tag = 0;
-  if (h.ksplit > 1) {
+  if (ks_handoff) {
     unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)ep_raw) + 1u;
     if ((e & 0xfffffu) == 0u) e += 1u;   // tag 0 is "never written"
     ks_tag = (e << 12) | ((unsigned)cb & 0xfffu);
@@ -463,6 +490,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int r = 0; r < MB; ++r) {
       const unsigned xv = r < h.rows ? b.xv[r] : 0u;
       float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
+      if constexpr (PARTS_IN) {
+        // no branch in here (a branch makes the compiler's vmcnt bookkeeping give up: the wait for these coefficients became a wait
+        // for the unit's HBM tiles, +1.0 .. 1.6 us per launch): unused slots hold zeros, and only column block 0's buffer
+        // descriptor has a non-zero size, so every other workgroup's store is dropped
+        const float v0 = ((b.xp[0][0] + b.xp[0][1]) + b.xp[0][2]) + b.xp[0][3];
+        const float v1 = ((b.xp[1][0] + b.xp[1][1]) + b.xp[1][2]) + b.xp[1][3];
+        const unsigned h0 = A::from_f32(v0 + x0), h1 = A::from_f32(v1 + x1);   // the reducer's `v += residual`, one rounding
+        x0 = A::to_f32(h0);
+        x1 = A::to_f32(h1);
+        __builtin_amdgcn_raw_buffer_store_b32(h0 | (h1 << 16), xout_rsrc, (unsigned)(b.g * 256 + 4 * lane), 0, 0);
+      }
       if constexpr (FMODE == 2) {
         {
           const unsigned uv = r < h.rows ? b.xu[r] : 0u;
@@ -831,6 +869,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         }
         y_p[(int64_t)b * h.N + col] = A::from_f32(v);
       }
+    } else if (h.parts_out) {
+      // deferred reduction (one row, K-split launches): every split leaves its fp32 partial sum and exits -- no granule, no poll;
+      // the CONSUMER launch adds the partials while it seeds its rotation (FUSED | 8 above)
+      // Layout [N][4]: slot 0 = the last split, slot q = split q - 1 (the order in which the in-launch reducer adds them), the
+      // last split also zeroes the slots beyond the split count -- the consumer adds four slots, no count, no mask.
+      if constexpr (!AREP) {
+        float* pc = (float*)a.slabs + (int64_t)col * 4;
+        const bool last = ks == h.ksplit - 1;
+        pc[last ? 0 : ks + 1] = v;
+        if (last) for (int q = h.ksplit; q < 4; ++q) pc[q] = 0.f;
+      }
     } else if (ks != h.ksplit - 1) {
       // producer: ONE 8-byte {tag, fp32 partial} granule per output, written through (sc1); no
       // drain, no flag, no fence -- the data IS the flag (cdna guide G16 recipe R2); then exit.
@@ -894,7 +943,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if ((col & 15) == 0) ar_st[kArStateTiles + (col >> 4)] = ep;
     }
   }
-  if (h.ksplit > 1 && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
+  if (ks_handoff && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
   if constexpr (DIAG == 3) {
     ts[6] = __builtin_amdgcn_s_memtime();
     // 80 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], stages done [10], then
@@ -930,7 +979,7 @@ constexpr int PARO_ERR_NOT_RESIDENT = -100;   // internal: mapped to PARO_ERR_UN
 int device_cu_count();
 template <auto Kern, int THREADS>
 int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !a.parts_out) {   // (partial sums left to the consumer: nobody waits inside the launch)
     static int per_cu = -1;
     if (per_cu < 0) {
       int v = 0;
@@ -972,6 +1021,10 @@ int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) 
     }
     return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is built for one row");
   }
+  if (a.parts_in) {   // x = base + the producer's partial sums (FUSED | 8): one row, RMSNorm or no prologue
+    if constexpr (MB == 1 && !PREROT) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 9>(a, waves, grid, st);
+    return fail(PARO_ERR_UNSUPPORTED, "partial sums as input are built for one row, in-kernel rotation");
+  }
   if (a.prologue == PARO_PROLOGUE_SILU_MUL || a.prologue == PARO_PROLOGUE_GELU_TANH_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);
   return launch_waves_fused_mode<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
@@ -1008,7 +1061,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine || a.parts_in) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

@@ -15,6 +15,13 @@ Here a Llama / Qwen3-style decoder layer is FIVE launches, all captured with the
     gate_up  fused GEMV, RMSNorm prologue (post_attention_layernorm folded)
     down     fused GEMV, SiLU(gate) * up prologue, residual epilogue
 
+On one GPU the K-split reduction of o and down is DEFERRED (include/paro_abi.h v12, ``_layers_deferred``): their K-slices leave
+fp32 partial sums and exit -- no in-launch hand-off (1.3 .. 1.45 us per launch) --, and the RMSNorm-prologue launch behind them
+(gate_up; the next layer's qkv) adds them to the residual stream while it seeds its rotation and writes the new stream (0.6 .. 0.8 us:
+every workgroup reads the four fp32 slots of every channel).  Same launches, same bits (tests/test_gpu_parts.py,
+tests/test_gpu_parity.py::test_decoder_harness_deferred_matches_reducer); Qwen3-4B 691 -> 710 tokens/s, Llama-3-8B 614 -> 625
+(profiles/r03_e2e.jsonl vs r03_e2e_reducer.jsonl).  ``PARO_DEFERRED_KSPLIT=0`` keeps the in-launch reducer.
+
 Embedding lookup, final norm, the (unquantised, fp16) lm_head and the greedy argmax are plain torch ops inside the
 same graph; the token and position live in device tensors, so a replay is one whole token with no host round trip.
 Prefill runs the same weights through ``PackedParoWeights.apply`` (MFMA GEMM) with torch attention.
@@ -300,6 +307,14 @@ class ParoDecoderLM:
         self.attn_buf = torch.zeros(1, self.nh * c.head_dim, dtype=dt, device=dev)
         self.gu_buf = torch.zeros(1, 2 * self.inter_l, dtype=dt, device=dev)
         self.part = torch.zeros(1, c.hidden, dtype=dt, device=dev)     # this rank's partial sum of a row-parallel linear (TP)
+        # deferred K-split reduction of o / down (one GPU, every layer's o and down K-split by the automatic launch shape and carry
+        # no bias; PARO_DEFERRED_KSPLIT=0 keeps the in-launch reducer)
+        n_o = min(ops.gemv_parts_count(L.o, dt) for L in self.layers)
+        n_d = min(ops.gemv_parts_count(L.down, dt) for L in self.layers)
+        self.deferred = self.tp_world == 1 and n_o >= 2 and n_d >= 2 and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0"
+        if self.deferred:
+            self.parts_o = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
+            self.parts_d = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
@@ -321,7 +336,9 @@ class ParoDecoderLM:
         R, S = nat.PROLOGUE_RMSNORM, nat.PROLOGUE_SILU_MUL
         torch.index_select(self.embed, 0, self.tok, out=self.h)
         h, h2 = self.h, self.h2
-        for L in self.layers:
+        if self.deferred:
+            h = self._layers_deferred()
+        for L in (() if self.deferred else self.layers):
             ops.w4a16_gemv_fused(h, L.qkv, R, c.rms_eps, out=self.qkv_buf)
             ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv, c.head_dim,
                             L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws)
@@ -347,6 +364,32 @@ class ParoDecoderLM:
             self.out_tokens.index_copy_(0, self.pos.long(), self.tok)
             torch.argmax(self.logits, dim=-1, out=self.tok)
             self.pos.add_(1)
+
+    def _layers_deferred(self) -> torch.Tensor:
+        """The decoder layers with the deferred K-split reduction (include/paro_abi.h v12; one GPU): o_proj and down_proj leave
+        their fp32 partial sums (no in-launch hand-off, ~1 us each); the RMSNorm-prologue launch behind them -- gate_up, the NEXT
+        layer's qkv -- adds them to the residual stream while it seeds its rotation and writes the new stream.  Same launches per
+        layer, same bits as the ordinary route (the reducer's summation order and single rounding); one small completion launch
+        in front of the final norm.  Returns the buffer that holds the final residual stream."""
+        c = self.cfg
+        R, S = nat.PROLOGUE_RMSNORM, nat.PROLOGUE_SILU_MUL
+        cur, other = self.h, self.h2
+        pend = None
+        for L in self.layers:
+            if pend is None:
+                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, out=self.qkv_buf)
+            else:
+                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, out=self.qkv_buf, parts_in=pend, x_out=other.view(-1))
+                cur, other = other, cur
+            ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv, c.head_dim,
+                            L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws)
+            ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, parts_out=self.parts_o)
+            ops.w4a16_gemv_fused(cur, L.gate_up, R, c.rms_eps, out=self.gu_buf, parts_in=self.parts_o, x_out=other.view(-1))
+            cur, other = other, cur
+            ops.w4a16_gemv_fused(self.gu_buf, L.down, S, parts_out=self.parts_d)
+            pend = self.parts_d
+        ops.parts_finish(pend, cur.view(-1), out=other.view(-1))
+        return other
 
     def _final_norm(self, h: torch.Tensor) -> torch.Tensor:
         x = h.float()

@@ -316,14 +316,23 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
 
 
 def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, allreduce=None,
+                     parts_out: Optional[torch.Tensor] = None, parts_in: Optional[torch.Tensor] = None,
+                     x_out: Optional[torch.Tensor] = None, parts_n: int = 0) -> torch.Tensor:
     """Decode-layer fusions around one fused linear (``paro_w4a16_gemv_fused``; rows <= 4):
     ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
     ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
     gate_up output ``[rows, 2 K]`` and the linear consumes ``silu(gate) * up``; ``residual [rows, N]`` is added to
     the output (nat.PROLOGUE_GELU_TANH_MUL: ``gelu_tanh(gate) * up``, the Gemma MLP).  ``out`` may be given (e.g. a static buffer of a captured decode step).  ``allreduce`` (a
     ``paroquant_amd.tp.OneShotAllReduce``): ``pk`` is a row-parallel shard and the output becomes the sum over the ranks
-    (+ bias + residual, once), exchanged inside this launch -- one row, every rank issuing the same launches."""
+    (+ bias + residual, once), exchanged inside this launch -- one row, every rank issuing the same launches.
+
+    Deferred K-split reduction (one row; include/paro_abi.h, v12): ``parts_out`` (float32 ``[N, 4]``) -- the launch's K-splits
+    (``parts_n`` of them; 0 = :func:`gemv_parts_count`, the automatic launch shape's) leave their partial sums there, in the
+    in-launch reducer's summation order, instead of reducing them in the launch; nothing else is written and ``parts_out`` is
+    returned.  ``parts_in`` (float32 ``[K, 4]``, a producer's ``parts_out``): ``x`` is the residual stream BEFORE the producer's output
+    and the kernel completes ``x' = round(x + sum(parts_in, 1))`` while it seeds its rotation (prologue NONE or RMSNORM);
+    ``x_out [K]`` (not aliasing ``x``) receives ``x'``."""
     lib = nat.load()
     K, N = pk.K, pk.N
     width = 2 * K if prologue in (nat.PROLOGUE_SILU_MUL, nat.PROLOGUE_GELU_TANH_MUL) else K
@@ -335,7 +344,16 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     rows = x2.size(0)
     if x.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"expected float16 or bfloat16 activations, got {x.dtype}")
-    y = out if out is not None else torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    for name, t, width_t in (("parts_out", parts_out, N), ("parts_in", parts_in, K)):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (width_t, nat.PARO_MAX_PARTIALS) or not t.is_contiguous()
+                              or t.device != x.device):
+            raise ValueError(f"{name} must be a contiguous float32 [{width_t}, {nat.PARO_MAX_PARTIALS}] tensor on {x.device}")
+    if x_out is not None and (parts_in is None or x_out.numel() != K or x_out.dtype != x.dtype or not x_out.is_contiguous() or x_out.device != x.device):
+        raise ValueError(f"x_out (with parts_in) must be a contiguous [{K}] tensor of {x.dtype} on {x.device}")
+    if parts_out is not None:
+        y = None
+    else:
+        y = out if out is not None else torch.empty((rows, N), dtype=x.dtype, device=x.device)
     if out is not None and (out.numel() != rows * N or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device):
         raise ValueError(f"out must be a contiguous [{rows}, {N}] tensor of {x.dtype} on {x.device} (the kernel writes through its raw pointer)")
     if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N or not residual.is_contiguous()):
@@ -347,11 +365,48 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     f.residual = residual.data_ptr() if residual is not None else None
     if allreduce is not None:
         f.ar_peers, f.ar_own, f.ar_state, f.ar_world, f.ar_rank, f.ar_max_elems = allreduce.fusion_args()
+    if parts_out is not None:
+        f.parts_out = parts_out.data_ptr()
+        f.parts_out_n = int(parts_n) if parts_n else lib.paro_gemv_parts_count(ctypes.byref(d))
+        if f.parts_out_n < 2:
+            raise RuntimeError(f"parts_out: this layer does not K-split on its own (paro_gemv_parts_count = {f.parts_out_n}); "
+                               "pass parts_n = 2..4 or use the ordinary route")
+    if parts_in is not None:
+        f.parts_in = parts_in.data_ptr()
+        f.x_out = x_out.data_ptr() if x_out is not None else None
     ws = pk.workspace
     with torch.cuda.device(x.device):
-        nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr(), rows, ws.data_ptr(),
+        nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr() if y is not None else None, rows, ws.data_ptr(),
                                             ws.numel() * ws.element_size(), ctypes.byref(f), nat.current_stream_ptr(x.device)))
-    return y
+    return y if y is not None else parts_out
+
+
+def gemv_parts_count(pk, act_dtype: torch.dtype = torch.float16) -> int:
+    """How many fp32 partial sums ``w4a16_gemv_fused(..., parts_out=)`` of this layer leaves (``paro_gemv_parts_count``: the K-split
+    of the automatic launch shape); 0 = the layer does not split (or has a bias): use the ordinary route."""
+    n = nat.load().paro_gemv_parts_count(ctypes.byref(pk_desc(pk, act_dtype)))
+    if n < 0:
+        nat.check(n)
+    return int(n)
+
+
+def parts_finish(parts: torch.Tensor, x: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``out[k] = round(x[k] + sum(parts[k, :]))`` in the order of the in-launch reducer (``paro_parts_finish``): completes a
+    producer's ``parts_out [K, 4]`` when no linear follows (the last layer's down_proj in front of the final norm)."""
+    dt = x.dtype if x is not None else (dtype or torch.float16)
+    K = int(parts.size(0))
+    if parts.dtype != torch.float32 or parts.dim() != 2 or parts.size(1) != nat.PARO_MAX_PARTIALS or not parts.is_contiguous() \
+            or (x is not None and (x.numel() != K or not x.is_contiguous())):
+        raise ValueError(f"parts must be contiguous float32 [K, {nat.PARO_MAX_PARTIALS}]; x contiguous [K]")
+    if out is None:
+        out = torch.empty(K, dtype=dt, device=parts.device)
+    elif out.numel() != K or out.dtype != dt or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{K}] tensor of {dt}")
+    with torch.cuda.device(parts.device):
+        nat.check(nat.load().paro_parts_finish(x.data_ptr() if x is not None else None, parts.data_ptr(), K, out.data_ptr(),
+                                               nat.DTYPE_F16 if dt == torch.float16 else nat.DTYPE_BF16, nat.current_stream_ptr(parts.device)))
+    return out
 
 
 def pk_desc(pk, act_dtype: torch.dtype, bias=None) -> nat.ParoLinearDesc:

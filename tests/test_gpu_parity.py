@@ -1284,6 +1284,28 @@ def test_decoder_harness_matches_hf(dev, tmp_path, model_type, head_dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
+    """One GPU: o / down leave their K-split partial sums to the RMSNorm-prologue launch behind them (decoder._layers_deferred) --
+    logits bit for bit and tokens one for one what the in-launch reducer route (PARO_DEFERRED_KSPLIT=0) gives, eager and graph."""
+    from paroquant_amd.decoder import ParoDecoderLM, DecoderConfig
+    cfg = lambda: DecoderConfig(512, 2048, 16, 2, 128, 3, 640, 1e-6, 10000.0, True, 64)     # o: 2048 -> 512, down: 2048 -> 512: both K-split
+    ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
+    lm_d = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
+    assert lm_d.deferred
+    monkeypatch.setenv("PARO_DEFERRED_KSPLIT", "0")
+    lm_r = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
+    assert not lm_r.deferred
+    for use_graph in (False, True):
+        td, _ = lm_d.generate(ids, 10, use_graph=use_graph)
+        tr, _ = lm_r.generate(ids, 10, use_graph=use_graph)
+        assert torch.equal(td, tr)
+        assert torch.equal(lm_d.logits, lm_r.logits)
+    from paroquant_amd import ops
+    ops.check_workspace(lm_d.layers[0].o.workspace)
+
+
+@pytest.mark.gpu
 def test_decoder_harness_bf16_and_graph_consistency(dev):
     """The decode harness in bf16: the HIP-graph replay path reproduces the eager launch sequence token for token, and the
     bf16 model's first decode steps agree with the fp16 model built from the same seed (same synthetic weights)."""

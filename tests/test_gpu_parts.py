@@ -1,0 +1,141 @@
+"""GPU tests of the deferred K-split reduction (include/paro_abi.h v12, ``paro_fusion_t.parts_out / parts_in / x_out``):
+the K-split producer (o_proj, down_proj) leaves fp32 partial sums, the RMSNorm-prologue consumer behind it completes
+``x' = round(x + sum(parts))`` while it seeds its rotation.  Checked (1) against the CPU oracle on the same seeded inputs
+(tolerance of tests/test_gpu_parity.py), (2) BIT FOR BIT against the ordinary route (in-launch reducer + residual epilogue, then the
+RMSNorm-prologue launch): same summation order, same single rounding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import paro_oracle as po
+from tests.test_gpu_parity import TIGHT_BF16, TIGHT_F16, _np, _packed, _t, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+# (producer K, producer N = consumer K, consumer partitions): Qwen3-4B o -> gate_up, down -> qkv; Llama-3-8B down -> qkv; a small case
+PAIRS = [(4096, 2560, [9728, 9728]), (9728, 2560, [4096, 1024, 1024]), (14336, 4096, [4096, 1024, 1024]), (1024, 512, [208, 48])]
+
+
+def _layers(Kp, H, sizes, seed):
+    return po.make_layer(seed, Kp, [H]), po.make_layer(seed + 1, H, sizes)
+
+
+@pytest.mark.parametrize("Kp,H,sizes", PAIRS)
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, TIGHT_F16), (torch.bfloat16, TIGHT_BF16)])
+@pytest.mark.parametrize("n_parts", [0, 2, 3])
+def test_parts_route_matches_oracle_and_fused_route(dev, Kp, H, sizes, dtype, tol, n_parts):
+    from paroquant_amd import ops, _native as nat
+    Lp, Lc = _layers(Kp, H, sizes, Kp + H)
+    rng = np.random.default_rng(Kp * 3 + H)
+    xa = _t(rng.standard_normal((1, Kp)).astype(np.float32), dev, dtype)              # the producer's input (attention output / act)
+    h0 = _t((rng.standard_normal((1, H)) * 2.0).astype(np.float32), dev, dtype)       # the residual stream in front of the producer
+    w = (1.0 + 0.2 * rng.standard_normal(H)).astype(np.float16)
+    pp = _packed(Lp, dev)
+    pc = _packed(Lc, dev).fold_norm_weight(_t(w, dev))
+    n = n_parts if n_parts else ops.gemv_parts_count(pp, dtype)
+    if n == 0:
+        assert Kp < 4096                       # every decoder-sized o / down splits; the small case does not on its own
+        n = 2
+    # ---- the ordinary route: producer reduces in its launch and adds the residual; consumer with the RMSNorm prologue
+    h1_ref = ops.w4a16_gemv_fused(xa, pp, nat.PROLOGUE_NONE, residual=h0)
+    y_ref = ops.w4a16_gemv_fused(h1_ref, pc, nat.PROLOGUE_RMSNORM, 1e-6)
+    # ---- the parts route
+    parts = torch.full((H, 4), float("nan"), device=dev, dtype=torch.float32)
+    assert ops.w4a16_gemv_fused(xa, pp, nat.PROLOGUE_NONE, parts_out=parts, parts_n=n) is parts
+    h1 = torch.zeros(H, device=dev, dtype=dtype)
+    y = ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_RMSNORM, 1e-6, parts_in=parts, x_out=h1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts).all() and (parts[:, n:] == 0).all()          # unused slots are zeroed by the producer
+    # oracle: the producer's linear, the residual add, the norm, the consumer's linear
+    yo = po.paro_linear_merged(_np(xa), Lp["qweight"], Lp["qzeros"], Lp["scales"], Lp["theta"], Lp["pairs"], Lp["channel_scales"], [H],
+                               None, ideal=True)
+    assert po.rel_err(parts.double().sum(1)[None, :].cpu().numpy(), yo) < tol
+    assert po.rel_err(_np(h1)[None, :], yo + _np(h0)) < tol
+    xn = po.rmsnorm(_np(h1)[None, :].astype(np.float32), w, 1e-6)
+    ideal = po.paro_linear_merged(xn, Lc["qweight"], Lc["qzeros"], Lc["scales"], Lc["theta"], Lc["pairs"], Lc["channel_scales"], sizes,
+                                  None, ideal=True)
+    assert po.rel_err(_np(y), ideal) < 2 * tol
+    # bit identity with the ordinary route whenever that route split K the same way (its automatic shape)
+    if n_parts == 0 and ops.gemv_parts_count(pp, dtype) == n:
+        assert torch.equal(h1.view(-1), h1_ref.view(-1))
+        assert torch.equal(y, y_ref)
+    else:
+        assert po.rel_err(_np(h1)[None, :], _np(h1_ref)) < (2e-3 if dtype == torch.float16 else 2e-2)
+    # the stand-alone completion (no linear behind the producer) gives the same residual stream
+    assert torch.equal(ops.parts_finish(parts, h0.view(-1)), h1)
+    # the plain (no norm) consumer, without x_out
+    # (the ordinary launch may K-split -- Llama-3-8B's qkv does --, the consumer of partial sums never does: same numbers, not the same bits)
+    y_plain = ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_NONE, parts_in=parts)
+    assert po.rel_err(_np(y_plain), _np(ops.w4a16_gemv_fused(h1.view(1, -1), pc, nat.PROLOGUE_NONE))) < (1e-3 if dtype == torch.float16 else 1e-2)
+    ops.check_workspace(pp.workspace)
+
+
+def test_parts_with_silu_producer_and_graph_replay(dev):
+    """down_proj (SiLU * mul prologue) as the producer, the next layer's qkv as the consumer, captured in a HIP graph and replayed
+    on fresh inputs: nothing is armed or reset between launches."""
+    from paroquant_amd import ops, _native as nat
+    Kp, H, sizes = 9728, 2560, [4096, 1024, 1024]
+    Lp, Lc = _layers(Kp, H, sizes, 77)
+    pp, pc = _packed(Lp, dev), _packed(Lc, dev)
+    n = ops.gemv_parts_count(pp)
+    assert 2 <= n <= nat.PARO_MAX_PARTIALS
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    gu = torch.randn(1, 2 * Kp, device=dev, dtype=torch.float16, generator=gen)
+    h0 = torch.randn(1, H, device=dev, dtype=torch.float16, generator=gen)
+    parts = torch.zeros(H, 4, device=dev, dtype=torch.float32)
+    h1 = torch.zeros(H, device=dev, dtype=torch.float16)
+    y = torch.zeros(1, sum(sizes), device=dev, dtype=torch.float16)
+
+    def step():
+        ops.w4a16_gemv_fused(gu, pp, nat.PROLOGUE_SILU_MUL, parts_out=parts)
+        ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_RMSNORM, 1e-6, parts_in=parts, x_out=h1, out=y)
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for it in range(3):
+        gu.copy_(torch.randn(1, 2 * Kp, device=dev, dtype=torch.float16, generator=gen))
+        h0.copy_(torch.randn(1, H, device=dev, dtype=torch.float16, generator=gen))
+        g.replay()
+        torch.cuda.synchronize()
+        h1_ref = ops.w4a16_gemv_fused(gu, pp, nat.PROLOGUE_SILU_MUL, residual=h0)
+        y_ref = ops.w4a16_gemv_fused(h1_ref, pc, nat.PROLOGUE_RMSNORM, 1e-6)
+        assert torch.equal(h1, h1_ref.view(-1)) and torch.equal(y, y_ref), it
+
+
+def test_parts_argument_errors(dev):
+    from paroquant_amd import ops, _native as nat
+    Lp, Lc = _layers(1024, 512, [208, 48], 9)
+    pp, pc = _packed(Lp, dev), _packed(Lc, dev)
+    x = torch.zeros(1, 1024, device=dev, dtype=torch.float16)
+    h = torch.zeros(1, 512, device=dev, dtype=torch.float16)
+    parts = torch.zeros(512, 4, device=dev, dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="batch-1"):
+        ops.w4a16_gemv_fused(torch.zeros(2, 1024, device=dev, dtype=torch.float16), pp, parts_out=parts, parts_n=2)
+    with pytest.raises(RuntimeError, match="residual and bias"):
+        ops.w4a16_gemv_fused(x, pp, residual=h, parts_out=parts, parts_n=2)
+    with pytest.raises(RuntimeError, match="residual and bias"):
+        ops.w4a16_gemv_fused(x, pp, bias=torch.zeros(512, device=dev, dtype=torch.float16), parts_out=parts, parts_n=2)
+    with pytest.raises(ValueError, match="float32"):
+        ops.w4a16_gemv_fused(x, pp, parts_out=parts.half())
+    with pytest.raises(ValueError, match="float32"):
+        ops.w4a16_gemv_fused(x, pp, parts_out=torch.zeros(512, 5, device=dev))
+    with pytest.raises(RuntimeError, match="does not K-split on its own"):
+        ops.w4a16_gemv_fused(x, pp, parts_out=parts)
+    with pytest.raises(RuntimeError, match="parts_out_n must be in 2"):
+        ops.w4a16_gemv_fused(x, pp, parts_out=parts, parts_n=5)
+    with pytest.raises(RuntimeError, match="non-empty slices|parts_out_n"):
+        ops.w4a16_gemv_fused(torch.zeros(1, 128, device=dev, dtype=torch.float16), _packed(po.make_layer(1, 128, [512]), dev), parts_out=parts, parts_n=2)
+    with pytest.raises(RuntimeError, match="plain or the RMSNorm"):
+        ops.w4a16_gemv_fused(torch.zeros(1, 1024, device=dev, dtype=torch.float16), _packed(po.make_layer(2, 512, [64]), dev),
+                             nat.PROLOGUE_SILU_MUL, parts_in=parts)
+    with pytest.raises(RuntimeError, match="alias"):
+        ops.w4a16_gemv_fused(h, pc, nat.PROLOGUE_RMSNORM, parts_in=parts, x_out=h.view(-1))
+    with pytest.raises(RuntimeError, match="both receive and leave"):
+        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), parts_in=parts, parts_out=parts, parts_n=2)
+    with pytest.raises(ValueError, match="x_out"):
+        ops.w4a16_gemv_fused(h, pc, x_out=h.view(-1).clone())
+    assert ops.gemv_parts_count(_packed(po.make_layer(4, 256, [4096]), dev)) == 0      # wide output, shallow K: no split

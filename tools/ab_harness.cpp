@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
   hipStream_t st; HIP_OK(hipStreamCreate(&st));
   std::mt19937 rng(1234);
   for (const Shape& s : shapes_of(model)) {
+    if (getenv("AB_ONLY") && !strstr(getenv("AB_ONLY"), s.name)) continue;
     const int K = s.K, P = (int)s.parts.size(), G = K / 128;
     int N = 0; for (int c : s.parts) N += c;
     int32_t part_cols[PARO_MAX_PARTS] = {0};
@@ -113,7 +114,8 @@ int main(int argc, char** argv) {
     void *d_pairs, *d_theta, *d_cs, *d_x, *d_rot, *d_qw, *d_qz, *d_sc, *d_ws, *d_ya, *d_yb;
     int32_t* d_status;
     HIP_OK(hipMalloc(&d_pairs, pairs.size() * 2)); HIP_OK(hipMalloc(&d_theta, theta.size() * 2)); HIP_OK(hipMalloc(&d_cs, cs.size() * 2));
-    HIP_OK(hipMalloc(&d_x, (size_t)K * 2)); HIP_OK(hipMalloc(&d_rot, rot_bytes)); HIP_OK(hipMalloc(&d_status, 4));
+    HIP_OK(hipMalloc(&d_x, (size_t)K * 2 * 16)); HIP_OK(hipMemset(d_x, 0, (size_t)K * 2 * 16));   // 16 slabs: room for the PARO_XSLABS experiment
+    HIP_OK(hipMalloc(&d_rot, rot_bytes)); HIP_OK(hipMalloc(&d_status, 4));
     HIP_OK(hipMalloc(&d_qw, qw_words * 4)); HIP_OK(hipMalloc(&d_qz, qz_words * 4)); HIP_OK(hipMalloc(&d_sc, sc_halves * 2));
     HIP_OK(hipMalloc(&d_ya, (size_t)N * 2)); HIP_OK(hipMalloc(&d_yb, (size_t)N * 2));
     HIP_OK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 2, hipMemcpyHostToDevice));
@@ -143,7 +145,9 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&d_ws, ws_bytes)); HIP_OK(hipMemset(d_ws, 0, ws_bytes));
     auto launch = [&](Lib& lib, int c, void* y) {
       paro_linear_t l = L; l.wq = pk[c].wq; l.sz = pk[c].sz;
-      const int rc = lib.w4a16_gemv(&l, d_x, y, 1, d_ws, ws_bytes, 0, 0, 0, -1, st);
+      static const int f_tpw = getenv("AB_TPW") ? atoi(getenv("AB_TPW")) : 0, f_ks = getenv("AB_KS") ? atoi(getenv("AB_KS")) : 0,
+                       f_wv = getenv("AB_WV") ? atoi(getenv("AB_WV")) : 0;   // launch-shape overrides (0 = the library's choice)
+      const int rc = lib.w4a16_gemv(&l, d_x, y, 1, d_ws, ws_bytes, f_tpw, f_ks, f_wv, -1, st);
       if (rc != PARO_OK) { fprintf(stderr, "gemv: %s\n", lib.last_error()); exit(3); }
     };
     // ---- bit identity of the two builds on every weight set

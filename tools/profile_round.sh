@@ -4,7 +4,7 @@
 # decode     : bench lines + per-shape tables (qwen3-4b = the driver's line, llama3-8b, qwen3-0.6b, qwen3.5-9b, llama3-70b x 8 layers),
 #              rocprofv3 kernel traces of the qwen3-4b / llama3-8b / llama3-70b bench commands,
 #              batched decode (--rows 2..16) through both routes, the C++ chain harness (fused vs chain per shape and per layer)
-# end to end : fused decode harness tokens/s
+# end to end : fused decode harness tokens/s (deferred K-split reduction, and the in-launch reducer for comparison); tools/bench_parts.py
 # prefill    : TFLOP/s per linear at M = 65536 (variant 4), MoE grouped prefill vs the per-expert loop
 # PMC        : HBM traffic of the bench command (separate FETCH_SIZE / WRITE_SIZE passes) -- LAST, so that the summary's
 #              kernel_sources_sha is the tree's (bench.py refuses an older summary as roofline.traffic)
@@ -43,7 +43,7 @@ fi
 cd /tmp
 for spec in "qwen3-4b:" "llama3-8b:--workload llama3-8b" "llama3-70b_8layers:--workload llama3-70b --layers 8"; do
   name=${spec%%:*}; args=${spec#*:}
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -o b -- python $ROOT/bench.py $args --steps 20 --warmup 3 --no-cpu-baseline --no-e2e > $OUT/stats_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -o b -- python $ROOT/bench.py $args --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-route-ab > $OUT/stats_$name.log 2>&1
   S=$(find $OUT/stats_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$S" ] && (cd $ROOT && python tools/pmc_summary.py stats $S $P/${R}_bench_${name}_kernel_stats.csv)
 done
@@ -51,13 +51,19 @@ cd $ROOT
 # ---- end to end
 rm -f $P/${R}_e2e.jsonl
 for m in qwen3-4b llama3-8b qwen3-0.6b; do timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e.jsonl 2>> $OUT/e2e.err; done
+# ... and with the in-launch K-split reducer instead of the deferred reduction (paroquant_amd/decoder.py), same session
+rm -f $P/${R}_e2e_reducer.jsonl
+for m in qwen3-4b llama3-8b; do PARO_DEFERRED_KSPLIT=0 timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e_reducer.jsonl 2>> $OUT/e2e.err; done
+# ---- deferred K-split reduction per launch and per producer -> consumer pair
+rm -f $P/${R}_parts_micro.jsonl
+for m in qwen3-4b llama3-8b; do timeout 300 python tools/bench_parts.py --model $m >> $P/${R}_parts_micro.jsonl 2>> $OUT/parts.err; done
 # ---- prefill
 timeout 400 python tools/bench_gemm.py --model llama3-8b --rows 65536 --variants 0 > $P/${R}_prefill_llama3-8b.jsonl 2> $OUT/gemm.err
 timeout 300 python tools/bench_moe.py > $P/${R}_moe_prefill.jsonl 2>> $OUT/gemm.err
 # ---- PMC passes LAST
 cd /tmp
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e > $OUT/fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e > $OUT/write.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e --no-route-ab > $OUT/fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e --no-route-ab > $OUT/write.log 2>&1
 cd $ROOT
 F=$(dirname $(find $OUT/fetch -name "*counter_collection.csv" | head -1))
 W=$(dirname $(find $OUT/write -name "*counter_collection.csv" | head -1))
