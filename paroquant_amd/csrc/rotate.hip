@@ -154,10 +154,14 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
                                                          int nparts) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 256];
+  constexpr int OP = 256;   // output staging pitch (a 272-byte pitch, conflict-free for the 2-byte D-fragment writes, measured equal)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * OP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * 256, g = blockIdx.y;
+  // blockIdx.x = group: the workgroups that run together cover whole rows of x (and of every rotated copy) -- consecutive DRAM
+  // pages -- instead of one 256-byte column stripe of 256 x (resident workgroups) different rows (pre-pass 757 -> 578 us at
+  // M = 65536, Llama-3-8B qkv + gate_up, profiles/r03_prepass_order.txt)
+  const int row0 = blockIdx.y * 256, g = blockIdx.x;
   const int G = K >> 7;
   const int n = lane & 15, mq = lane >> 4;
 
@@ -185,21 +189,26 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
   // every merged partition from the SAME staged activations (qkv: x is read once, not three times)
   for (int p = 0; p < nparts; ++p) {
     const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;  // [n][k], k contiguous
-#pragma unroll 2
-    for (int ct = 0; ct < 8; ++ct) {
-      vec8 bf[4];
+    // the rotation matrix's B fragments one column tile ahead (they come from L2: a dependent round trip per tile otherwise)
+    vec8 bf[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bf[i] = *(const vec8*)(rp + (ct * 16 + n) * 128 + 32 * i + 8 * mq);
+    for (int i = 0; i < 4; ++i) bf[0][i] = *(const vec8*)(rp + n * 128 + 32 * i + 8 * mq);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      if (ct + 1 < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[(ct + 1) & 1][i] = *(const vec8*)(rp + ((ct + 1) * 16 + n) * 128 + 32 * i + 8 * mq);
+      }
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[i], d);
-        // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major 256 B)
+        for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[ct & 1][i], d);
+        // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major, pitch OP)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wave * 64 + rt * 16 + 4 * mq + r;
-          *(unsigned short*)(lds + row * 256 + (ct * 16 + n) * 2) = A::from_f32(d[r]);
+          *(unsigned short*)(lds + row * OP + (ct * 16 + n) * 2) = A::from_f32(d[r]);
         }
       }
     }
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
     for (int c = 0; c < 16; ++c) {
       const int row = (tid >> 4) + 16 * c;
       if (row0 + row < rows)
-        *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * 256 + (tid & 15) * 16);
+        *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * OP + (tid & 15) * 16);
     }
     __syncthreads();   // the staging tile is reused by the next partition
   }
@@ -219,7 +228,8 @@ int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows,
                        hipStream_t st) {
   if (rows == 0) return PARO_OK;
   const int64_t rb = (rows + 255) / 256;
-  dim3 grid((unsigned)rb, (unsigned)(K / 128));
+  if (rb > 65535) return fail(PARO_ERR_UNSUPPORTED, "rotate pre-pass: more than 65535 x 256 rows");
+  dim3 grid((unsigned)(K / 128), (unsigned)rb);
   if (dt == PARO_DTYPE_F16)
     hipLaunchKernelGGL(rotate_mfma_kernel<f16>, grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,
                        (const unsigned short*)rmat, (int)rows, (int)K, nparts);
