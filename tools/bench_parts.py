@@ -5,8 +5,8 @@
 
 For (o_proj -> gate_up) and (down_proj -> qkv) of the model, each variant captured in a HIP graph of `reps` launches (pairs: reps / 2
 pairs) that cycle >= 1 GiB of distinct weight copies, variants interleaved over 5 rounds, median reported:
-  producer   : residual epilogue (in-launch reducer)  |  parts_out
-  consumer   : plain | RMSNorm prologue | RMSNorm + parts_in | RMSNorm + parts_in + x_out      (partial sums not rewritten: cache-warm)
+  producer   : plain | residual epilogue (in-launch reducer)  |  parts_out
+  consumer   : plain | residual epilogue only | RMSNorm prologue | RMSNorm + parts_in | RMSNorm + parts_in + x_out      (partial sums not rewritten: cache-warm)
   pair       : [producer(residual) -> consumer(RMSNorm)]  |  [producer(parts_out) -> consumer(RMSNorm + parts_in + x_out)]"""
 import argparse
 import json
@@ -48,7 +48,10 @@ def main():
         h1 = torch.zeros(1, H, device=dev, dtype=torch.float16)
         parts = torch.zeros(H, 4, device=dev, dtype=torch.float32)
         yc = torch.zeros(1, sum(sc), device=dev, dtype=torch.float16)
+        resc = torch.zeros(1, sum(sc), device=dev, dtype=torch.float16)
         variants = {
+            "producer plain": lambda i: ops.w4a16_gemv_tuned(xa, prod[i % cp], 0, 0, 0, 0),
+            "consumer residual only": lambda i: ops.w4a16_gemv_fused(h0, cons[i % cc], 0, residual=resc, out=yc),
             "producer residual": lambda i: ops.w4a16_gemv_fused(xa, prod[i % cp], 0, residual=h0, out=h1),
             "producer parts_out": lambda i: ops.w4a16_gemv_fused(xa, prod[i % cp], 0, parts_out=parts),
             "consumer plain": lambda i: ops.w4a16_gemv_tuned(h0, cons[i % cc], 0, 1, 0, 0),
