@@ -218,9 +218,12 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
  *                x'[k] = round(x[k] + (((parts[k][0] + parts[k][1]) + parts[k][2]) + parts[k][3]))
  *            -- the summation order and the single rounding of the in-launch reducer, so both routes give the same bits.
  *            x_out (optional, must not alias x) receives x' (the new residual stream; written by one workgroup).
- *            One row; in-kernel rotation; the consumer's prologue is NONE or RMSNORM and it does not K-split.
- *            parts_out_n: paro_gemv_parts_count(L) (the split the automatic launch shape uses; 0 = this layer does not
- *            split, use the ordinary route), or any 2..PARO_MAX_PARTIALS that K / 128 can be cut into.
+ *            One row; in-kernel rotation; the consumer's prologue is NONE or RMSNORM.  With the RMSNorm prologue or x_out the
+ *            consumer covers all of K per workgroup; a plain consumer may split K itself (each slice completes the channels it
+ *            reads) and may in turn leave partial sums (parts_in and parts_out in one call: a chain of plain linears).
+ *            parts_out_n: paro_gemv_parts_count(L) -- the split of the launch shape chosen for a launch nobody polls in (the
+ *            narrow deep linears as in the automatic shape; mid-width ones such as qkv split 2-way); 0 = this layer does
+ *            not split, use the ordinary route -- or any 2..PARO_MAX_PARTIALS that K / 128 can be cut into.
  *            paro_parts_finish completes the sum without a linear behind it (the last layer's down_proj in front of the
  *            final norm): out[k] = round(x[k] + sum) in the same order; x may be NULL.
  * rows <= 4, krot <= 8 (in-kernel rotation); the launch shape is chosen automatically. */

@@ -39,7 +39,7 @@ constexpr int kMaxKsplit = 16;
 
 // Launch-shape heuristic (calibrated on MI355X with tools/sweep_gemv.py):
 // one workgroup covers all of K whenever that still yields >= ~1 workgroup per CU.
-void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, int& waves) {
+void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, int& waves, bool deferred = false) {
   // Measured on MI355X (tools/sweep_gemv.py; Llama-3-8B, Qwen3-4B, Qwen3-0.6B shapes, M = 1):
   //   * every workgroup rotates all the groups it covers, so the total rotation work is
   //     (#column blocks) x K/128 group rotations (VALU issue + 3 KiB of schedule through the CU's L1 each):
@@ -85,10 +85,11 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
     // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us)
     tpw = 1; ksplit = 2; waves = 8;
-  } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= 32) {
+  } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= (deferred && rows == 1 ? 16 : 32)) {
     // mid-width outputs with K >= 4096 (Llama-3-8B qkv: 384 tiles x 32 groups): 96 fat column blocks x 2 splits halve
     // the replicated rotation; pays since the reducer polls all splits at once (7.10 -> 6.71 us; at G = 20, Qwen3-4B
-    // qkv, the unsplit 2-tile shape stays ahead: 5.65 vs 5.94)
+    // qkv, the unsplit 2-tile shape stays ahead: 5.65 vs 5.94).  `deferred` (the splits leave partial sums, nobody polls):
+    // pays from G = 16 (Qwen3-4B qkv 5.50 -> 4.96 us, Llama-3-8B 6.78 -> 5.73, profiles/r03_sweep_noreducer_wide.jsonl)
     tpw = 4; ksplit = 2; waves = 8;
   }
   if (tpw <= 0) {
@@ -129,7 +130,7 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
 
 namespace paro {
 // The launch shape a GEMV call ends up with: caller's knobs (0 = auto, mode -1 = auto) -> final values.
-int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ksp, int& wv, int& mode) {
+int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ksp, int& wv, int& mode, bool deferred = false) {
   const int waves_in = wv;
   if (tpw != 0 && tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8)
     return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto), 1, 2, 4 or 8 (got %d)", tpw);
@@ -148,7 +149,7 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // M=8 qkv 11.4 / 13.4, o 10.1 / 13.4, gate_up 21.5 / 20.8, down 17.5 / 16.8; M=12 qkv 16.7 / 14.9, gate_up 47 / 22:
   // below 9 rows only the wide merged projections still prefer the pre-pass)
   if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
-  gemv_autotune(L, rows, tpw, ksp, wv);
+  gemv_autotune(L, rows, tpw, ksp, wv, deferred);
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   (void)waves_in;
   if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
@@ -215,7 +216,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (L->krot > 8 || mode == 1 || mode == 2) return fail(PARO_ERR_UNSUPPORTED, "partial sums need the in-kernel rotation (krot <= 8, mode 0)");
   }
   if (pout) {
-    if (pin) return fail(PARO_ERR_UNSUPPORTED, "one launch cannot both receive and leave partial sums (the consumer's RMSNorm needs all of K per workgroup)");
+    if (pin && F->prologue != PARO_PROLOGUE_NONE) return fail(PARO_ERR_UNSUPPORTED, "a launch that receives AND leaves partial sums splits K: not with the RMSNorm prologue (the norm needs all of K per workgroup)");
     if (F->parts_out_n < 2 || F->parts_out_n > PARO_MAX_PARTIALS) return fail(PARO_ERR_INVALID, "parts_out_n must be in 2..%d (got %d): a launch that does not split K writes y itself", PARO_MAX_PARTIALS, F->parts_out_n);
     if (F->residual || L->bias) return fail(PARO_ERR_UNSUPPORTED, "parts_out: residual and bias are added where the partial sums are completed; this launch takes neither");
     if (F->prologue == PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
@@ -223,9 +224,12 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   }
   if (pin) {
     if (F->prologue != PARO_PROLOGUE_NONE && F->prologue != PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_UNSUPPORTED, "parts_in feeds the plain or the RMSNorm prologue");
-    if (ksplit > 1) return fail(PARO_ERR_INVALID, "parts_in: every workgroup completes all of x, the launch does not K-split");
-    if (F->x_out == x) return fail(PARO_ERR_INVALID, "x_out must not alias x (other workgroups still read it)");
-    ksplit = 1;
+    if (F->x_out && F->x_out == x) return fail(PARO_ERR_INVALID, "x_out must not alias x (other workgroups still read it)");
+    if (F->x_out && pout) return fail(PARO_ERR_UNSUPPORTED, "x_out is written by launches that do not split K; this one leaves partial sums");
+    if (F->x_out) {    // the completed x is written by one workgroup that covers all of K
+      if (ksplit > 1) return fail(PARO_ERR_INVALID, "x_out: the launch must not K-split");
+      ksplit = 1;
+    }
   }
   if (E) {
     if (!F) F = &no_fusion;
@@ -259,7 +263,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
   }
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
-  rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode);
+  rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode, pout);
   if (rc != PARO_OK) return rc;
   if (pout && ksp != F->parts_out_n) {
     // the automatic shape splits K differently from what the caller sized its buffers for: the caller's count wins
@@ -301,7 +305,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.counters = nullptr;
   a.prologue = fused ? F->prologue : PARO_PROLOGUE_NONE;
   a.parts_out = pout ? 1 : 0;
-  a.parts_in = pin ? 1 : 0;
+  a.parts_in = pin ? F->parts_in : nullptr;
+  a.x_out = pin ? (unsigned short*)F->x_out : nullptr;
   const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue >= PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.expert_idx = E ? E->expert_idx : nullptr;
   a.wq_estride = E ? E->wq_stride_bytes : 0;
@@ -333,11 +338,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
   if (pout) a.slabs = (unsigned long long*)F->parts_out;        // float [N][4]
-  if (pin) {
-    a.counters = (unsigned*)const_cast<float*>(F->parts_in);    // float [K][4]
-    a.slabs = (unsigned long long*)F->x_out;                    // the completed x [K], or null
-  }
-  if (a.pd == 31 && a.ksplit == 1 && !pin && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
+  if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
   // mode 2: the caller hands over rotated activations, [n_parts][rows][K] in the activation type (whoever produced x
   // rotated it -- rotation::rotate per partition, or a producer kernel's epilogue): the pre-rotated kernels, no pre-pass
@@ -412,7 +413,7 @@ extern "C" int paro_gemv_parts_count(const paro_linear_t* L) {
   if (validate_linear(L) != PARO_OK) return -1;
   if (L->krot > 8 || L->bias) return 0;
   int tpw = 0, ks = 0, wv = 0, mode = 0;
-  if (resolve_launch_shape(L, 1, tpw, ks, wv, mode) != PARO_OK) return -1;
+  if (resolve_launch_shape(L, 1, tpw, ks, wv, mode, true) != PARO_OK) return -1;
   return (ks >= 2 && ks <= PARO_MAX_PARTIALS) ? ks : 0;
 }
 

@@ -69,8 +69,11 @@ struct GemvArgs {
   const unsigned short* bias;
   unsigned short* y;
   unsigned long long* slabs;     // K-split granules {tag << 32 | fp32 bits}: [ksplit - 1][rows][N]; parts_out launches: float [N][4] (the
-                                 // caller's partial sums, no hand-off); parts_in launches: the completed x [K] in the activation type, or null
-  unsigned* counters;            // K-split epoch words; parts_in launches: const float [K][4], the producer's partial sums
+                                 // caller's partial sums, no hand-off)
+  unsigned* counters;            // K-split epoch words
+  // deferred K-split reduction, consumer side (FUSED | 8): one 16-byte pair, fetched with one scalar load at kernel entry
+  alignas(16) const float* parts_in;   // [K][4] fp32: the producer's partial sums of x's missing term, or null
+  unsigned short* x_out;               // the completed x [K] in the activation type (unsplit launches), or null
   // expert slots (FUSED instantiations only; paro_w4a16_gemv_experts): blockIdx.z = slot, the slot's expert id
   // is read from DEVICE memory; all experts share the rotation (cli/convert.py:280-379, mlx/modules.py:159-212)
   const int* expert_idx;         // [slots] or null
@@ -88,7 +91,7 @@ struct GemvArgs {
   long long ar_off;                 // byte offset of that region inside a buffer
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
-  int parts_out, parts_in;       // deferred K-split reduction (paro_fusion_t, v12): this launch writes / reads partial sums
+  int parts_out;                 // deferred K-split reduction (paro_fusion_t, v12): this launch leaves partial sums
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
@@ -129,7 +132,7 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 //                      gate_up projection's output [rows][2 K] (the MLX MoE path rotates the activation output the
 //                      same way before down_proj, mlx/modules.py:204-207).
 //   epilogue residual  y += residual[row][col] (the decoder's residual stream), in the final write.
-// FUSED | 8 (with FUSED & 3 == 1, one row): x arrives INCOMPLETE -- the K-split producer in front (o_proj, down_proj) left its
+// FUSED | 8 (with FUSED & 3 == 0 or 1, one row): x arrives INCOMPLETE -- the K-split producer in front (o_proj, down_proj) left its
 //   `n` <= 4 fp32 partial sums [K][4] instead of reducing them in its launch, and this kernel finishes the sum while it seeds the
 //   rotation: x_k = round(base_k + ((p[n-1][k] + p[0][k]) + ... + p[n-2][k])) -- the order and the one rounding of the reducer
 //   below, so both routes give the same bits (the producer stores its splits in that order, four slots per channel, unused ones zero).  Column block 0 also stores the completed x (the decoder's residual stream).
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int FMODE = FUSED & 3;          // 0 plain, 1 RMSNorm prologue and / or residual, 2 SiLU*mul prologue (+ residual)
   constexpr bool AREP = (FUSED & 4) != 0;   // + all-reduce epilogue (its own instantiations: the code costs the others ~5 % otherwise)
   constexpr bool PARTS_IN = (FUSED & 8) != 0;   // x = base + the producer's partial sums, completed while seeding (see above)
-  static_assert(!PARTS_IN || (FMODE == 1 && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
+  static_assert(!PARTS_IN || ((FMODE == 0 || FMODE == 1) && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -177,14 +180,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   u32x16 k0;
   int p;
   unsigned p_cb0_u, ent0, ent1;
-  unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words; PARTS_IN: the partial sums), fetched with the same batch
-  unsigned long long aux_ptr = 0;   // PARTS_IN: GemvArgs::slabs (where the completed x goes)
+  unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words), fetched with the same batch
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 pin_ptrs = {0ull, 0ull};   // PARTS_IN: GemvArgs::parts_in, x_out
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned m0_save;
     // (PARTS_IN: one more request in front of the batch below, whose wait covers it; its own statement so that the other
     // instantiations' prologue is byte for byte what it was)
-    if constexpr (PARTS_IN) asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(aux_ptr) : "s"(kp), "i"(offsetof(GemvArgs, slabs)) : "memory");
+    if constexpr (PARTS_IN) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(pin_ptrs) : "s"(kp), "i"(offsetof(GemvArgs, parts_in)) : "memory");
     asm volatile(
         "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
         "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   }
   // PARTS_IN: where the completed x goes -- a buffer descriptor whose size is K halves in column block 0 (and when the caller
   // wants it) and ZERO elsewhere: out-of-range buffer stores are dropped by the hardware, no branch around the store
-  __amdgpu_buffer_rsrc_t xout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)aux_ptr, 0, (PARTS_IN && cb == 0 && aux_ptr != 0) ? h.K * 2 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t xout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pin_ptrs[1], 0, (PARTS_IN && cb == 0 && pin_ptrs[1] != 0) ? h.K * 2 : 0, 0x00020000);
   GP<u32x4> wq_p = h.wq;
   GP<unsigned> sz_p = h.sz;
   GP<unsigned short> x_p = h.x;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         // [K][4] fp32: the four slots of a channel are one 16-byte load, already in the reducer's summation order (slot 0 = the LAST
         // split, slot q = split q - 1), unused slots zero -- the producer's epilogue below arranges both
         b.g = g;
-        GP<f32x4> pp = (GP<f32x4>)cnt_ptr + (unsigned)(g * 128 + 2 * lane);
+        GP<f32x4> pp = (GP<f32x4>)pin_ptrs[0] + (unsigned)(g * 128 + 2 * lane);
         b.xp[0] = pp[0];
         b.xp[1] = pp[1];
       }
@@ -1022,7 +1026,10 @@ int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) 
     return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is built for one row");
   }
   if (a.parts_in) {   // x = base + the producer's partial sums (FUSED | 8): one row, RMSNorm or no prologue
-    if constexpr (MB == 1 && !PREROT) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 9>(a, waves, grid, st);
+    if constexpr (MB == 1 && !PREROT) {
+      if (a.prologue == PARO_PROLOGUE_NONE && !(a.hot.residual_lo | a.hot.residual_hi)) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 8>(a, waves, grid, st);
+      return launch_waves_fused_mode<AT, TPW, MB, PREROT, 9>(a, waves, grid, st);
+    }
     return fail(PARO_ERR_UNSUPPORTED, "partial sums as input are built for one row, in-kernel rotation");
   }
   if (a.prologue == PARO_PROLOGUE_SILU_MUL || a.prologue == PARO_PROLOGUE_GELU_TANH_MUL) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 2>(a, waves, grid, st);

@@ -134,8 +134,48 @@ def test_parts_argument_errors(dev):
                              nat.PROLOGUE_SILU_MUL, parts_in=parts)
     with pytest.raises(RuntimeError, match="alias"):
         ops.w4a16_gemv_fused(h, pc, nat.PROLOGUE_RMSNORM, parts_in=parts, x_out=h.view(-1))
-    with pytest.raises(RuntimeError, match="both receive and leave"):
-        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), parts_in=parts, parts_out=parts, parts_n=2)
+    with pytest.raises(RuntimeError, match="not with the RMSNorm prologue"):
+        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), nat.PROLOGUE_RMSNORM, parts_in=parts, parts_out=parts, parts_n=2)
+    with pytest.raises(RuntimeError, match="x_out is written by launches that do not split K"):
+        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), parts_in=parts, parts_out=parts.clone(), parts_n=2,
+                             x_out=torch.zeros(512, device=dev, dtype=torch.float16))
     with pytest.raises(ValueError, match="x_out"):
         ops.w4a16_gemv_fused(h, pc, x_out=h.view(-1).clone())
     assert ops.gemv_parts_count(_packed(po.make_layer(4, 256, [4096]), dev)) == 0      # wide output, shallow K: no split
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, TIGHT_F16), (torch.bfloat16, TIGHT_BF16)])
+def test_parts_chain_consumer_is_producer(dev, dtype, tol):
+    """A chain of plain linears (bench.py's stack): down -> qkv -> o, every K-split deferred.  qkv both RECEIVES down's partial sums and
+    LEAVES its own (2-way split of the launch shape nobody polls in), o receives them and reduces its 4-way split in the launch.
+    Against the oracle on the chain, and bit for bit against the ordinary launches wherever the split is the same."""
+    from paroquant_amd import ops, _native as nat
+    Kd, H, qkv_sizes, Ko = 9728, 2560, [4096, 1024, 1024], 4096
+    Ld, Lq, Lo = po.make_layer(31, Kd, [H]), po.make_layer(32, H, qkv_sizes), po.make_layer(33, Ko, [H])
+    pd, pq, pko = _packed(Ld, dev), _packed(Lq, dev), _packed(Lo, dev)
+    assert ops.gemv_parts_count(pd, dtype) == 4 and ops.gemv_parts_count(pq, dtype) == 2 and ops.gemv_parts_count(pko, dtype) == 4
+    rng = np.random.default_rng(8)
+    xd = _t(rng.standard_normal((1, Kd)).astype(np.float32), dev, dtype)
+    zeros = torch.zeros(1, 4096, device=dev, dtype=dtype)
+    # ordinary launches
+    y_d = pd.apply(xd)
+    y_q = pq.apply(y_d)
+    y_o = pko.apply(y_q[:, :Ko].contiguous())
+    # deferred chain
+    p_d = torch.full((H, 4), float("nan"), device=dev, dtype=torch.float32)
+    p_q = torch.full((sum(qkv_sizes), 4), float("nan"), device=dev, dtype=torch.float32)
+    ops.w4a16_gemv_fused(xd, pd, 0, parts_out=p_d)
+    ops.w4a16_gemv_fused(zeros[:, :H], pq, 0, parts_in=p_d, parts_out=p_q)               # consumer AND producer
+    y_o2 = ops.w4a16_gemv_fused(zeros[:, :Ko], pko, 0, parts_in=p_q[:Ko])                 # consumer with its own (polled) 4-way split
+    torch.cuda.synchronize()
+    assert torch.equal(ops.parts_finish(p_d, dtype=dtype), y_d.view(-1))                  # same 4-way split: the reducer's bits
+    yq2 = ops.parts_finish(p_q, dtype=dtype)
+    assert (p_q[:, 2:] == 0).all()
+    assert po.rel_err(_np(yq2)[None, :], _np(y_q)) < (1e-3 if dtype == torch.float16 else 1e-2)     # 2-way split vs unsplit: fp32 order only
+    # o on the completed qkv output: the same launch shape in both routes -> the same bits
+    assert torch.equal(y_o2, pko.apply(yq2[None, :Ko].contiguous()))
+    ideal = po.paro_linear_merged(_np(yq2)[None, :Ko], Lo["qweight"], Lo["qzeros"], Lo["scales"], Lo["theta"], Lo["pairs"], Lo["channel_scales"],
+                                  [H], None, ideal=True)
+    assert po.rel_err(_np(y_o2), ideal) < tol
+    assert po.rel_err(_np(y_o2), _np(y_o)) < 20 * tol          # two chained linears amplify the rounding differences of their inputs
+    ops.check_workspace(pko.workspace)
