@@ -220,7 +220,9 @@ class DecodeStack:
         # (profiles/r03_parts_micro.jsonl): the in-launch hand-off is 1.3 .. 1.45 us of the producer's launch, completing the sums costs
         # the consumer 0.6 .. 0.8 us (every workgroup reads the four fp32 slots of every channel).
         if route == "auto":
-            route = "chain" if (rows > 1 and tp == 1) else "fused"    # (parts: -1.5 % .. +8 % per step on these stacks -- reported next to it, config.route_ab)
+            # one row, one GPU: parts (-2.8 % per step on Qwen3-4B, -2.4 % Llama-3-8B, -1.4 % Qwen3.5 hybrid, +0.3 % on Llama-3-70B shapes against the
+            # in-launch reducer, profiles/r03_parts_bench.jsonl; the other leg is reported next to it, config.route_ab)
+            route = "chain" if (rows > 1 and tp == 1) else ("parts" if (rows == 1 and tp == 1 and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0") else "fused")
         if route in ("chain", "parts") and tp != 1:
             raise SystemExit(f"the {route} route is single-GPU")
         if route == "parts" and rows != 1:
@@ -521,7 +523,7 @@ def parse_args(argv=None):
     ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain"],
                     help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
                          "launch (decode-chain family); parts = fused with the deferred K-split reduction of o / down (one row, one GPU); "
-                         "auto = fused at one row, chain at 2..16 rows (measured: profiles/r03_chain_rows_sweep.jsonl, r03_parts_bench.jsonl)")
+                         "auto = parts at one row on one GPU, chain at 2..16 rows, fused under tensor parallelism (measured: profiles/r03_chain_rows_sweep.jsonl, r03_parts_bench.jsonl)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-route-ab", action="store_true", help="skip the second one-row leg (the other of fused / parts) that `config.route_ab` reports")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -749,7 +751,8 @@ def run(args, rank: int, local_rank: int, world: int):
     elif pmc_file:
         pmc_reason = "the PMC summary describes the default one-row workload at full depth"
     roofline = {"bound": "hbm", "kernel": ("paro::chain_kernel (INT4 GEMV on rotated activations + the consumer's rotation in the epilogue"
-                                           if stack.route == "chain" else "paro::gemv_kernel (fused rotate+INT4 GEMV") + ", all launches of the step)",
+                                           if stack.route == "chain" else ("paro::gemv_kernel (fused rotate+INT4 GEMV; K-split reductions deferred into the consuming launch"
+                                                                           if stack.route == "parts" else "paro::gemv_kernel (fused rotate+INT4 GEMV")) + ", all launches of the step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": os.path.relpath(pmc_file, ROOT) if (pmc_file and traffic is not None) else None,

@@ -418,11 +418,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // with fewer units re-read their last unit) so that the compiler's vmcnt bookkeeping is exact: a wait
   // for coefficients never waits for the younger tile loads (vmcnt retires in order).
   auto load_t = [&](TBuf& b, int g) {
+    auto load_q = [&]() {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int jj = j < nt ? j : nt - 1;
-      b.q[j] = __builtin_nontemporal_load(wq_p + ((unsigned)((tile0 + jj) * h.tstride + g * h.gstride) * 64u + (unsigned)lane));
-    }
+      for (int j = 0; j < TPW; ++j) {
+        const int jj = j < nt ? j : nt - 1;
+        b.q[j] = __builtin_nontemporal_load(wq_p + ((unsigned)((tile0 + jj) * h.tstride + g * h.gstride) * 64u + (unsigned)lane));
+      }
+    };
+    // (PARTS_IN builds request the scale / zero words BEFORE the tiles: the register allocator copies the first unit's last-loaded
+    // words in front of the unit loop there, and a copy of the youngest request is a wait for everything -- the HBM tiles included)
+    if constexpr (!PARTS_IN) load_q();
 #pragma unroll
     for (int hq = 0; hq < QS; ++hq) {
       const unsigned grow = (unsigned)(g * QS + hq) * szrow;   // row of the scale/zero array = quantisation group
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         }
       }
     }
+    if constexpr (PARTS_IN) load_q();
   };
 
   // residual epilogue: the value this thread adds to its FIRST output is requested here, at kernel entry -- not as a
