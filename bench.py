@@ -222,7 +222,9 @@ class DecodeStack:
         if route == "auto":
             # one row, one GPU: parts (-2.8 % per step on Qwen3-4B, -2.4 % Llama-3-8B, -1.4 % Qwen3.5 hybrid, +0.3 % on Llama-3-70B shapes against the
             # in-launch reducer, profiles/r03_parts_bench.jsonl; the other leg is reported next to it, config.route_ab)
-            route = "chain" if (rows > 1 and tp == 1) else ("parts" if (rows == 1 and tp == 1 and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0") else "fused")
+            # (70B-class shapes, hidden >= 8192: the launches are long enough that the hand-off no longer shows -- fused)
+            route = "chain" if (rows > 1 and tp == 1) else ("parts" if (rows == 1 and tp == 1 and self.hidden < 8192
+                                                                        and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0") else "fused")
         if route in ("chain", "parts") and tp != 1:
             raise SystemExit(f"the {route} route is single-GPU")
         if route == "parts" and rows != 1:

@@ -17,10 +17,11 @@ def short(name: str) -> str:
     m = re.search(r"gemv_kernel<([^>]*)>", name)
     if m:
         return "paro::gemv_kernel<" + m.group(1).replace(" ", "") + ">"
-    m = re.search(r"gemv_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E", name)   # mangled
+    m = re.search(r"gemv_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E(?:Li(\d+)E)?", name)   # mangled
     if m:
         at = "f16" if m.group(1) == "DF16_" else "bf16"
-        return f"paro::gemv_kernel<{at},tpw={m.group(2)},rows<={m.group(3)},waves={m.group(4)},prerot={m.group(5)},pd={m.group(6)}>"
+        fused = f",fused={m.group(7)}" if m.group(7) not in (None, "0") else ""   # 1 / 2: prologue / residual builds, | 8: consumes partial sums
+        return f"paro::gemv_kernel<{at},tpw={m.group(2)},rows<={m.group(3)},waves={m.group(4)},prerot={m.group(5)},pd={m.group(6)}{fused}>"
     m = re.search(r"paro::(\w+)", name)
     if m:
         return "paro::" + m.group(1)
