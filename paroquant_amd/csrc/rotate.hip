@@ -154,8 +154,17 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
                                                          int nparts) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
-  constexpr int OP = 256;   // output staging pitch (a 272-byte pitch, conflict-free for the 2-byte D-fragment writes, measured equal)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * OP];
+  // What bounds this kernel is what a CU can take in through its vector-memory path (10..17 B / clock in this code base), not HBM:
+  // with every wave fetching its own copy of the group's 128 x 128 rotation matrix as B fragments, a workgroup pulled 128 KB of
+  // matrix per 64 KB of output (T = 80 + 200 P us at M = 65536; twice the waves per CU with half the rows each: 1.5x SLOWER).
+  // Now the matrix of (partition, group) comes into LDS ONCE per workgroup (LDS-DMA, 32 KB, 16-byte chunks XOR-swizzled by the row
+  // so that the 16 rows of a B fragment read conflict-free) and the four waves read their fragments from there.
+  // LDS: [0, 64 KB) the x tile (256 rows x 256 B) at first; then [0, 36 KB) output staging (per wave 64 rows x 64 columns, pitch
+  // 144 B), [36 KB, 68 KB) the rotation matrix.
+  constexpr int OP = 144;                       // staging pitch: rows 4 mq + r of a D fragment fall into different banks
+  constexpr int STG = 64 * OP;                  // bytes of staging per wave
+  constexpr int RM0 = 4 * STG;                  // 36864: rotation matrix tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RM0 + 128 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // blockIdx.x = group: the workgroups that run together cover whole rows of x (and of every rotated copy) -- consecutive DRAM
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
   const int G = K >> 7;
   const int n = lane & 15, mq = lane >> 4;
 
-  // stage X[row0 .. row0+255][g*128 .. +127]: wave w fills rows 64w .. 64w+63
+  // stage X[row0 .. row0+255][g*128 .. +127]: wave w fills rows 64w .. 64w+63 (its own rows)
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int row = wave * 64 + c * 4 + (lane >> 4);
@@ -174,8 +183,8 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + (wave * 64 + c * 4) * 256), 16, 0, 0);
   }
-  __syncthreads();
-
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (a wave reads only the rows it staged itself)
+  __builtin_amdgcn_wave_barrier();
   // A fragments of this wave's 64 rows (4 row tiles x 4 k-steps)
   vec8 af[4][4];
 #pragma unroll
@@ -184,43 +193,63 @@ __global__ __launch_bounds__(256) void rotate_mfma_kernel(const unsigned short* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[rt][i] = *(const vec8*)(lds + row * 256 + (((4 * i + mq) ^ (row & 15)) << 4));
   }
-  __syncthreads();  // the tile is now free: it becomes the output staging buffer
+  __syncthreads();  // every wave has its rows in registers: the tile becomes staging + matrix space
 
-  // every merged partition from the SAME staged activations (qkv: x is read once, not three times)
-  for (int p = 0; p < nparts; ++p) {
-    const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;  // [n][k], k contiguous
-    // the rotation matrix's B fragments one column tile ahead (they come from L2: a dependent round trip per tile otherwise)
-    vec8 bf[2][4];
+  // matrix of (p, g): rmat[p][g][n][k] (k contiguous, 256 B per output column n) -> LDS row n, chunk (k / 8) ^ (n & 15)
+  auto issue_rmat = [&](int p) {
+    const unsigned short* rp = rmat + (((int64_t)p * G + g) * 128) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bf[0][i] = *(const vec8*)(rp + n * 128 + 32 * i + 8 * mq);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      if (ct + 1 < 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bf[(ct + 1) & 1][i] = *(const vec8*)(rp + ((ct + 1) * 16 + n) * 128 + 32 * i + 8 * mq);
-      }
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[ct & 1][i], d);
-        // D: row = 4*mq + r, col = n  ->  LDS[row][ct*16 + n] (2-byte elements, row-major, pitch OP)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wave * 64 + rt * 16 + 4 * mq + r;
-          *(unsigned short*)(lds + row * OP + (ct * 16 + n) * 2) = A::from_f32(d[r]);
-        }
-      }
+    for (int c = 0; c < 8; ++c) {
+      const int row = (wave * 8 + c) * 4 + (lane >> 4);        // 4 rows of 16 chunks per wave instruction
+      const unsigned short* src = rp + row * 128 + (((lane & 15) ^ (row & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + RM0 + (wave * 8 + c) * 1024), 16, 0, 0);
     }
-    __syncthreads();
+  };
+  issue_rmat(0);
+  unsigned char* stg = lds + wave * STG;
+  for (int p = 0; p < nparts; ++p) {
+    // (the only requests younger than the matrix pieces are none at p = 0 and the previous partition's last 8 row stores after:
+    // vmcnt retires in order, so waiting for the pieces does not wait for those stores)
+    // (a partial last tile may skip store instructions whose rows are all out of range: count nothing there)
+    if (p == 0 || row0 + 256 > rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();                                      // the whole matrix has landed
     unsigned short* op = out + (int64_t)p * rows * K;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int row = (tid >> 4) + 16 * c;
-      if (row0 + row < rows)
-        *(u32x4*)(op + (int64_t)(row0 + row) * K + g * 128 + (tid & 15) * 8) = *(const u32x4*)(lds + row * OP + (tid & 15) * 16);
+    for (int hh = 0; hh < 2; ++hh) {                      // 64 output columns at a time through the staging buffer
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int ct = hh * 4 + c4;
+        vec8 bf[4];
+        const int brow = ct * 16 + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = *(const vec8*)(lds + RM0 + brow * 256 + (((4 * i + mq) ^ (brow & 15)) << 4));
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) d = A::mfma(af[rt][i], bf[i], d);
+          // D: row = 4*mq + r, col = n  ->  staging[row][c4*16 + n]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *(unsigned short*)(stg + (rt * 16 + 4 * mq + r) * OP + (c4 * 16 + n) * 2) = A::from_f32(d[r]);
+        }
+      }
+      if (hh == 1) {
+        // every wave is done with this partition's matrix: the next one is requested BEFORE the stores below
+        __syncthreads();
+        if (p + 1 < nparts) issue_rmat(p + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int row = (lane >> 3) + 8 * c;                 // the wave's own rows: 128 contiguous bytes per 8 lanes
+        if (row0 + wave * 64 + row < rows)
+          *(u32x4*)(op + (int64_t)(row0 + wave * 64 + row) * K + g * 128 + hh * 64 + (lane & 7) * 8) = *(const u32x4*)(stg + row * OP + (lane & 7) * 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next half overwrites them
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();   // the staging tile is reused by the next partition
   }
 }
 
