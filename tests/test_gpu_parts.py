@@ -179,3 +179,71 @@ def test_parts_chain_consumer_is_producer(dev, dtype, tol):
     assert po.rel_err(_np(y_o2), ideal) < tol
     assert po.rel_err(_np(y_o2), _np(y_o)) < 20 * tol          # two chained linears amplify the rounding differences of their inputs
     ops.check_workspace(pko.workspace)
+
+
+def _parts_fuzz_cases(n=48):
+    rng = np.random.default_rng(1203)
+    out = []
+    for i in range(n):
+        Gp = int(rng.integers(2, 40))                       # producer groups (K = 128 Gp)
+        n_parts = int(rng.integers(2, min(4, Gp) + 1))
+        gps = -(-Gp // n_parts)
+        n_parts = -(-Gp // gps)                             # empty slices are dropped by the launch: ask for what K / 128 divides into
+        H = int(rng.integers(1, 17)) * 128                  # producer N = consumer K
+        P = int(rng.integers(1, 4))
+        sizes = [int(rng.integers(1, 60)) * 16 for _ in range(P)]
+        if i % 6 == 0:
+            sizes[0] = int(rng.integers(64, 200)) * 16      # a wide consumer now and then
+        out.append((i, Gp * 128, n_parts, H, tuple(sizes), i % 3, 64 if i % 5 == 1 else 128, bool(i % 2), int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("case,Kp,n_parts,H,sizes,consumer,gs,use_bf16,producer_prologue", _parts_fuzz_cases())
+def test_random_shapes_deferred_reduction(dev, case, Kp, n_parts, H, sizes, consumer, gs, use_bf16, producer_prologue):
+    """Seeded random (producer, consumer) pairs: any split count K / 128 allows, ragged consumers, both group sizes, both dtypes;
+    the consumer with the RMSNorm prologue (+ x_out), plain with x_out (unsplit), or plain without (it may split K itself).
+    The producer plain or behind the SiLU * mul prologue.  Against the oracle, stage by stage on the GPU's own intermediate."""
+    from paroquant_amd import ops, _native as nat
+    sizes = list(sizes)
+    dt = torch.bfloat16 if use_bf16 else torch.float16
+    tol = 2e-2 if use_bf16 else TIGHT_F16
+    Lp, Lc = po.make_layer(5000 + case, Kp, [H], group_size=gs), po.make_layer(6000 + case, H, sizes, group_size=gs)
+    pp, pc = _packed(Lp, dev), _packed(Lc, dev)
+    rng = np.random.default_rng(case)
+    h0 = _t((rng.standard_normal((1, H)) * 1.5).astype(np.float32), dev).to(dt)
+    parts = torch.full((H, 4), float("nan"), device=dev, dtype=torch.float32)
+    if producer_prologue == 2:
+        xin = _t(rng.standard_normal((1, 2 * Kp)).astype(np.float32), dev).to(dt)
+        xeff = po.silu_mul(xin.float().cpu().numpy(), Kp)
+        ops.w4a16_gemv_fused(xin, pp, nat.PROLOGUE_SILU_MUL, parts_out=parts, parts_n=n_parts)
+    else:
+        xin = _t(rng.standard_normal((1, Kp)).astype(np.float32), dev).to(dt)
+        xeff = xin.float().cpu().numpy()
+        ops.w4a16_gemv_fused(xin, pp, 0, parts_out=parts, parts_n=n_parts)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts).all() and (parts[:, n_parts:] == 0).all()
+    y_p = po.paro_linear_merged(xeff, Lp["qweight"], Lp["qzeros"], Lp["scales"], Lp["theta"], Lp["pairs"], Lp["channel_scales"], [H], None,
+                                group_size=gs, ideal=True)
+    assert po.rel_err(parts.double().sum(1)[None, :].cpu().numpy(), y_p) < tol
+    h1_ref = ops.parts_finish(parts, h0.view(-1))
+    assert po.rel_err(_np(h1_ref)[None, :], y_p + _np(h0)) < tol
+    h1 = torch.zeros(H, device=dev, dtype=dt)
+    if consumer == 0:      # RMSNorm prologue, the new residual stream written
+        w = (1.0 + 0.2 * rng.standard_normal(H)).astype(np.float16)
+        pc = pc.fold_norm_weight(_t(w, dev))
+        y = ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_RMSNORM, 1e-6, parts_in=parts, x_out=h1)
+        x_c = po.rmsnorm(_np(h1_ref)[None, :].astype(np.float32), w, 1e-6)
+        assert torch.equal(h1, h1_ref)
+    elif consumer == 1:    # plain, unsplit (x_out asked for)
+        y = ops.w4a16_gemv_fused(h0, pc, 0, parts_in=parts, x_out=h1)
+        x_c = _np(h1_ref)[None, :]
+        assert torch.equal(h1, h1_ref)
+    else:                  # plain, free to split K
+        y = ops.w4a16_gemv_fused(h0, pc, 0, parts_in=parts)
+        x_c = _np(h1_ref)[None, :]
+    ideal = po.paro_linear_merged(x_c, Lc["qweight"], Lc["qzeros"], Lc["scales"], Lc["theta"], Lc["pairs"], Lc["channel_scales"], sizes, None,
+                                  group_size=gs, ideal=True)
+    got = _np(y)
+    assert y.dtype == dt and np.isfinite(got).all()
+    assert po.rel_err(got, ideal) < tol
+    ops.check_workspace(pc.workspace)
