@@ -224,6 +224,10 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
  *            parts_out_n: paro_gemv_parts_count(L) -- the split of the launch shape chosen for a launch nobody polls in (the
  *            narrow deep linears as in the automatic shape; mid-width ones such as qkv split 2-way); 0 = this layer does
  *            not split, use the ordinary route -- or any 2..PARO_MAX_PARTIALS that K / 128 can be cut into.
+ *            RMSNorm prologue + parts_out: no workgroup of a K-split launch sees all of x, so the norm's scalar travels with the
+ *            partial sums: the buffer is [N + 1][PARO_MAX_PARTIALS], the partial sums are UN-normalised and row N holds the K-slices'
+ *            sums of squares in the same slots; the consumer multiplies by rsqrt(sum(row N) / K + eps) (paro_attn_decode_parts for
+ *            the qkv projection: each q / k / v element is read by one workgroup there, so completing it costs next to nothing).
  *            paro_parts_finish completes the sum without a linear behind it (the last layer's down_proj in front of the
  *            final norm): out[k] = round(x[k] + sum) in the same order; x may be NULL.
  * rows <= 4, krot <= 8 (in-kernel rotation); the launch shape is chosen automatically. */
@@ -324,6 +328,15 @@ int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, con
                      const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads, int n_kv_heads,
                      int head_dim, int max_positions, int act_dtype, void* workspace, int64_t workspace_bytes,
                      void* stream);
+/* v12: the same with q / k / v arriving as the partial sums a K-split qkv projection left (paro_fusion_t.parts_out):
+ *   qkv_parts  fp32 [(n_heads + 2 n_kv_heads) * head_dim + 1][PARO_MAX_PARTIALS]
+ *   element    = round((((p0 + p1) + p2) + p3) * rstd) in act_dtype -- what the projection's own epilogue would have stored --,
+ *                rstd = rsqrt(sum(last row) / norm_dim + norm_eps) when norm_dim > 0 (the projection ran with the RMSNorm prologue
+ *                over norm_dim = hidden channels), 1 when norm_dim == 0. */
+int paro_attn_decode_parts(const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache, void* out,
+                           const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w, float eps,
+                           float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Tail of a decode step (decode harness): final RMSNorm + the unquantised lm_head as an HBM-bound
  * fp16 / bf16 matrix-vector product, then the greedy argmax.

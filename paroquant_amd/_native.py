@@ -42,6 +42,7 @@ EXPORTS = (
     "paro_w4a16_gemv_experts",
     "paro_attn_decode_workspace_bytes",
     "paro_attn_decode",
+    "paro_attn_decode_parts",
     "paro_lm_head_workspace_bytes",
     "paro_lm_head",
     "paro_argmax_advance",
@@ -172,6 +173,9 @@ def load() -> ctypes.CDLL:
     lib.paro_attn_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                                      c_void_p]
+    lib.paro_attn_decode_parts.restype = c_int
+    lib.paro_attn_decode_parts.argtypes = [c_void_p, c_int64, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]
     lib.paro_lm_head_workspace_bytes.restype = c_int64
     lib.paro_lm_head_workspace_bytes.argtypes = [c_int64]
     lib.paro_lm_head.restype = c_int

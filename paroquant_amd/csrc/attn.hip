@@ -28,6 +28,11 @@ constexpr int attn_chunk(int max_positions) { return max_positions <= 512 ? 256 
 
 struct AttnArgs {
   const unsigned short* qkv;   // [(Hq + 2 Hkv) * hd]: q heads, k heads, v heads of this token
+  // PARTS builds: the same vector as the fp32 partial sums a K-split qkv projection left (paro_fusion_t.parts_out): [N + 1][4], N = (Hq + 2 Hkv) hd;
+  // value = round(((p0 + p1) + p2) + p3) * rstd), rstd = rsqrt(sum(row N) / norm_dim + norm_eps) when norm_dim > 0 (the projection's RMSNorm
+  // prologue, whose scalar a K-split launch cannot apply itself), else 1
+  const f32x4* qkv_parts;
+  float norm_dim, norm_eps;
   unsigned short* kcache;      // [Hkv][T_max][hd]
   unsigned short* vcache;      // [Hkv][hd][T_max]  (position-contiguous: the P V product's MFMA B fragments are 16-byte loads)
   unsigned short* out;         // [Hq * hd]
@@ -78,7 +83,7 @@ __device__ __forceinline__ float wave_sum(float v) {   // the same value in ever
 // scores on the matrix cores (the new key patched into the K fragments) -> soft-max of each wave's 64 positions in
 // registers (DPP row reductions, no LDS, no barrier) -> P V of the wave's own rows -> ONE barrier -> the four waves'
 // (max, sum, partial output) triples merged like chunks are.
-template <typename AT, int HD, int NREP, int CH>
+template <typename AT, int HD, int NREP, int CH, bool PARTS>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   constexpr int kChunk = CH;                   // positions of a workgroup
   constexpr int WP = CH / 4;                   // positions of a wave (64 / 32)
@@ -111,18 +116,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const bool act = lane < half;
   const int li = act ? lane : 0;
   float x0[ITER], x1[ITER], w0[ITER], w1[ITER];
+  f32x4 pn = {0.f, 0.f, 0.f, 0.f};            // PARTS: the projection's partial sums of squares
+  if constexpr (PARTS) pn = a.qkv_parts[(a.Hq + 2 * a.Hkv) * hd];
+  f32x4 pq0[PARTS ? ITER : 1], pq1[PARTS ? ITER : 1], pv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int v = min(wave + 4 * it, n_rep);
     const bool isk = v == n_rep;
-    const unsigned short* src = isk ? a.qkv + (int64_t)a.Hq * hd + (int64_t)h * hd : a.qkv + ((int64_t)h * n_rep + v) * hd;
-    x0[it] = A::to_f32(src[li]);
-    x1[it] = A::to_f32(src[li + half]);
+    const int col0 = isk ? a.Hq * hd + h * hd : (h * n_rep + v) * hd;
+    if constexpr (PARTS) {
+      pq0[it] = a.qkv_parts[col0 + li];
+      pq1[it] = a.qkv_parts[col0 + li + half];
+    } else {
+      x0[it] = A::to_f32(a.qkv[col0 + li]);
+      x1[it] = A::to_f32(a.qkv[col0 + li + half]);
+    }
     const unsigned short* nw = isk ? a.knw : a.qnw;
     w0[it] = nw ? A::to_f32(nw[li]) : 1.f;
     w1[it] = nw ? A::to_f32(nw[li + half]) : 1.f;
   }
-  const unsigned short vnew = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + (tid < hd ? tid : 0)];   // this token's v[tid]
+  unsigned short vnew = 0;                                                                                    // this token's v[tid]
+  if constexpr (PARTS) pv = a.qkv_parts[(a.Hq + a.Hkv) * hd + h * hd + (tid < hd ? tid : 0)];
+  else vnew = a.qkv[(int64_t)(a.Hq + a.Hkv) * hd + (int64_t)h * hd + (tid < hd ? tid : 0)];
   // The position, through the scalar cache (one ~300-cycle round trip): chunks beyond it leave at once; nothing past
   // the chunk's last position is requested below (a CU ingests ~13 B / clock: the 128 KiB of a full chunk are ~4.5 us,
   // the floor of this kernel).
@@ -134,6 +149,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position
   const float* rp = a.rope + (int64_t)pos * hd;
   const float rope_c = rp[li], rope_s = rp[half + li];
+  if constexpr (PARTS) {
+    // complete q / k / v: the reducer's summation order, the projection's norm scalar, ONE rounding to the activation type (what the
+    // projection's own epilogue would have stored)
+    const float rstd = a.norm_dim > 0.f ? __builtin_amdgcn_rsqf((((pn[0] + pn[1]) + pn[2]) + pn[3]) / a.norm_dim + a.norm_eps) : 1.f;
+    auto fin = [&](const f32x4& p) { return A::from_f32((((p[0] + p[1]) + p[2]) + p[3]) * rstd); };
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      x0[it] = A::to_f32(fin(pq0[it]));
+      x1[it] = A::to_f32(fin(pq1[it]));
+    }
+    vnew = fin(pv);
+  }
   // ---- the chunk's K and V, all requested here (a dependent global access costs ~1-2 us at this occupancy), as MFMA B
   // fragments: wave w owns positions 64 w .. 64 w + 63 of the chunk.
   //   K [pos][dim]: tile t = positions 16 t .. + 15; lane (kb, mm) holds dims 32 i + 8 kb .. + 7 of position 16 t + mm: kw[t][i]
@@ -413,12 +440,14 @@ extern "C" int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads,
   return 256 + (int64_t)n_kv_heads * chunks * n_rep * (head_dim + 2) * 4;   // tickets (zero-filled by the caller once) + partials
 }
 
-extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
-                                const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads,
-                                int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
-  using namespace paro;
-  if (!qkv || !kcache || !vcache || !out || !pos || !rope) return fail(PARO_ERR_INVALID, "null pointer");
+namespace paro {
+static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache, void* out,
+                            const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w, float eps, float scale,
+                            int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  const bool parts = qkv_parts != nullptr;
+  if ((!qkv && !parts) || !kcache || !vcache || !out || !pos || !rope) return fail(PARO_ERR_INVALID, "null pointer");
+  if (parts && norm_dim < 0) return fail(PARO_ERR_INVALID, "norm_dim must be >= 0");
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0) return fail(PARO_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
   if (n_kv_heads > 64) return fail(PARO_ERR_UNSUPPORTED, "at most 64 KV heads");
   if (n_heads / n_kv_heads > 8) return fail(PARO_ERR_UNSUPPORTED, "at most 8 query heads per KV head (got %d)", n_heads / n_kv_heads);
@@ -432,6 +461,9 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
     return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;
   a.qkv = (const unsigned short*)qkv;
+  a.qkv_parts = (const f32x4*)qkv_parts;
+  a.norm_dim = (float)norm_dim;
+  a.norm_eps = norm_eps;
   a.kcache = (unsigned short*)kcache;
   a.vcache = (unsigned short*)vcache;
   a.out = (unsigned short*)out;
@@ -458,8 +490,11 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
   const int nr = n_rep <= 1 ? 1 : (n_rep <= 2 ? 2 : (n_rep <= 4 ? 4 : 8));
 #define PARO_ATTN_LAUNCH(T, HD, NR) \
   do { \
-    if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128>), grid, dim3(256), 0, st, a); \
+    if (parts) { \
+      if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256, true>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, true>), grid, dim3(256), 0, st, a); \
+    } else if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256, false>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, false>), grid, dim3(256), 0, st, a); \
   } while (0)
 #define PARO_ATTN_NR(T, HD) \
   do { \
@@ -476,4 +511,22 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
 #undef PARO_ATTN_NR
 #undef PARO_ATTN_LAUNCH
   return check_launch("paro_attn_decode");
+}
+}  // namespace paro
+
+extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
+                                const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads,
+                                int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  return paro::attn_decode_impl(qkv, nullptr, 0, 0.f, kcache, vcache, out, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads, n_kv_heads, head_dim,
+                                max_positions, act_dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int paro_attn_decode_parts(const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache, void* out,
+                                      const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w, float eps,
+                                      float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!qkv_parts) return paro::fail(PARO_ERR_INVALID, "null pointer");
+  return paro::attn_decode_impl(nullptr, qkv_parts, norm_dim, norm_eps, kcache, vcache, out, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads,
+                                n_kv_heads, head_dim, max_positions, act_dtype, workspace, workspace_bytes, stream);
 }

@@ -216,20 +216,13 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (L->krot > 8 || mode == 1 || mode == 2) return fail(PARO_ERR_UNSUPPORTED, "partial sums need the in-kernel rotation (krot <= 8, mode 0)");
   }
   if (pout) {
-    if (pin && F->prologue != PARO_PROLOGUE_NONE) return fail(PARO_ERR_UNSUPPORTED, "a launch that receives AND leaves partial sums splits K: not with the RMSNorm prologue (the norm needs all of K per workgroup)");
     if (F->parts_out_n < 2 || F->parts_out_n > PARO_MAX_PARTIALS) return fail(PARO_ERR_INVALID, "parts_out_n must be in 2..%d (got %d): a launch that does not split K writes y itself", PARO_MAX_PARTIALS, F->parts_out_n);
     if (F->residual || L->bias) return fail(PARO_ERR_UNSUPPORTED, "parts_out: residual and bias are added where the partial sums are completed; this launch takes neither");
-    if (F->prologue == PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
     if (ksplit != 0 && ksplit != F->parts_out_n) return fail(PARO_ERR_INVALID, "ksplit %d contradicts parts_out_n %d", ksplit, F->parts_out_n);
   }
   if (pin) {
     if (F->prologue != PARO_PROLOGUE_NONE && F->prologue != PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_UNSUPPORTED, "parts_in feeds the plain or the RMSNorm prologue");
     if (F->x_out && F->x_out == x) return fail(PARO_ERR_INVALID, "x_out must not alias x (other workgroups still read it)");
-    if (F->x_out && pout) return fail(PARO_ERR_UNSUPPORTED, "x_out is written by launches that do not split K; this one leaves partial sums");
-    if (F->x_out) {    // the completed x is written by one workgroup that covers all of K
-      if (ksplit > 1) return fail(PARO_ERR_INVALID, "x_out: the launch must not K-split");
-      ksplit = 1;
-    }
   }
   if (E) {
     if (!F) F = &no_fusion;
@@ -246,7 +239,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (mode == 1 || mode == 2) return fail(PARO_ERR_INVALID, "fused prologue / epilogue needs mode 0 (in-kernel rotation)");
     mode = 0;
     // sum(x^2) of the RMSNorm prologue is collected per workgroup: every workgroup must cover all of K
-    if (F->prologue == PARO_PROLOGUE_RMSNORM) {
+    // ... unless the launch leaves partial sums (parts_out): the partial sums of squares travel with them (row N) and the consumer scales
+    if (F->prologue == PARO_PROLOGUE_RMSNORM && !pout) {
       if (ksplit > 1) return fail(PARO_ERR_INVALID, "the RMSNorm prologue cannot be combined with a K-split");
       ksplit = 1;
     }

@@ -954,6 +954,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   }
   if (ks_handoff && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
+  if constexpr (FMODE == 1) {
+    // RMSNorm prologue on a launch that leaves partial sums: no workgroup sees all of K, so the norm's scalar travels with the partial
+    // sums -- row N of the buffer gets this K-slice's sum of squares (same slot order, unused slots zero) and whoever completes the
+    // sums scales them by rsqrt(sum / K + eps) (the attention kernel for qkv, attn.hip)
+    if (h.parts_out && h.prologue == PARO_PROLOGUE_RMSNORM && cb == 0 && tid == 0) {
+      float ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) ss += ssl[w * MB];
+      float* pr = (float*)a.slabs + (int64_t)h.N * 4;
+      const bool last = ks == h.ksplit - 1;
+      pr[last ? 0 : ks + 1] = ss;
+      if (last) for (int q = h.ksplit; q < 4; ++q) pr[q] = 0.f;
+    }
+  }
   if constexpr (DIAG == 3) {
     ts[6] = __builtin_amdgcn_s_memtime();
     // 80 words per workgroup: wave 0's phase stamps [0..8], HW_ID | XCC_ID << 32 [9], stages done [10], then

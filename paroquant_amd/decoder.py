@@ -19,8 +19,11 @@ On one GPU the K-split reduction of o and down is DEFERRED (include/paro_abi.h v
 fp32 partial sums and exit -- no in-launch hand-off (1.3 .. 1.45 us per launch) --, and the RMSNorm-prologue launch behind them
 (gate_up; the next layer's qkv) adds them to the residual stream while it seeds its rotation and writes the new stream (0.6 .. 0.8 us:
 every workgroup reads the four fp32 slots of every channel).  Same launches, same bits (tests/test_gpu_parts.py,
-tests/test_gpu_parity.py::test_decoder_harness_deferred_matches_reducer); Qwen3-4B 691 -> 710 tokens/s, Llama-3-8B 614 -> 625
-(profiles/r03_e2e.jsonl vs r03_e2e_reducer.jsonl).  ``PARO_DEFERRED_KSPLIT=0`` keeps the in-launch reducer.
+tests/test_gpu_parity.py::test_decoder_harness_deferred_matches_reducer); Qwen3-4B 691 -> 718 tokens/s, Llama-3-8B 612 -> 628
+(profiles/r03_e2e.jsonl vs r03_e2e_reducer.jsonl).  ``PARO_DEFERRED_KSPLIT=0`` keeps the in-launch reducer.  The qkv projection
+defers too where its launch shape splits (2-way): its partial sums and the K-slices' sums of squares go to the attention kernel,
+which completes q / k / v as it reads them (``PARO_DEFERRED_QKV=0``: off; the summation order of qkv changes, so this part is equal
+to the reducer route within rounding, not bit for bit).
 
 Embedding lookup, final norm, the (unquantised, fp16) lm_head and the greedy argmax are plain torch ops inside the
 same graph; the token and position live in device tensors, so a replay is one whole token with no host round trip.
@@ -315,6 +318,12 @@ class ParoDecoderLM:
         if self.deferred:
             self.parts_o = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
             self.parts_d = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
+        # ... and of qkv (2-way in the launch shape nobody polls in): its consumer is the attention kernel, where each q / k / v element
+        # is read by ONE workgroup; the RMSNorm scalar travels as the K-slices' sums of squares (row N).  PARO_DEFERRED_QKV=0: off
+        self.deferred_qkv = self.deferred and min(ops.gemv_parts_count(L.qkv, dt) for L in self.layers) >= 2 \
+            and os.environ.get("PARO_DEFERRED_QKV", "1") != "0"
+        if self.deferred_qkv:
+            self.parts_q = torch.zeros(qkv_w + 1, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
@@ -375,14 +384,16 @@ class ParoDecoderLM:
         R, S = nat.PROLOGUE_RMSNORM, nat.PROLOGUE_SILU_MUL
         cur, other = self.h, self.h2
         pend = None
+        qkv_to = dict(parts_out=self.parts_q) if self.deferred_qkv else dict(out=self.qkv_buf)
         for L in self.layers:
             if pend is None:
-                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, out=self.qkv_buf)
+                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, **qkv_to)
             else:
-                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, out=self.qkv_buf, parts_in=pend, x_out=other.view(-1))
+                ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, parts_in=pend, x_out=other.view(-1), **qkv_to)
                 cur, other = other, cur
-            ops.attn_decode(self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv, c.head_dim,
-                            L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws)
+            ops.attn_decode(self.parts_q if self.deferred_qkv else self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv,
+                            c.head_dim, L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws, norm_dim=c.hidden,
+                            norm_eps=c.rms_eps)
             ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, parts_out=self.parts_o)
             ops.w4a16_gemv_fused(cur, L.gate_up, R, c.rms_eps, out=self.gu_buf, parts_in=self.parts_o, x_out=other.view(-1))
             cur, other = other, cur

@@ -344,7 +344,8 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     rows = x2.size(0)
     if x.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"expected float16 or bfloat16 activations, got {x.dtype}")
-    for name, t, width_t in (("parts_out", parts_out, N), ("parts_in", parts_in, K)):
+    # (with the RMSNorm prologue a producer also leaves its K-slices' sums of squares: one more row)
+    for name, t, width_t in (("parts_out", parts_out, N + (1 if prologue == nat.PROLOGUE_RMSNORM else 0)), ("parts_in", parts_in, K)):
         if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (width_t, nat.PARO_MAX_PARTIALS) or not t.is_contiguous()
                               or t.device != x.device):
             raise ValueError(f"{name} must be a contiguous float32 [{width_t}, {nat.PARO_MAX_PARTIALS}] tensor on {x.device}")
@@ -515,31 +516,43 @@ def attn_workspace(device, n_heads: int, n_kv_heads: int, head_dim: int, max_pos
 
 def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, rope: torch.Tensor,
                 n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
-                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, norm_dim: int = 0,
+                norm_eps: float = 1e-6) -> torch.Tensor:
     """One decoder layer's batch-1 attention in one launch (``paro_attn_decode``): q/k norm + RoPE + KV-cache append at
     ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache``: [n_kv_heads, T_max, head_dim];
     ``vcache``: [n_kv_heads, head_dim, T_max] (position-contiguous); T_max a multiple of 8; both must hold finite values
-    (allocate them zero-filled)."""
+    (allocate them zero-filled).  ``qkv`` is the merged projection's output in the cache dtype, or -- float32
+    ``[(n_heads + 2 n_kv_heads) * head_dim + 1, 4]`` -- the partial sums a K-split qkv projection left
+    (``w4a16_gemv_fused(..., parts_out=)``; ``paro_attn_decode_parts``): the kernel completes each element as it reads it, scaled by
+    ``rsqrt(sum(last row) / norm_dim + norm_eps)`` when ``norm_dim > 0`` (the projection ran with the RMSNorm prologue)."""
     lib = nat.load()
     T_max = kcache.size(1)
+    parts = qkv.dtype == torch.float32
+    act_dtype = kcache.dtype
     if tuple(kcache.shape) != (n_kv_heads, T_max, head_dim) or tuple(vcache.shape) != (n_kv_heads, head_dim, T_max) \
-            or not kcache.is_contiguous() or not vcache.is_contiguous() or kcache.dtype != qkv.dtype or vcache.dtype != qkv.dtype:
-        raise ValueError(f"caches must be contiguous {qkv.dtype} tensors: K [{n_kv_heads}, T, {head_dim}], V [{n_kv_heads}, {head_dim}, T] "
+            or not kcache.is_contiguous() or not vcache.is_contiguous() or vcache.dtype != act_dtype or (not parts and qkv.dtype != act_dtype):
+        raise ValueError(f"caches must be contiguous {act_dtype} tensors: K [{n_kv_heads}, T, {head_dim}], V [{n_kv_heads}, {head_dim}, T] "
                          f"(got K {tuple(kcache.shape)}, V {tuple(vcache.shape)})")
     if tuple(rope.shape) != (T_max, head_dim) or rope.dtype != torch.float32 or pos.dtype != torch.int32:
         raise ValueError("rope must be fp32 [T, head_dim] (cos then sin per position) and pos an int32 device scalar")
-    y = out if out is not None else torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
-    if out is not None and (out.numel() != n_heads * head_dim or out.dtype != qkv.dtype or not out.is_contiguous() or out.device != qkv.device):
-        raise ValueError(f"out must be a contiguous tensor of {n_heads * head_dim} {qkv.dtype} elements on {qkv.device}")
-    if qkv.numel() != (n_heads + 2 * n_kv_heads) * head_dim or not qkv.is_contiguous():
-        raise ValueError(f"qkv must be a contiguous vector of (n_heads + 2 n_kv_heads) * head_dim = {(n_heads + 2 * n_kv_heads) * head_dim} elements")
+    y = out if out is not None else torch.empty(n_heads * head_dim, dtype=act_dtype, device=qkv.device)
+    if out is not None and (out.numel() != n_heads * head_dim or out.dtype != act_dtype or not out.is_contiguous() or out.device != qkv.device):
+        raise ValueError(f"out must be a contiguous tensor of {n_heads * head_dim} {act_dtype} elements on {qkv.device}")
+    n_qkv = (n_heads + 2 * n_kv_heads) * head_dim
+    if parts:
+        if tuple(qkv.shape) != (n_qkv + 1, nat.PARO_MAX_PARTIALS) or not qkv.is_contiguous():
+            raise ValueError(f"partial sums of qkv must be a contiguous float32 [{n_qkv + 1}, {nat.PARO_MAX_PARTIALS}] tensor")
+    elif qkv.numel() != n_qkv or not qkv.is_contiguous():
+        raise ValueError(f"qkv must be a contiguous vector of (n_heads + 2 n_kv_heads) * head_dim = {n_qkv} elements")
     ws = workspace if workspace is not None else attn_workspace(qkv.device, n_heads, n_kv_heads, head_dim, T_max)
+    tail = (kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(), rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
+            None if k_norm_w is None else k_norm_w.data_ptr(), float(eps), float(head_dim) ** -0.5, n_heads, n_kv_heads, head_dim, T_max,
+            nat.dtype_code(act_dtype), ws.data_ptr(), ws.numel(), nat.current_stream_ptr(qkv.device))
     with torch.cuda.device(qkv.device):
-        nat.check(lib.paro_attn_decode(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(),
-                                       rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
-                                       None if k_norm_w is None else k_norm_w.data_ptr(), float(eps), float(head_dim) ** -0.5,
-                                       n_heads, n_kv_heads, head_dim, T_max, nat.dtype_code(qkv.dtype), ws.data_ptr(),
-                                       ws.numel(), nat.current_stream_ptr(qkv.device)))
+        if parts:
+            nat.check(lib.paro_attn_decode_parts(qkv.data_ptr(), int(norm_dim), float(norm_eps), *tail))
+        else:
+            nat.check(lib.paro_attn_decode(qkv.data_ptr(), *tail))
     return y
 
 

@@ -1291,8 +1291,9 @@ def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
     from paroquant_amd.decoder import ParoDecoderLM, DecoderConfig
     cfg = lambda: DecoderConfig(512, 2048, 16, 2, 128, 3, 640, 1e-6, 10000.0, True, 64)     # o: 2048 -> 512, down: 2048 -> 512: both K-split
     ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
+    monkeypatch.setenv("PARO_DEFERRED_QKV", "0")           # (the 2-way qkv changes qkv's own summation order: its own test below)
     lm_d = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
-    assert lm_d.deferred
+    assert lm_d.deferred and not lm_d.deferred_qkv
     monkeypatch.setenv("PARO_DEFERRED_KSPLIT", "0")
     lm_r = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
     assert not lm_r.deferred
@@ -1303,6 +1304,37 @@ def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
         assert torch.equal(lm_d.logits, lm_r.logits)
     from paroquant_amd import ops
     ops.check_workspace(lm_d.layers[0].o.workspace)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decoder_harness_deferred_qkv(dev, dtype, monkeypatch):
+    """qkv as a 2-way K-split producer whose partial sums (and sums of squares: its RMSNorm prologue) the attention kernel completes:
+    teacher-forced decode steps against the same model with qkv reduced in its own launch -- equal within rounding (the fp32 summation
+    order of qkv differs), KV caches included."""
+    from paroquant_amd.decoder import ParoDecoderLM, DecoderConfig
+    cfg = lambda: DecoderConfig(2048, 2048, 16, 2, 128, 2, 640, 1e-6, 10000.0, True, 64)     # qkv 2048 -> 2560: splits 2-way when nobody polls
+    ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
+    lm_q = ParoDecoderLM.random(cfg(), dev, seed=4, dtype=dtype)
+    assert lm_q.deferred and lm_q.deferred_qkv
+    monkeypatch.setenv("PARO_DEFERRED_QKV", "0")
+    lm_r = ParoDecoderLM.random(cfg(), dev, seed=4, dtype=dtype)
+    assert lm_r.deferred and not lm_r.deferred_qkv
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-3
+    lq, lr = lm_q.prefill(ids), lm_r.prefill(ids)
+    assert torch.equal(lq, lr)                               # the prefill path is the same code
+    for step in range(4):
+        lm_r.tok.copy_(lm_q.tok)                             # teacher forcing: both consume the same token
+        lm_q.decode_step(); lm_r.decode_step()
+        torch.cuda.synchronize()
+        a, b = lm_q.logits.float(), lm_r.logits.float()
+        assert torch.isfinite(a).all() and ((a - b).abs().max() / b.abs().max()).item() < tol, step
+    for Lq, Lr in zip(lm_q.layers, lm_r.layers):
+        n = int(lm_q.pos.item())
+        assert ((Lq.kcache[:, :n].float() - Lr.kcache[:, :n].float()).abs().max() / Lr.kcache[:, :n].float().abs().max()).item() < tol
+        assert ((Lq.vcache[:, :, :n].float() - Lr.vcache[:, :, :n].float()).abs().max() / Lr.vcache[:, :, :n].float().abs().max()).item() < tol
+    tq, _ = lm_q.generate(ids, 6, use_graph=True)            # and the graph replay runs
+    assert tq.numel() == ids.numel() + 6
 
 
 @pytest.mark.gpu

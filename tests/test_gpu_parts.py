@@ -134,11 +134,8 @@ def test_parts_argument_errors(dev):
                              nat.PROLOGUE_SILU_MUL, parts_in=parts)
     with pytest.raises(RuntimeError, match="alias"):
         ops.w4a16_gemv_fused(h, pc, nat.PROLOGUE_RMSNORM, parts_in=parts, x_out=h.view(-1))
-    with pytest.raises(RuntimeError, match="not with the RMSNorm prologue"):
-        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), nat.PROLOGUE_RMSNORM, parts_in=parts, parts_out=parts, parts_n=2)
-    with pytest.raises(RuntimeError, match="x_out is written by launches that do not split K"):
-        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), parts_in=parts, parts_out=parts.clone(), parts_n=2,
-                             x_out=torch.zeros(512, device=dev, dtype=torch.float16))
+    with pytest.raises(ValueError, match="513"):            # an RMSNorm-prologue producer also leaves its sums of squares: one more row
+        ops.w4a16_gemv_fused(h, _packed(po.make_layer(3, 512, [512]), dev), nat.PROLOGUE_RMSNORM, parts_in=parts, parts_out=parts.clone(), parts_n=2)
     with pytest.raises(ValueError, match="x_out"):
         ops.w4a16_gemv_fused(h, pc, x_out=h.view(-1).clone())
     assert ops.gemv_parts_count(_packed(po.make_layer(4, 256, [4096]), dev)) == 0      # wide output, shallow K: no split
@@ -247,3 +244,62 @@ def test_random_shapes_deferred_reduction(dev, case, Kp, n_parts, H, sizes, cons
     assert y.dtype == dt and np.isfinite(got).all()
     assert po.rel_err(got, ideal) < tol
     ops.check_workspace(pc.workspace)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, TIGHT_F16), (torch.bfloat16, TIGHT_BF16)])
+@pytest.mark.parametrize("Hq,Hkv,hd,qk_norm,pos", [(32, 8, 128, True, 300), (16, 2, 128, False, 0), (8, 4, 64, True, 37)])
+def test_qkv_partial_sums_completed_by_attention(dev, dtype, tol, Hq, Hkv, hd, qk_norm, pos):
+    """The qkv projection with the RMSNorm prologue as a 2-way K-split producer: un-normalised partial sums + the K-slices' sums of squares
+    (row N); the attention kernel completes q / k / v as it reads them.  Against the oracle (norm -> linear -> attention) and against
+    the attention kernel on the ordinary projection's output."""
+    from paroquant_amd import ops, _native as nat
+    K, sizes = 2560, [Hq * hd, Hkv * hd, Hkv * hd]
+    N = sum(sizes)
+    L = po.make_layer(Hq + pos, K, sizes)
+    rng = np.random.default_rng(Hq * 7 + pos)
+    w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+    x = _t((rng.standard_normal((1, K)) * 2.0).astype(np.float32), dev, dtype)
+    assert ops.gemv_parts_count(pk, dtype) == 2
+    parts = torch.full((N + 1, 4), float("nan"), device=dev, dtype=torch.float32)
+    ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6, parts_out=parts)
+    y_ref = ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6)                      # the ordinary launch: unsplit, norm applied in its epilogue
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts).all() and (parts[:, 2:] == 0).all()
+    ss = float(parts[N].sum())
+    assert abs(ss - float((x.float() ** 2).sum())) < 1e-4 * ss                           # row N: the K-slices' sums of squares
+    y_c = (parts[:N].sum(1) * torch.rsqrt(parts[N].sum() / K + 1e-6)).to(dtype)
+    assert po.rel_err(_np(y_c)[None, :], _np(y_ref)) < (1e-3 if dtype == torch.float16 else 1e-2)
+    ideal = po.paro_linear_merged(po.rmsnorm(_np(x).astype(np.float32), w, 1e-6), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
+                                  L["channel_scales"], sizes, None, ideal=True)
+    assert po.rel_err(_np(y_c)[None, :], ideal) < tol
+    with pytest.raises(ValueError, match="float32"):                                     # the RMSNorm producer needs the extra row
+        ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6, parts_out=parts[:N])
+    # ---- attention on the partial sums vs on the ordinary projection's output
+    T = 512
+    kc = _t(rng.standard_normal((Hkv, T, hd)).astype(np.float32), dev, dtype)
+    vc = _t(rng.standard_normal((Hkv, hd, T)).astype(np.float32), dev, dtype)
+    qw = _t((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32), dev, dtype) if qk_norm else None
+    kw = _t((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32), dev, dtype) if qk_norm else None
+    cos, sin = po.rope_tables(hd, T, 1e4)
+    rope = torch.from_numpy(np.concatenate([cos, sin], axis=-1).astype(np.float32)).to(dev)
+    pt = torch.tensor([pos], dtype=torch.int32, device=dev)
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    o_parts = ops.attn_decode(parts, k1, v1, pt, rope, Hq, Hkv, hd, qw, kw, 1e-6, norm_dim=K, norm_eps=1e-6)
+    o_ref = ops.attn_decode(y_c.contiguous(), k2, v2, pt, rope, Hq, Hkv, hd, qw, kw, 1e-6)
+    torch.cuda.synchronize()
+    # (the kernel's rsqrt is the hardware approximation: an element may round the other way now and then)
+    atol = 2e-3 if dtype == torch.float16 else 2e-2
+    assert po.rel_err(_np(o_parts)[None, :], _np(o_ref)[None, :]) < atol
+    assert po.rel_err(_np(k1[:, pos]), _np(k2[:, pos])) < atol and po.rel_err(_np(v1[:, :, pos]), _np(v2[:, :, pos])) < atol
+    if pos > 0:
+        assert torch.equal(k1[:, :pos], kc[:, :pos]) and torch.equal(v1[:, :, :pos], vc[:, :, :pos])      # the rest of the cache is untouched
+    ref, _, _ = po.attention_decode(_np(y_c), _np(kc), np.ascontiguousarray(_np(vc).transpose(0, 2, 1)), pos, Hq, Hkv, hd, cos, sin,
+                                    None if qw is None else _np(qw), None if kw is None else _np(kw), 1e-6)
+    assert po.rel_err(_np(o_parts), ref) < (4e-3 if dtype == torch.float16 else 3e-2)
+    # norm_dim = 0: plain sums (a projection without the norm prologue)
+    p0 = torch.zeros(N + 1, 4, device=dev, dtype=torch.float32)
+    p0[:N, 0] = y_c.float() * 0.25
+    p0[:N, 1] = y_c.float() * 0.75
+    o_plain = ops.attn_decode(p0, kc.clone(), vc.clone(), pt, rope, Hq, Hkv, hd, qw, kw, 1e-6)
+    assert po.rel_err(_np(o_plain)[None, :], _np(o_ref)[None, :]) < atol
