@@ -303,3 +303,29 @@ def test_qkv_partial_sums_completed_by_attention(dev, dtype, tol, Hq, Hkv, hd, q
     p0[:N, 1] = y_c.float() * 0.75
     o_plain = ops.attn_decode(p0, kc.clone(), vc.clone(), pt, rope, Hq, Hkv, hd, qw, kw, 1e-6)
     assert po.rel_err(_np(o_plain)[None, :], _np(o_ref)[None, :]) < atol
+
+
+@pytest.mark.parametrize("K,sizes,n", [(1024, [256, 64, 64], 2), (1024, [512], 4), (384, [48, 16], 3), (4096, [1024, 512, 512], 2), (2048, [2560], 0)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_rmsnorm_producer_leaves_sums_of_squares(dev, K, sizes, n, dtype):
+    """RMSNorm prologue on a launch that leaves partial sums: un-normalised partials + the K-slices' sums of squares in row N, for splits
+    with fewer groups than waves, ragged partitions, forced and automatic split counts -- completed on the host they equal the ordinary
+    launch (norm applied in its own epilogue)."""
+    from paroquant_amd import ops, _native as nat
+    N = sum(sizes)
+    L = po.make_layer(K + N + n, K, sizes)
+    rng = np.random.default_rng(K + n)
+    w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+    x = _t((rng.standard_normal((1, K)) * 3.0).astype(np.float32), dev, dtype)
+    n_eff = n or ops.gemv_parts_count(pk, dtype)
+    assert n_eff >= 2
+    parts = torch.full((N + 1, 4), float("nan"), device=dev, dtype=torch.float32)
+    ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6, parts_out=parts, parts_n=n)
+    y_ref = ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts).all() and (parts[:, n_eff:] == 0).all() and (parts[N, :n_eff] > 0).all()
+    ss = float(parts[N].sum())
+    assert abs(ss - float((x.float() ** 2).sum())) < 1e-4 * ss
+    y_c = (parts[:N].sum(1) * torch.rsqrt(parts[N].sum() / K + 1e-6)).to(dtype)
+    assert po.rel_err(_np(y_c)[None, :], _np(y_ref)) < (1e-3 if dtype == torch.float16 else 1e-2)
