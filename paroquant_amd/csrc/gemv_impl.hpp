@@ -678,14 +678,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         seed(pc, sa, sb);
         if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = stamp_after(sa[0] + sb[0]); }
         if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
-#ifdef PARO_KROT8_FASTPATH   // experiment (make EXTRA=-DPARO_KROT8_FASTPATH, tools/ab_harness.cpp): the universal krot = 8 without the
-          // per-stage compare + branch.  Bit-identical; Qwen3-4B qkv 5.58 -> 5.37 us, down 7.35 -> 7.20, gate_up unchanged, but
-          // the 4-wave o_proj shape 4.82 -> 5.61 (profiles/r02_ab_krot8.jsonl): not on by default until that is understood
-          if (h.krot == 8) {
+          // the universal krot = 8 without the per-stage compare + branch, in the 8- and 16-wave builds (bit-identical; down_proj
+          // 7.58 -> 7.45 us on Qwen3-4B, 9.39 -> 9.08 on Llama-3-8B, the others within noise; in the 4-wave builds the same change
+          // cost o_proj 0.8 us in round 2 -- profiles/r02_ab_krot8.jsonl, r03_ab_krot8_w8.jsonl -- and stays out)
+          if (WAVES >= 8 && h.krot == 8) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) stage(pc, t, sa, sb);
           } else
-#endif
           {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
