@@ -18,8 +18,13 @@ static void chain_shape(int nblocks, int G, bool pair, int rows, int& ksplit, in
     if (ks < 1) ks = 1;
     if (ks > 16) ks = 16;
     if (ks > G) ks = G;
-    // more rows: the reducer's polls grow with rows x slices; keep the split small
-    if (rows > 4 && ks > 4) ks = 4;
+    // more rows: the reducer's polls grow with rows x slices; keep the split small -- but not as small as 4 everywhere
+    // (CHAIN_SWEEP at 8 / 16 rows, profiles/r03_chain_shape_sweep_rows.jsonl: deep K (down_proj) wants 8 slices at <= 8 rows
+    // -- Qwen3-4B 11.6 -> 9.8 us, Llama-3-8B 13.8 -> 12.4 -- and 5 at <= 16; the others 5 / 4: Qwen3-4B qkv at 8 rows 8.0 -> 7.2)
+    if (rows > 4) {
+      const int cap = rows <= 8 ? (G >= 64 ? 8 : 5) : (G >= 64 ? 5 : 4);
+      if (ks > cap) ks = cap;
+    }
     ksplit = ks;
   }
   if (ksplit > G) ksplit = G;
