@@ -13,6 +13,7 @@ int launch_rotate(const void* x, void* out, const int16_t* idx, const void* thet
 // chip once (~1 workgroup per CU); 4 waves when a K-slice has <= 4 groups per block, else 8.
 static void chain_shape(int nblocks, int G, bool pair, int rows, int& ksplit, int& waves) {
   const int cus = device_cu_count();
+  const bool auto_ks = ksplit <= 0;
   if (ksplit <= 0) {
     int ks = (cus + nblocks / 2) / nblocks;           // round(cus / blocks)
     if (ks < 1) ks = 1;
@@ -28,7 +29,10 @@ static void chain_shape(int nblocks, int G, bool pair, int rows, int& ksplit, in
     ksplit = ks;
   }
   if (ksplit > G) ksplit = G;
-  const int gps = (G + ksplit - 1) / ksplit;
+  int gps = (G + ksplit - 1) / ksplit;
+  // three groups per slice leave one of the four waves idle and cost more slices to poll: four, when the grid still covers half the
+  // chip (Qwen3-4B o_proj at 2..4 rows: 11 slices of 3 groups 7.5 us, 8 slices of 4 groups 6.5; profiles/r03_chain_shape_sweep_rows.jsonl)
+  if (auto_ks && !pair && gps == 3 && nblocks * ((G + 3) / 4) >= cus / 2) gps = 4;
   ksplit = (G + gps - 1) / gps;
   if (waves <= 0) waves = pair ? (gps <= 2 ? 4 : 8) : (gps <= 4 ? 4 : 8);
 }
