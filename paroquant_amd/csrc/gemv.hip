@@ -257,6 +257,14 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
   }
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
+  if (E && tpw == 0 && wv == 0) {
+    // expert slots: the grid is (column blocks) x (slots), so the slots fill the chip and fat column blocks cut the rotation every
+    // workgroup repeats: 4 tiles per wave, 8 waves from 16 groups of K on, else 4 (64 experts, top-8, 2048 / 768: one token 18.7 ->
+    // ~11.6 us per MoE block, four tokens 59.4 -> ~23; profiles/r03_moe_decode_shapes.txt)
+    const int64_t tiles_min = L->part_cols[0] / 16;
+    tpw = tiles_min >= 4 ? 4 : (tiles_min >= 2 ? 2 : 1);
+    wv = L->K / 128 >= 16 ? 8 : 4;
+  }
   rc = resolve_launch_shape(L, rows, tpw, ksp, wv, mode, pout);
   if (rc != PARO_OK) return rc;
   if (pout && ksp != F->parts_out_n) {

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--topk", type=int, default=8)
     ap.add_argument("--hidden", type=int, default=2048)
     ap.add_argument("--inter", type=int, default=768)
-    ap.add_argument("--tokens", default="512,4096")
+    ap.add_argument("--tokens", default="1,4,512,4096")
     args = ap.parse_args()
     import paroquant_amd  # noqa: F401
     from paroquant_amd.moe import ParoMoEExperts
@@ -47,6 +47,21 @@ def main():
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1))
             return best
+        if T * k <= 64:      # decode: the (token, expert) slots of paro_w4a16_gemv_experts, two launches, in a HIP graph
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                moe(x, idx)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g):
+                for _ in range(50):
+                    moe(x, idx)
+            t = timed(g.replay) / 50
+            wbytes = T * k * (H * 2 * I + I * H) / 2           # INT4 weights of the selected experts
+            print(json.dumps({"experts": E, "topk": k, "hidden": H, "inter": I, "tokens": T, "route": "decode slots (2 launches)",
+                              "us_per_moe_block": round(t * 1e3, 2), "GBps_int4_weights": round(wbytes / t / 1e6, 1)}), flush=True)
+            continue
         t_grouped = timed(lambda: moe(x, idx))
         t_loop = timed(lambda: moe.per_expert_prefill(x, idx))
         g = torch.cuda.CUDAGraph()
