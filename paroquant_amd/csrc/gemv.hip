@@ -82,14 +82,18 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj class
     tpw = 4; ksplit = 4;
     waves = G / 4 <= 8 ? 4 : 8;   // 8 groups per split: 4 waves x 2 units beat 8 x 1 (o_proj 7.0 -> 6.6 us on the same box)
+    // more than one row (tools/sweep_gemv.py --rows 2 / 4 / 8, profiles/r03_sweep_rows.jsonl): 8 waves, and 2-tile blocks up to 4 rows
+    // (o_proj Qwen3-4B 6.85 -> 6.17 us at 2 rows, 9.27 -> 7.88 at 8; Llama-3-8B 7.27 -> 6.46, 9.55 -> 8.28)
+    if (rows > 1) { waves = 8; if (rows <= 4) tpw = 2; }
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
     // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us)
     tpw = 1; ksplit = 2; waves = 8;
-  } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= (deferred && rows == 1 ? 16 : 32)) {
+  } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= ((deferred && rows == 1) || rows > 4 ? 16 : 32)) {
     // mid-width outputs with K >= 4096 (Llama-3-8B qkv: 384 tiles x 32 groups): 96 fat column blocks x 2 splits halve
     // the replicated rotation; pays since the reducer polls all splits at once (7.10 -> 6.71 us; at G = 20, Qwen3-4B
     // qkv, the unsplit 2-tile shape stays ahead: 5.65 vs 5.94).  `deferred` (the splits leave partial sums, nobody polls):
-    // pays from G = 16 (Qwen3-4B qkv 5.50 -> 4.96 us, Llama-3-8B 6.78 -> 5.73, profiles/r03_sweep_noreducer_wide.jsonl)
+    // pays from G = 16 (Qwen3-4B qkv 5.50 -> 4.96 us, Llama-3-8B 6.78 -> 5.73, profiles/r03_sweep_noreducer_wide.jsonl); so it does at
+    // 5..8 rows, where the replicated rotation has grown with the rows (Qwen3-4B qkv at 8 rows 9.58 -> 8.35, r03_sweep_rows.jsonl)
     tpw = 4; ksplit = 2; waves = 8;
   }
   if (tpw <= 0) {

@@ -678,13 +678,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         seed(pc, sa, sb);
         if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = stamp_after(sa[0] + sb[0]); }
         if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
-          // the universal krot = 8 without the per-stage compare + branch, in the 8- and 16-wave builds (bit-identical; down_proj
-          // 7.58 -> 7.45 us on Qwen3-4B, 9.39 -> 9.08 on Llama-3-8B, the others within noise; in the 4-wave builds the same change
-          // cost o_proj 0.8 us in round 2 -- profiles/r02_ab_krot8.jsonl, r03_ab_krot8_w8.jsonl -- and stays out)
-          if (WAVES >= 8 && h.krot == 8) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) stage(pc, t, sa, sb);
-          } else
+          // (the universal krot = 8 without the per-stage compare + branch was tried twice: round 2 -- the 4-wave o_proj build 0.8 us
+          // SLOWER -- and round 3 in the 8- / 16-wave builds only: down_proj -0.1 .. -0.3 us at one row, but the 16-wave build for
+          // 2..4 rows came out of the compiler with nondeterministic results (tools/_stress-style loop: 136 mismatching runs of 150,
+          // none without it; profiles/NOTES.md).  The compare stays.)
           {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {

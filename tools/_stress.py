@@ -1,0 +1,36 @@
+import numpy as np, torch, sys, os
+sys.path.insert(0, ".")
+from oracle import paro_oracle as po
+from paroquant_amd import ops, _native as nat
+from paroquant_amd.linear import PackedParoWeights
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+bad = 0
+cases = [(2560, [4096, 1024, 1024], 3), (2560, [9728, 9728], 3), (1024, [3072, 3072], 3), (2560, [4096, 1024, 1024], 1)]
+refs = {}
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):
+    for (K, sizes, rows) in cases:
+        key = (K, tuple(sizes), rows)
+        if key not in refs:
+            L = po.make_layer(K + rows, K, sizes)
+            rng = np.random.default_rng(K)
+            w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+            x = (rng.standard_normal((rows, K)) * 3.0).astype(np.float16)
+            res = rng.standard_normal((rows, sum(sizes))).astype(np.float16)
+            pk = PackedParoWeights(t(L["qweight"]), t(L["qzeros"]), t(L["scales"]), t(L["theta"]), t(L["pairs"]), t(L["channel_scales"]), sizes).fold_norm_weight(t(w))
+            refs[key] = (pk, x, res, None, None)
+        pk, x, res, y_first, y2_first = refs[key]
+        y = ops.w4a16_gemv_fused(t(x), pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=t(res))
+        wide = torch.zeros(rows, K + 64, device=dev, dtype=torch.float16)
+        wide[:, :K] = t(x)
+        y2 = ops.w4a16_gemv_fused(wide[:, :K], pk, nat.PROLOGUE_RMSNORM, 1e-6)
+        torch.cuda.synchronize()
+        if y_first is None:
+            refs[key] = (pk, x, res, y.clone(), y2.clone())
+        else:
+            if not torch.equal(y, y_first) or not torch.equal(y2, y2_first):
+                bad += 1
+                d1 = (y.float() - y_first.float()).abs().max().item(); d2 = (y2.float() - y2_first.float()).abs().max().item()
+                rowsbad = [(r, (y2[r].float() - y2_first[r].float()).abs().max().item()) for r in range(rows)]
+                print("MISMATCH iter", it, key, "dy", d1, "dy2", d2, rowsbad, flush=True)
+print("lib", os.environ.get("PARO_LIB_DIR", "_lib"), "mismatches", bad)

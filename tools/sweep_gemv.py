@@ -61,8 +61,9 @@ def main():
         G = K // 128
         import itertools
         for tpw, ksp, wv, mode in itertools.product(tpws, ksps, wvs, modes):
-            if ksp > max(1, G // 2) or (tpw == 8 and wv == 16) or (args.rows > 4 and wv == 16) \
-                    or tpw not in (1, 2, 4, 8):
+            auto = tpw == 0 and ksp == 0 and wv == 0          # (0, 0, 0) = the library's automatic launch shape, next to the forced ones
+            if not auto and (0 in (tpw, ksp, wv) or ksp > max(1, G // 2) or (tpw == 8 and wv == 16) or (args.rows > 4 and wv == 16)
+                             or tpw not in (1, 2, 4, 8)):
                 continue
 
             def run(i, tpw=tpw, ksp=ksp, wv=wv, mode=mode):
