@@ -1141,6 +1141,32 @@ def test_fused_rmsnorm_prologue(dev, K, sizes, rows):
     assert po.rel_err(_np(y2), ideal - res.astype(np.float64)) < TIGHT_F16
 
 
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+def test_fused_gemv_repeated_calls_are_deterministic(dev, rows):
+    """The same fused launches 40 times: bit-identical outputs every time (a build whose results vary from run to run passes a
+    tolerance test most of the time -- this is the test that catches it; tools/stress_fused.py is the long version)."""
+    from paroquant_amd import ops, _native as nat
+    for K, sizes in [(2560, [4096, 1024, 1024]), (1024, [3072, 3072])]:
+        L = po.make_layer(K + rows, K, sizes)
+        rng = np.random.default_rng(K + rows)
+        w = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+        pk = _packed(L, dev).fold_norm_weight(_t(w, dev))
+        x = _t((rng.standard_normal((rows, K)) * 3.0).astype(np.float16), dev)
+        res = _t(rng.standard_normal((rows, sum(sizes))).astype(np.float16), dev)
+        wide = torch.zeros(rows, K + 64, device=dev, dtype=torch.float16)
+        wide[:, :K] = x
+        first = None
+        for it in range(40):
+            y = ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_RMSNORM, 1e-6, residual=res)
+            y2 = ops.w4a16_gemv_fused(wide[:, :K], pk, nat.PROLOGUE_RMSNORM, 1e-6)
+            y3 = ops.w4a16_gemv_fused(x, pk, nat.PROLOGUE_NONE, residual=res)
+            torch.cuda.synchronize()
+            if first is None:
+                first = (y.clone(), y2.clone(), y3.clone())
+            else:
+                assert torch.equal(y, first[0]) and torch.equal(y2, first[1]) and torch.equal(y3, first[2]), (K, it)
+
+
 @pytest.mark.parametrize("K,N", [(9728, 2560), (3072, 1024), (14336, 4096), (512, 48)])
 @pytest.mark.parametrize("rows", [1, 4])
 def test_fused_silu_mul_prologue_and_residual(dev, K, N, rows):

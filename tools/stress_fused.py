@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""Determinism stress of the fused decode GEMV (RMSNorm prologue, residual, strided x; 1 and 3 rows): the same launches N times, outputs
+compared BIT FOR BIT with the first iteration.
+
+    python tools/stress_fused.py [iterations = 100]          (PARO_LIB_DIR=_lib_x: an experiment build)
+
+Exists because a compiler-level change (the krot = 8 stage loop without its per-stage compare, round 3) produced a 16-wave / 2..4-row
+build whose results differed from run to run -- 136 mismatching iterations of 150 -- while every parity test passed most of the time
+(profiles/NOTES.md); tests/test_gpu_parity.py::test_fused_gemv_repeated_calls_are_deterministic runs a short version."""
 import numpy as np, torch, sys, os
 sys.path.insert(0, ".")
 from oracle import paro_oracle as po
