@@ -205,6 +205,60 @@ def test_bench_byte_model():
     assert per_tok == 32 * (13414400 + 8839168 + 61292544 + 30916608)
 
 
+def test_round3_launch_shape_heuristics():
+    """Heuristics added in round 3, all host-only queries: the split of a launch nobody polls in (deferred K-split reduction:
+    paro_gemv_parts_count), the fused family at 2..8 rows, the chain family's K-split caps at 5..16 rows and its groups per slice."""
+    import bench
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+
+    def desc(K, sizes, bias=False):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.wq_order, d.group_size = K, sum(sizes), len(sizes), 8, nat.DTYPE_F16, 0, 128
+        for i, s_ in enumerate(sizes):
+            d.part_cols[i] = s_
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)          # never dereferenced on the host
+        if bias:
+            d.bias = 0x1000
+        return d
+
+    def shape(K, sizes, rows):
+        out = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
+        nat.check(lib.paro_gemv_launch_shape(ctypes.byref(desc(K, sizes)), rows, *[ctypes.byref(o) for o in out]))
+        return tuple(o.value for o in out)
+
+    def chain(K, sizes, rows):
+        ks, wv = ctypes.c_int(0), ctypes.c_int(0)
+        c = nat.ParoChain()
+        nat.check(lib.paro_chain_launch_shape(ctypes.byref(desc(K, sizes)), ctypes.byref(c), rows, ctypes.byref(ks), ctypes.byref(wv)))
+        return ks.value, wv.value
+
+    by = {m: {n: (K, s) for n, K, s, _ in bench.layer_shapes(m)} for m in ("llama3-8b", "qwen3-4b", "qwen3-0.6b")}
+    l8, q4, q06 = by["llama3-8b"], by["qwen3-4b"], by["qwen3-0.6b"]
+    parts = lambda K, sizes, bias=False: lib.paro_gemv_parts_count(ctypes.byref(desc(K, sizes, bias)))
+    # deferred reduction: o / down 4-way as in the automatic shape, qkv 2-way (only when nobody polls), gate_up never; a bias keeps the reducer
+    for m in (l8, q4):
+        assert parts(*m["o_proj"]) == 4 and parts(*m["down_proj"]) == 4 and parts(*m["qkv_proj"]) == 2 and parts(*m["gate_up_proj"]) == 0
+    assert parts(*q06["o_proj"]) == 2 and parts(*q06["down_proj"]) == 2
+    assert parts(*q4["o_proj"], bias=True) == 0
+    assert shape(*q4["qkv_proj"], 1) == (2, 1, 16, 0)          # ... while the ordinary one-row launch of Qwen3-4B's qkv stays unsplit
+    # fused family, more than one row (profiles/r03_sweep_rows.jsonl): o_proj 2-tile blocks x 4 splits x 8 waves up to 4 rows, 4 tiles at
+    # 5..8; mid-width qkv 4 tiles x 2 splits x 8 waves at 5..8 rows from K = 2048 on
+    for m in (l8, q4):
+        assert shape(*m["o_proj"], 2) == (2, 4, 8, 0) and shape(*m["o_proj"], 4) == (2, 4, 8, 0) and shape(*m["o_proj"], 8) == (4, 4, 8, 0)
+        assert shape(*m["o_proj"], 1)[:3] == (4, 4, 4)
+    assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 0) and shape(*q4["qkv_proj"], 4) == (2, 1, 16, 0)
+    # chain family (profiles/r03_chain_shape_sweep_rows.jsonl): deep K 8 slices at <= 8 rows, 5 at <= 16; the others 5 / 4; four groups per
+    # slice instead of three (Qwen3-4B o_proj: 8 slices x 4 waves, not 11)
+    assert chain(*q4["down_proj"], 8)[0] == 8 and chain(*q4["down_proj"], 16)[0] == 5
+    assert chain(*l8["down_proj"], 8)[0] == 8 and chain(*l8["down_proj"], 16)[0] == 5
+    assert chain(*q4["o_proj"], 8)[0] == 5 and chain(*q4["o_proj"], 16)[0] == 4
+    assert chain(*q4["o_proj"], 2) == (8, 4) and chain(*l8["o_proj"], 2) == (8, 4)
+    assert chain(*q4["qkv_proj"], 8) == (5, 4)
+    assert chain(*l8["gate_up_proj"], 16)[0] == 1          # wide outputs own whole column blocks, no split
+
+
 def test_gemv_launch_shape_heuristics():
     """The launch shapes the dispatcher picks for the Llama-3-8B / Qwen3-4B / Llama-3-70B linears (calibrated on
     MI355X with tools/sweep_gemv.py) -- host-only query, no device memory is touched."""
