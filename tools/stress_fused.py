@@ -42,4 +42,25 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):
                 d1 = (y.float() - y_first.float()).abs().max().item(); d2 = (y2.float() - y2_first.float()).abs().max().item()
                 rowsbad = [(r, (y2[r].float() - y2_first[r].float()).abs().max().item()) for r in range(rows)]
                 print("MISMATCH iter", it, key, "dy", d1, "dy2", d2, rowsbad, flush=True)
-print("lib", os.environ.get("PARO_LIB_DIR", "_lib"), "mismatches", bad)
+# ---- the deferred K-split reduction: producer (parts_out) -> consumer (RMSNorm prologue + parts_in + x_out), qkv as an RMSNorm producer
+Lp, Lc = po.make_layer(91, 4096, [2560]), po.make_layer(92, 2560, [4096, 1024, 1024])
+mk = lambda L_: PackedParoWeights(t(L_["qweight"]), t(L_["qzeros"]), t(L_["scales"]), t(L_["theta"]), t(L_["pairs"]), t(L_["channel_scales"]), L_["sizes"])
+pp, pc = mk(Lp), mk(Lc)
+rng = np.random.default_rng(5)
+xa, h0 = t(rng.standard_normal((1, 4096)).astype(np.float16)), t(rng.standard_normal((1, 2560)).astype(np.float16))
+parts, partsq = torch.zeros(2560, 4, device=dev), torch.zeros(6144 + 1, 4, device=dev)
+h1 = torch.zeros(2560, device=dev, dtype=torch.float16)
+first = None
+bad2 = 0
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):
+    ops.w4a16_gemv_fused(xa, pp, 0, parts_out=parts)
+    y = ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_RMSNORM, 1e-6, parts_in=parts, x_out=h1)
+    ops.w4a16_gemv_fused(h0, pc, nat.PROLOGUE_RMSNORM, 1e-6, parts_in=parts, parts_out=partsq)
+    torch.cuda.synchronize()
+    cur = (parts.clone(), y.clone(), h1.clone(), partsq.clone())
+    if first is None:
+        first = cur
+    elif not all(torch.equal(a, b) for a, b in zip(cur, first)):
+        bad2 += 1
+        print("MISMATCH (deferred) iter", it, [bool(torch.equal(a, b)) for a, b in zip(cur, first)], flush=True)
+print("lib", os.environ.get("PARO_LIB_DIR", "_lib"), "mismatches", bad, "deferred-route mismatches", bad2)
