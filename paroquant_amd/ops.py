@@ -328,11 +328,13 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     (+ bias + residual, once), exchanged inside this launch -- one row, every rank issuing the same launches.
 
     Deferred K-split reduction (one row; include/paro_abi.h, v12): ``parts_out`` (float32 ``[N, 4]``) -- the launch's K-splits
-    (``parts_n`` of them; 0 = :func:`gemv_parts_count`, the automatic launch shape's) leave their partial sums there, in the
-    in-launch reducer's summation order, instead of reducing them in the launch; nothing else is written and ``parts_out`` is
-    returned.  ``parts_in`` (float32 ``[K, 4]``, a producer's ``parts_out``): ``x`` is the residual stream BEFORE the producer's output
-    and the kernel completes ``x' = round(x + sum(parts_in, 1))`` while it seeds its rotation (prologue NONE or RMSNORM);
-    ``x_out [K]`` (not aliasing ``x``) receives ``x'``."""
+    (``parts_n`` of them; 0 = :func:`gemv_parts_count`) leave their partial sums there, in the in-launch reducer's summation
+    order, unused slots zero, instead of reducing them in the launch; nothing else is written and ``parts_out`` is returned.
+    With the RMSNorm prologue the buffer is ``[N + 1, 4]``: the partial sums are UN-normalised and the last row receives the
+    K-slices' sums of squares -- the consumer applies ``rsqrt(sum / K + eps)`` (:func:`attn_decode` does for the qkv projection).
+    ``parts_in`` (float32 ``[K, 4]``, a producer's ``parts_out``): ``x`` is the residual stream BEFORE the producer's output
+    and the kernel completes ``x' = round(x + sum(parts_in, 1))`` while it seeds its rotation (prologue NONE or RMSNORM; a plain
+    launch may K-split and may itself leave ``parts_out``); ``x_out [K]`` (not aliasing ``x``) receives ``x'``."""
     lib = nat.load()
     K, N = pk.K, pk.N
     width = 2 * K if prologue in (nat.PROLOGUE_SILU_MUL, nat.PROLOGUE_GELU_TANH_MUL) else K
@@ -384,7 +386,8 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
 
 def gemv_parts_count(pk, act_dtype: torch.dtype = torch.float16) -> int:
     """How many fp32 partial sums ``w4a16_gemv_fused(..., parts_out=)`` of this layer leaves (``paro_gemv_parts_count``: the K-split
-    of the automatic launch shape); 0 = the layer does not split (or has a bias): use the ordinary route."""
+    of the launch shape chosen for a launch nobody polls in -- o / down 4, mid-width projections such as qkv 2); 0 = the layer does
+    not split (or has a bias): use the ordinary route."""
     n = nat.load().paro_gemv_parts_count(ctypes.byref(pk_desc(pk, act_dtype)))
     if n < 0:
         nat.check(n)
@@ -394,7 +397,8 @@ def gemv_parts_count(pk, act_dtype: torch.dtype = torch.float16) -> int:
 def parts_finish(parts: torch.Tensor, x: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                  dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """``out[k] = round(x[k] + sum(parts[k, :]))`` in the order of the in-launch reducer (``paro_parts_finish``): completes a
-    producer's ``parts_out [K, 4]`` when no linear follows (the last layer's down_proj in front of the final norm)."""
+    producer's ``parts_out [K, 4]`` when no linear follows (the last layer's down_proj in front of the final norm).  Not for the
+    ``[N + 1, 4]`` buffer of an RMSNorm-prologue producer (its sums still lack the norm's scalar)."""
     dt = x.dtype if x is not None else (dtype or torch.float16)
     K = int(parts.size(0))
     if parts.dtype != torch.float32 or parts.dim() != 2 or parts.size(1) != nat.PARO_MAX_PARTIALS or not parts.is_contiguous() \
