@@ -48,7 +48,10 @@ for spec in "qwen3-4b:" "llama3-8b:--workload llama3-8b" "llama3-70b_8layers:--w
   [ -n "$S" ] && (cd $ROOT && python tools/pmc_summary.py stats $S $P/${R}_bench_${name}_kernel_stats.csv)
 done
 cd $ROOT
-# ---- end to end
+# ---- end to end: kernel trace of the decode harness (per-launch durations of one model), then tokens/s
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_stats -o b -- python $ROOT/tools/bench_e2e.py --model qwen3-4b --runs 2 --warmup 1 > $OUT/e2e_stats.log 2>&1)
+S=$(find $OUT/e2e_stats -name "*kernel_stats.csv" | head -1)
+[ -n "$S" ] && python tools/pmc_summary.py stats $S $OUT/e2e_stats_short.csv && head -12 $OUT/e2e_stats_short.csv > $P/${R}_e2e_qwen3-4b_kernel_stats.csv
 rm -f $P/${R}_e2e.jsonl
 for m in qwen3-4b llama3-8b qwen3-0.6b; do timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e.jsonl 2>> $OUT/e2e.err; done
 # ... and with the in-launch K-split reducer instead of the deferred reduction (paroquant_amd/decoder.py), same session
