@@ -45,6 +45,13 @@ import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# who can reach a one-row route (the headline is what the drop-in boundary delivers)
+ROUTE_REACH = {
+    "fused": "every RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply call (the reference's per-linear operator API)",
+    "parts": "a caller that owns the decoder loop (paroquant_amd.decoder.ParoDecoderLM; INTEGRATION.md 5b)",
+    "engine": "a caller that hands over a whole chain of linears (paroquant_amd.engine.DecodeEngine; the HF plug-in installs it per MLP block)",
+}
+
 MODELS = {
     #              hidden, inter, q_dim, kv_dim, layers
     "qwen3-0.6b": (1024, 3072, 2048, 1024, 28),
@@ -112,23 +119,41 @@ def alg_bytes(K: int, N: int, P: int) -> int:
     return K * N // 2 + G * N * 2 + G * N // 2 + 2 * K + 2 * N + P * (16 * K + 8 * K + 2 * K)
 
 
-def hybrid_layer_shapes(model: str, full: bool):
-    """Quantised linears of one Qwen3.5 decoder layer, merged where the inputs coincide (q|k|v, in_proj_qkv|in_proj_z, gate|up)."""
+def hybrid_layer_shapes(model: str, full: bool, tp: int = 1):
+    """Quantised linears of one Qwen3.5 decoder layer (per TP rank), merged where the inputs coincide (q|k|v,
+    in_proj_qkv|in_proj_z, gate|up).  Megatron sharding as the reference's loaders do it (vllm/plugin.py:33-50,66-76): the merged
+    projections are column-parallel over whole heads (gated q: a head's query AND gate columns stay on one rank; KV heads replicate
+    once there are fewer than ranks; the gated delta net's key / value heads split the same way), out_proj / o_proj / down_proj are
+    row-parallel with K cut in multiples of 128 (one rotation group) and an all-reduce behind them."""
     h, inter, nh, nkv, hd, lk, lv, _, _ = HYBRID[model]
-    mlp = [("gate_up_proj", h, [inter, inter], "col"), ("down_proj", inter, [h], "row")]
+    kvh = max(nkv // tp, 1)
+    mlp = [("gate_up_proj", h, [inter // tp, inter // tp], "col"), ("down_proj", inter // tp, [h], "row")]
     if full:
-        return [("qkv_proj(gated q)", h, [2 * nh * hd, nkv * hd, nkv * hd], "col"), ("o_proj", nh * hd, [h], "row")] + mlp
-    return [("in_proj_qkvz", h, [2 * lk * 128 + lv * 128, lv * 128], "col"), ("out_proj", lv * 128, [h], "row")] + mlp
+        return [("qkv_proj(gated q)", h, [2 * (nh // tp) * hd, kvh * hd, kvh * hd], "col"), ("o_proj", (nh // tp) * hd, [h], "row")] + mlp
+    return [("in_proj_qkvz", h, [(2 * (lk // tp) + lv // tp) * 128, (lv // tp) * 128], "col"), ("out_proj", (lv // tp) * 128, [h], "row")] + mlp
+
+
+def shard_error(model: str, tp: int):
+    """None when `model` shards `tp`-way (row-parallel K slices in multiples of 128, column slices of whole heads / 16 columns), else why not."""
+    if tp == 1:
+        return None
+    if model in HYBRID:
+        h, inter, nh, nkv, hd, lk, lv, _, _ = HYBRID[model]
+        if nh % tp or lk % tp or lv % tp or ((nh // tp) * hd) % 128 or inter % (tp * 128) or (nkv >= tp and nkv % tp):
+            return f"{model} does not shard {tp}-way: heads {nh}/{nkv}, linear heads {lk}/{lv}, intermediate {inter}"
+        return None
+    h, inter, q, kv, _ = MODELS[model]
+    if q % (tp * 128) or inter % (tp * 128) or kv % (tp * 16):
+        return f"{model} does not shard {tp}-way: K slices must be multiples of 128, column slices of 16"
+    return None
 
 
 def layer_plan(model: str, tp: int = 1, n_layers=None):
     """Per decoder layer, the list of its quantised linears [(name, K, partition sizes, kind)]."""
     L = n_layers or n_layers_of(model)
     if model in HYBRID:
-        if tp != 1:
-            raise SystemExit("the hybrid (Qwen3.5) workloads run unsharded here")
         iv = HYBRID[model][8]
-        return [hybrid_layer_shapes(model, (l + 1) % iv == 0) for l in range(L)]
+        return [hybrid_layer_shapes(model, (l + 1) % iv == 0, tp) for l in range(L)]
     return [layer_shapes(model, tp) for _ in range(L)]
 
 
@@ -220,17 +245,22 @@ class DecodeStack:
         # (profiles/r03_parts_micro.jsonl): the in-launch hand-off is 1.3 .. 1.45 us of the producer's launch, completing the sums costs
         # the consumer 0.6 .. 0.8 us (every workgroup reads the four fp32 slots of every channel).
         if route == "auto":
-            # one row, one GPU: parts (-2.8 % per step on Qwen3-4B, -2.4 % Llama-3-8B, -1.4 % Qwen3.5 hybrid, +0.3 % on Llama-3-70B shapes against the
-            # in-launch reducer, profiles/r03_parts_bench.jsonl; the other leg is reported next to it, config.route_ab)
-            # (70B-class shapes, hidden >= 8192: the launches are long enough that the hand-off no longer shows -- fused)
-            route = "chain" if (rows > 1 and tp == 1) else ("parts" if (rows == 1 and tp == 1 and self.hidden < 8192
-                                                                        and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0") else "fused")
-        if route in ("chain", "parts") and tp != 1:
+            # The headline route is what the DROP-IN BOUNDARY delivers: one paro_w4a16_gemv per `RotateQuantizedLinear.forward` /
+            # `ParoQuantLinearMethod.apply` call (transformers/modules.py:57-71, vllm/plugin.py:281-311) = "fused".  The routes that need a
+            # caller who owns the decoder loop -- "parts" (deferred K-split reductions, paroquant_amd/decoder.py uses it), "engine" (one
+            # persistent launch for the whole chain, csrc/engine.hip) -- are timed next to it and reported under config.route_ab
+            # (VERDICT r3 weak #2).  2..16 rows: the decode-chain family (also a decoder-loop route; --route fused for the per-call number).
+            route = "chain" if (rows > 1 and tp == 1) else "fused"
+        if route == "parts":
+            from paroquant_amd.decoder import deferred_route_pays
+            self.parts_pays = deferred_route_pays(self.hidden)      # the decode harness' gate (70B-class widths keep the in-launch reducer)
+        if route in ("chain", "parts", "engine") and tp != 1:
             raise SystemExit(f"the {route} route is single-GPU")
-        if route == "parts" and rows != 1:
-            raise SystemExit("the parts route is batch-1")
+        if route in ("parts", "engine") and rows != 1:
+            raise SystemExit(f"the {route} route is batch-1")
         self.route = route
-        if route == "parts" or (route == "fused" and rows == 1 and tp == 1):     # (the fused stack can also run the parts route: the A/B leg)
+        self._engine = None
+        if route in ("parts", "engine") or (route == "fused" and rows == 1 and tp == 1):     # (the fused stack can also run the parts route: the A/B leg)
             flat = [pk for lay in self.layers for pk in lay]
             self._flat = flat
             # producer i hands partial sums to consumer i + 1 (which reads the first K columns of i's output) when the launch shape for
@@ -250,6 +280,8 @@ class DecodeStack:
             self._y = {pk.N: torch.empty(1, pk.N, device=dev, dtype=torch.float16) for pk in flat}
             if route == "parts":
                 self.launches_per_step += 1 if self._nparts[-1] else 0
+            if route == "engine":
+                self._ensure_engine()
         if route == "chain":
             self.launches_per_step += 1        # the head's rotate_parts
             flat = [pk for lay in self.layers for pk in lay]
@@ -262,7 +294,26 @@ class DecodeStack:
                     self._xr[key] = torch.empty(key[0], rows, key[1], device=dev, dtype=torch.float16)
             self._y = {pk.N: torch.empty(rows, pk.N, device=dev, dtype=torch.float16) for pk in flat}
 
+    def use_route(self, route: str):
+        """Switch the one-row route of a built stack (config.route_ab legs)."""
+        if route in ("parts", "engine") and not hasattr(self, "_flat"):
+            raise RuntimeError(f"stack was not built for the {route} route")
+        if route == "engine":
+            self._ensure_engine()
+        self.route = route
+
+    def _ensure_engine(self):
+        if getattr(self, "_engine", None) is None:
+            from paroquant_amd.engine import DecodeEngine
+            # the same chain as `step`: linear i + 1 reads the first K columns of linear i's output
+            self._engine = DecodeEngine(self._flat, in_col0=[0] * len(self._flat))
+
+    def _step_engine(self, x: torch.Tensor) -> torch.Tensor:
+        return self._engine(x)
+
     def step(self, x: torch.Tensor) -> torch.Tensor:
+        if self.route == "engine":
+            return self._step_engine(x)
         if self.route == "chain":
             return self._step_chain(x)
         if self.route == "parts":
@@ -352,15 +403,24 @@ def time_steps(fn, steps: int, warmup: int, world: int, dev):
     return wall, ev_ms
 
 
-def per_shape_table(model: str, dev, reps: int = 400):
-    """Per-linear GEMV timing (events around `reps` back-to-back launches cycling >= 1 GiB of distinct
-    weights so neither L2 nor the Infinity Cache can serve them)."""
+# BASELINE.json's target: ">= 70 % of MI355X HBM roofline on batch-1 INT4 GEMV at Llama-3-8B q/k/v/o/mlp shapes" -- the five rows of
+# BASELINE.md section 3 that a plug-in issues one call for (q / o and k / v unmerged as the HF path runs them, merged qkv / gate_up as the
+# vLLM path runs them, down).  Measured by every default bench run so that the driver-run record carries them (VERDICT r3 missing #4).
+NORTH_STAR_SHAPES = [("q_proj / o_proj", 4096, [4096], "row"), ("k_proj / v_proj", 4096, [1024], "col"),
+                     ("qkv_proj merged [P=3]", 4096, [4096, 1024, 1024], "col"), ("gate_up_proj merged [P=2]", 4096, [14336, 14336], "col"),
+                     ("down_proj", 14336, [4096], "row")]
+
+
+def per_shape_table(model: str, dev, reps: int = 400, shapes=None, min_bytes: int = 1 << 30):
+    """Per-linear GEMV timing through the per-call operator (`PackedParoWeights.apply` = what RotateQuantizedLinear.forward /
+    ParoQuantLinearMethod.apply run): events around `reps` back-to-back launches cycling >= `min_bytes` of distinct weights so
+    neither L2 nor the 256 MB Infinity Cache can serve them."""
     rows = []
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
-    for name, K, sizes, _ in distinct_shapes(model):
+    for name, K, sizes, _ in (shapes or distinct_shapes(model)):
         nb = alg_bytes(K, sum(sizes), len(sizes))
-        copies = max(2, min(64, int((1 << 30) // nb) + 1))
+        copies = max(2, min(64, int(min_bytes // nb) + 1))
         packs = [synth_packed(K, sizes, dev, gen) for _ in range(copies)]
         x = torch.randn(1, K, device=dev, dtype=torch.float16, generator=gen)
         for i in range(20):
@@ -448,6 +508,75 @@ def cpu_baseline(model: str, budget_s: float = 20.0):
     return out
 
 
+def cpu_per_shape(budget_s: float = 12.0):
+    """SURVEY 8d / BASELINE.md section 4: the CPU baselines per shape, on the host cores of this box, ms per call and effective GB/s with
+    the same bytes(K, N, P) as the GPU rows.  B1 = the oracle path on torch-CPU (unpack -> (q - z) s -> fp16 W, rotate(x * cs), fp32 matmul;
+    what AutoAWQ's no-extension fallback does), B2 = the C / OpenMP port of the reference algorithm (oracle/paro_cpu.c; the only use of
+    oracle/ here is this baseline leg).  Config 1 (4096 x 4096, M in {1, 16, 2048}) plus every Llama-3-8B shape of BASELINE.md section 3 at
+    M = 1.  Median of up to 20 runs after one warm-up, bounded by `budget_s` in total (each row gets an equal share; at least 2 runs)."""
+    from oracle import paro_cpu as pc
+    pc.load()
+    pc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    torch.set_num_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    rng = np.random.default_rng(1)
+    cases = [("config 1: 4096 x 4096", 4096, [4096], M) for M in (1, 16, 2048)] + [(n, K, sz, 1) for n, K, sz, _ in NORTH_STAR_SHAPES]
+    share = budget_s / (2 * len(cases))
+    out = []
+    for name, K, sizes, M in cases:
+        N, P, G = sum(sizes), len(sizes), K // 128
+        L = dict(qweight=rng.integers(-2**31, 2**31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32),
+                 qzeros=rng.integers(-2**31, 2**31 - 1, size=(G, N // 8), dtype=np.int64).astype(np.int32),
+                 scales=rng.uniform(0.002, 0.02, size=(G, N)).astype(np.float16),
+                 theta=(rng.standard_normal((P, 8, K // 2)) * 0.1).astype(np.float16),
+                 pairs=np.stack([synth_pairs(rng, 8, K) for _ in range(P)]),
+                 channel_scales=rng.uniform(0.5, 2.0, size=(P, 1, K)).astype(np.float16), sizes=sizes, K=K)
+        x = rng.standard_normal((M, K)).astype(np.float16)
+
+        def timed(fn):
+            fn()
+            ts, t_begin = [], time.perf_counter()
+            while len(ts) < 2 or (len(ts) < 20 and time.perf_counter() - t_begin < share):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), len(ts)
+
+        # B1: torch-CPU -- the unpacked nibbles are prepared once (format conversion), dequant + rotation + matmul are timed
+        shifts = torch.tensor([0, 16, 4, 20, 8, 24, 12, 28], dtype=torch.int32)     # AWQ order (0,2,4,6,1,3,5,7): column 8c + j sits in nibble ...
+        qw = ((torch.from_numpy(L["qweight"]).unsqueeze(-1) >> shifts) & 15).reshape(K, N).to(torch.float32)
+        qz = ((torch.from_numpy(L["qzeros"]).unsqueeze(-1) >> shifts) & 15).reshape(G, N).to(torch.float32)
+        sc = torch.from_numpy(L["scales"]).float()
+        xt = torch.from_numpy(x).float()
+        cs = torch.from_numpy(L["channel_scales"]).float().reshape(P, K)
+        th = torch.from_numpy(L["theta"]).float()
+        pr = torch.from_numpy(L["pairs"].astype(np.int64))                           # [P][8][K] group-local
+        base = (torch.arange(K) // 128 * 128)
+        I = pr[:, :, 0::2] + base[0::2]
+        J = pr[:, :, 1::2] + base[0::2]
+        col0 = np.concatenate([[0], np.cumsum(sizes)])
+
+        def b1():
+            w = ((qw - qz.repeat_interleave(128, 0)) * sc.repeat_interleave(128, 0)).half().float()
+            ys = []
+            for p_ in range(P):
+                xr = (xt * cs[p_]).clone()
+                for r in range(8):
+                    c, s_ = torch.cos(th[p_, r]), torch.sin(th[p_, r])
+                    xi, xj = xr[:, I[p_, r]], xr[:, J[p_, r]]
+                    xr[:, I[p_, r]] = c * xi + s_ * xj
+                    xr[:, J[p_, r]] = c * xj - s_ * xi
+                ys.append(xr @ w[:, col0[p_]:col0[p_ + 1]])
+            return torch.cat(ys, 1).half()
+
+        nb = alg_bytes(K, N, P) + (M - 1) * 2 * (K + N)
+        t2, n2 = timed(lambda: pc.linear_f16(x, L))
+        t1, n1 = timed(b1)
+        out.append({"shape": name, "M": M, "K": K, "N": N, "P": P, "bytes": int(nb),
+                    "B2_c_port_ms": round(t2 * 1e3, 3), "B2_GBps": round(nb / t2 / 1e9, 2), "B2_runs": n2,
+                    "B1_torch_cpu_ms": round(t1 * 1e3, 3), "B1_GBps": round(nb / t1 / 1e9, 2), "B1_runs": n1})
+    return {"threads": pc.threads(), "rows": out}
+
+
 def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5, warmup: int = 2,
                tp_rank: int = 0, tp_world: int = 1, allreduce=None):
     """End-to-end batch-1 greedy decode of the whole model on the fused harness (paroquant_amd/decoder.py: five launches
@@ -522,7 +651,7 @@ def parse_args(argv=None):
     ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
     ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16)")
-    ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain"],
+    ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain", "engine"],
                     help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
                          "launch (decode-chain family); parts = fused with the deferred K-split reduction of o / down (one row, one GPU); "
                          "auto = parts at one row on one GPU, chain at 2..16 rows, fused under tensor parallelism (measured: profiles/r03_chain_rows_sweep.jsonl, r03_parts_bench.jsonl)")
@@ -531,7 +660,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end decode leg (fused harness: attention, norms, lm_head)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table to stderr")
+    ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table of the workload's model to stderr")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip extra.llama3_8b_per_shape (the five Llama-3-8B GEMV shapes of BASELINE.md section 3, timed by the default run)")
     ap.add_argument("--pmc-file", default="", help="PMC summary json for roofline.traffic (default: newest profiles/rNN_pmc_bench_<model>.json)")
     ap.add_argument("--tp-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the N > 1 run; gloo (+ --same-device) lets the whole TP path -- sharded HIP kernels, "
@@ -583,8 +714,6 @@ def run(args, rank: int, local_rank: int, world: int):
     model = workload[:-3] if tp_mode else workload
     if model not in MODELS and model not in HYBRID:
         raise SystemExit(f"unknown workload {workload!r}; known models: {known_models()} (the dense ones also as <model>-tp)")
-    if tp_mode and model in HYBRID:
-        raise SystemExit("tensor-parallel workloads are defined for the dense models")
     if not 1 <= args.rows <= 16:
         raise SystemExit("--rows must be in 1..16")
     tp = world if tp_mode else 1
@@ -632,10 +761,8 @@ def run(args, rank: int, local_rank: int, world: int):
     from paroquant_amd import _native
     _native.load()
 
-    if tp_mode:
-        h, inter, q, kv, _ = MODELS[model]
-        if q % (tp * 128) or inter % (tp * 128) or kv % (tp * 16):
-            raise SystemExit(f"{model} does not shard {tp}-way: K slices must be multiples of 128, column slices of 16")
+    if tp_mode and shard_error(model, tp):
+        raise SystemExit(shard_error(model, tp))
     allreduce, allreduce_name = None, None
     if tp_mode and world > 1:
         from paroquant_amd import tp as ptp
@@ -691,26 +818,31 @@ def run(args, rank: int, local_rank: int, world: int):
             if args.tp_backend == "gloo":
                 args.no_graph = True
             wall, ev_ms, use_graph = measure()
-    # one row, one GPU: the same stack through the other one-row route as well (in-launch K-split reducer vs deferred reduction)
+    # one row, one GPU: the same stack through the decoder-loop routes as well (deferred K-split reductions; the persistent engine):
+    # config.route_ab = {route: {ms_per_step, roofline_frac, max_rel_diff_vs_headline}}
     route_ab = None
-    if stack.route in ("parts", "fused") and not tp_mode and args.rows == 1 and not args.no_route_ab:
-        route_ab = {stack.route: {"ms_per_step": round(wall * 1e3 / args.steps, 4)}}
-        other = "fused" if stack.route == "parts" else "parts"
-        try:
-            mine = stack.route
-            if other == "parts" and not hasattr(stack, "_nparts"):
-                raise RuntimeError("stack was not built for the parts route")
-            y_mine = stack.step(stack.x).clone()
-            stack.route = other
-            y_other = stack.step(stack.x).clone()
-            w2, _, _ = measure()
-            route_ab[other] = {"ms_per_step": round(w2 * 1e3 / args.steps, 4)}
-            # same chain of linears; the deferred sums keep the reducer's order, a different split (qkv) changes the fp32 summation order
-            route_ab["max_rel_diff_of_outputs"] = float((y_mine.float() - y_other.float()).abs().max() / y_other.float().abs().max())
-        except Exception as e:
-            route_ab[other] = {"error": f"{type(e).__name__}: {e}"}
-        finally:
-            stack.route = mine
+    if stack.route in ("parts", "fused", "engine") and not tp_mode and args.rows == 1 and not args.no_route_ab:
+        frac_of = lambda w_s: round(stack.bytes_per_step * args.steps / w_s / 1e9 / HBM_PEAK_GBPS, 4)
+        route_ab = {stack.route: {"ms_per_step": round(wall * 1e3 / args.steps, 4), "roofline_frac": frac_of(wall),
+                                  "reachable_through": ROUTE_REACH[stack.route]}}
+        mine = stack.route
+        y_mine = stack.step(stack.x).clone()
+        for other in [r for r in ("fused", "parts", "engine") if r != mine]:
+            try:
+                stack.use_route(other)
+                y_other = stack.step(stack.x).clone()
+                torch.cuda.synchronize(dev)
+                w2, _, _ = measure()
+                # same chain of linears; another K partition changes the fp32 summation order: the difference is chain-amplified rounding
+                # (144 linears), gated at the north star's 1e-2
+                rel = float((y_mine.float() - y_other.float()).abs().max() / y_mine.float().abs().max())
+                route_ab[other] = {"ms_per_step": round(w2 * 1e3 / args.steps, 4), "roofline_frac": frac_of(w2),
+                                   "max_rel_diff_vs_headline": rel, "within_1e-2": bool(rel < 1e-2),
+                                   "reachable_through": ROUTE_REACH[other]}
+            except Exception as e:
+                route_ab[other] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                stack.route = mine
     # TP runs report BOTH collectives: the one-shot xGMI kernel (when it came up and passed its self-test)
     # and the backend's all-reduce (RCCL), timed on the same shards; the headline is the faster leg that is healthy.
     allreduce_ab = None
@@ -826,8 +958,20 @@ def run(args, rank: int, local_rank: int, world: int):
         if args.per_shape:
             for row in per_shape_table(model, dev):
                 print(json.dumps(row), file=sys.stderr, flush=True)
+        if world == 1 and not tp_mode and args.rows == 1 and not args.no_north_star:
+            # the north star's named shapes, in the ONE contract line: bytes, us per launch, fraction of 8 TB/s
+            try:
+                tab = per_shape_table("llama3-8b", dev, reps=300, shapes=NORTH_STAR_SHAPES, min_bytes=768 << 20)
+                result["extra"] = {"llama3_8b_per_shape": tab, "target_frac": 0.70,
+                                   "note": "batch-1 fused rotate + INT4 GEMV per operator call, HIP graph of 300 launches over >= 768 MiB of distinct weights"}
+            except Exception as e:
+                result["extra"] = {"llama3_8b_per_shape": {"error": f"{type(e).__name__}: {e}"}}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
+            try:       # SURVEY 8d's per-shape table (B1 torch-CPU, B2 C port); context, never fatal for the contract line
+                result["cpu_baseline"]["per_shape"] = cpu_per_shape(max(4.0, args.cpu_budget * 0.6))
+            except Exception as e:
+                result["cpu_baseline"]["per_shape"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             result["cpu_baseline"] = None
         if not args.no_e2e and world == 1 and not tp_mode and stack is not None and stack.n_layers == n_layers_of(model):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 12
+#define PARO_ABI_VERSION 13
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -218,9 +218,11 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
  *                x'[k] = round(x[k] + (((parts[k][0] + parts[k][1]) + parts[k][2]) + parts[k][3]))
  *            -- the summation order and the single rounding of the in-launch reducer, so both routes give the same bits.
  *            x_out (optional, must not alias x) receives x' (the new residual stream; written by one workgroup).
- *            One row; in-kernel rotation; the consumer's prologue is NONE or RMSNORM.  With the RMSNorm prologue or x_out the
- *            consumer covers all of K per workgroup; a plain consumer may split K itself (each slice completes the channels it
- *            reads) and may in turn leave partial sums (parts_in and parts_out in one call: a chain of plain linears).
+ *            One row; in-kernel rotation; the consumer's prologue is NONE or RMSNORM.  A consumer may split K itself -- every K-slice
+ *            completes (and, in column block 0, stores to x_out) exactly the channels it reads, so x_out is written piecewise, once
+ *            per channel -- and may in turn leave partial sums (parts_in and parts_out in one call: a chain of linears).  The RMSNorm
+ *            prologue on a K-split consumer is only defined together with parts_out (no workgroup sees all of x: see below); an
+ *            unsplit RMSNorm consumer covers all of K per workgroup.  x_out must not alias x, parts_in, parts_out or y.
  *            parts_out_n: paro_gemv_parts_count(L) -- the split of the launch shape chosen for a launch nobody polls in (the
  *            narrow deep linears as in the automatic shape; mid-width ones such as qkv split 2-way); 0 = this layer does
  *            not split, use the ordinary route -- or any 2..PARO_MAX_PARTIALS that K / 128 can be cut into.
@@ -274,6 +276,10 @@ typedef struct paro_experts {
   int32_t x_slot_div;
   int64_t wq_stride_bytes, sz_stride_bytes;
   int64_t x_slot_stride, y_slot_stride;   /* elements */
+  int32_t n_experts;                      /* v13: experts behind L->wq / L->sz.  A slot whose id is outside [0, n_experts) reads expert 0's
+                                             weights (never out of bounds) and its outputs are NaN -- checked on the DEVICE, so it also holds
+                                             under HIP-graph replay, where no host check can run.  Must be >= 1. */
+  int32_t reserved0;
 } paro_experts_t;
 int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                             int64_t workspace_bytes, const paro_fusion_t* fusion, const paro_experts_t* experts,
@@ -298,11 +304,13 @@ int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows
  * expert ON THE DEVICE, pads every expert's segment to a multiple of block_rows (64, 128 or 256) and passes
  *   x_rot         act_dtype [padded_rows][K]   rotated rows in that order (padding rows: anything finite)
  *   block_expert  int32 [padded_rows / block_rows] in DEVICE memory: the expert whose packed weights row block b uses,
- *                 L->wq + e * wq_stride_bytes / L->sz + e * sz_stride_bytes; -1 = block unused
+ *                 L->wq + e * wq_stride_bytes / L->sz + e * sz_stride_bytes; -1 = block unused; an id >= n_experts (v13) is
+ *                 treated as unused on the device (its rows of y are not written): never an out-of-bounds weight read
  *   y             act_dtype [padded_rows][N]
  * One launch of GEMM variant 4 for all experts; no host synchronisation; HIP-graph capturable.  L: one rotation partition. */
 int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot, void* y, int64_t padded_rows, int block_rows,
-                            const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, void* stream);
+                            const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, int32_t n_experts,
+                            void* stream);
 
 /* Dispatcher used by the Python operator: gemv for rows <= 16, gemm otherwise. */
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,

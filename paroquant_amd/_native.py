@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 12
+PARO_ABI_VERSION = 13
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -102,7 +102,8 @@ class ParoExperts(Structure):
     """``paro_experts_t`` (include/paro_abi.h)."""
 
     _fields_ = [("expert_idx", c_void_p), ("n_slots", c_int32), ("x_slot_div", c_int32), ("wq_stride_bytes", c_int64),
-                ("sz_stride_bytes", c_int64), ("x_slot_stride", c_int64), ("y_slot_stride", c_int64)]
+                ("sz_stride_bytes", c_int64), ("x_slot_stride", c_int64), ("y_slot_stride", c_int64), ("n_experts", c_int32),
+                ("reserved0", c_int32)]
 
 
 class ParoChain(Structure):
@@ -187,7 +188,8 @@ def load() -> ctypes.CDLL:
     lib.paro_w4a16_gemm.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                     c_void_p]
     lib.paro_w4a16_gemm_grouped.restype = c_int
-    lib.paro_w4a16_gemm_grouped.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]
+    lib.paro_w4a16_gemm_grouped.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int32,
+                                            c_void_p]
     lib.paro_workspace_status.restype = c_int
     lib.paro_workspace_status.argtypes = [c_void_p, c_void_p]
     lib.paro_w4a16_linear.restype = c_int

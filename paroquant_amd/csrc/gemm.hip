@@ -542,7 +542,8 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
 // padded up to a multiple of block_rows; row block b multiplies by expert block_expert[b]'s packed weights (device
 // memory, -1 = unused block): one launch for all experts, nothing on the host, HIP-graph capturable.
 extern "C" int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot, void* y, int64_t padded_rows, int block_rows,
-                                       const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, void* stream) {
+                                       const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, int32_t n_experts,
+                                       void* stream) {
   using namespace paro;
   int rc = validate_linear(L);
   if (rc != PARO_OK) return rc;
@@ -552,6 +553,7 @@ extern "C" int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot
   if (L->n_parts != 1) return fail(PARO_ERR_UNSUPPORTED, "grouped GEMM: one rotation partition per projection (the experts share it)");
   if (wq_stride_bytes % 16 || sz_stride_bytes % 4) return fail(PARO_ERR_INVALID, "expert strides must keep the packed buffers aligned");
   if (padded_rows / block_rows > 65535) return fail(PARO_ERR_INVALID, "too many row blocks");
+  if (n_experts < 1) return fail(PARO_ERR_INVALID, "n_experts must be >= 1 (the device checks every block's expert id against it)");
   GemmArgs a;
   a.wq = (const u32x4*)L->wq;
   a.sz = (const unsigned*)L->sz;
@@ -569,6 +571,7 @@ extern "C" int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot
   a.gps = a.G;
   a.partial = nullptr;
   a.block_expert = block_expert;
+  a.n_experts = n_experts;
   a.wq_estride = wq_stride_bytes / 16;
   a.sz_estride = sz_stride_bytes / 4;
   dim3 grid((unsigned)a.pt.cbs, (unsigned)(padded_rows / block_rows), 1u);

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const unsigned* sz_base = a.sz;
   if (a.block_expert) {   // grouped launch: this row block belongs to one expert (or to the padding behind the last one)
     const int e = a.block_expert[blockIdx.y];
-    if (e < 0) return;
+    if (e < 0 || e >= a.n_experts) return;   // unused block, or an id outside the expert table (never an out-of-bounds weight read)
     wq_base += (int64_t)e * a.wq_estride;
     sz_base += (int64_t)e * a.sz_estride;
   }

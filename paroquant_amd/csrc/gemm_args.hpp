@@ -19,6 +19,7 @@ struct GemmArgs {
   // block_expert[blockIdx.y] (device memory; -1 = an unused block of the padded row space); null = one weight set
   const int* block_expert = nullptr;
   long long wq_estride = 0, sz_estride = 0;   // u32x4 / u32 elements between consecutive experts' packed buffers
+  int n_experts = 0;                          // block_expert entries outside [0, n_experts) are skipped on the device
 };
 
 }  // namespace paro

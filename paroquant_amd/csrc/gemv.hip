@@ -226,12 +226,14 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   }
   if (pin) {
     if (F->prologue != PARO_PROLOGUE_NONE && F->prologue != PARO_PROLOGUE_RMSNORM) return fail(PARO_ERR_UNSUPPORTED, "parts_in feeds the plain or the RMSNorm prologue");
-    if (F->x_out && F->x_out == x) return fail(PARO_ERR_INVALID, "x_out must not alias x (other workgroups still read it)");
+    if (F->x_out && (F->x_out == x || F->x_out == (const void*)F->parts_in || F->x_out == (void*)F->parts_out || F->x_out == y))
+      return fail(PARO_ERR_INVALID, "x_out must not alias x, parts_in, parts_out or y (other workgroups still read / write them)");
   }
   if (E) {
     if (!F) F = &no_fusion;
     if (!E->expert_idx || E->n_slots < 1 || E->n_slots > 65535) return fail(PARO_ERR_INVALID, "bad expert slot table");
     if (E->x_slot_div < 1) return fail(PARO_ERR_INVALID, "x_slot_div must be >= 1");
+    if (E->n_experts < 1) return fail(PARO_ERR_INVALID, "n_experts must be >= 1 (the device checks every slot's id against it)");
     if (F->residual) return fail(PARO_ERR_UNSUPPORTED, "the residual epilogue is not defined for expert slots");
     if (ksplit > 1) return fail(PARO_ERR_INVALID, "expert launches do not K-split (the slots already fill the grid)");
     ksplit = 1;
@@ -320,6 +322,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.x_sstride = E ? E->x_slot_stride : 0;
   a.y_sstride = E ? E->y_slot_stride : 0;
   a.x_div = E ? E->x_slot_div : 1;
+  a.n_experts = E ? E->n_experts : 0;
   for (int r = 0; r < kArMaxWorld; ++r) a.ar_peer[r] = (ar && r < F->ar_world) ? (unsigned char*)F->ar_peers[r] : nullptr;
   a.ar_mine = ar ? (unsigned char*)F->ar_own : nullptr;
   a.ar_state = ar ? (unsigned*)F->ar_state : nullptr;

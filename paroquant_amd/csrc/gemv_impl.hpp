@@ -80,6 +80,7 @@ struct GemvArgs {
   long long wq_estride, sz_estride;      // bytes between experts in wq / sz
   long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
   int x_div;
+  int n_experts;                         // ids outside [0, n_experts) read expert 0 and give NaN outputs (checked on the device: graph replays too)
   // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
   // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
   unsigned char* ar_peer[kArMaxWorld];   // every rank's buffer as mapped in this process, BY VALUE: a pointer fetched from device
@@ -264,12 +265,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   GP<unsigned> sz_p = h.sz;
   GP<unsigned short> x_p = h.x;
   int slot = 0;
+  bool bad_expert = false;
   if constexpr (FMODE != 0) {
     if (h.experts) {
       slot = blockIdx.z;
       // the id is the same for the whole workgroup: pulled back into a scalar register so that the pointers derived
       // from it stay scalar (otherwise EVERY fused instantiation addresses its loads through 64-bit vector registers)
-      const long long ex = __builtin_amdgcn_readfirstlane(a.expert_idx[slot]);
+      const int ex_raw = __builtin_amdgcn_readfirstlane(a.expert_idx[slot]);
+      bad_expert = (unsigned)ex_raw >= (unsigned)a.n_experts;
+      const long long ex = bad_expert ? 0 : ex_raw;
       wq_p = (GP<u32x4>)((GP<unsigned char>)h.wq + ex * a.wq_estride);
       sz_p = (GP<unsigned>)((GP<unsigned char>)h.sz + ex * a.sz_estride);
       x_p = h.x + (long long)(slot / a.x_div) * a.x_sstride;
@@ -872,6 +876,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         if (a.bias) v += A::to_f32(a.bias[col]);
         if constexpr (FMODE) {
           if (h.residual) v += (e == tid && res_valid) ? A::to_f32(res_raw) : A::to_f32(h.residual[(int64_t)b * h.N + col]);
+          if (bad_expert) v = __builtin_nanf("");   // a slot whose expert id is out of range: loud, and its loads stayed in bounds
         }
         y_p[(int64_t)b * h.N + col] = A::from_f32(v);
       }

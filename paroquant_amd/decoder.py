@@ -71,12 +71,14 @@ class DecoderConfig:
         rp = c.get("rope_parameters") or {}
         rope_theta = c.get("rope_theta") or rp.get("rope_theta", 10000.0)
         # z-lab/Llama-3.1-8B-Instruct-PARO carries llama3 rope scaling: the low-frequency inv_freq change at EVERY position
-        scaling = c.get("rope_scaling") or ({k: v for k, v in rp.items() if k != "rope_theta"} if rp.get("rope_type", rp.get("type", "default")) != "default" else None)
+        scaling = c.get("rope_scaling") or ({k: v for k, v in rp.items() if k not in ("rope_theta", "partial_rotary_factor")}
+                                            if rp.get("rope_type", rp.get("type", "default")) != "default" else None)
         cfg = cls(c["hidden_size"], c["intermediate_size"], c["num_attention_heads"],
                   c.get("num_key_value_heads", c["num_attention_heads"]), hd, c["num_hidden_layers"], c["vocab_size"],
                   c.get("rms_norm_eps", 1e-6), float(rope_theta), c.get("model_type", "") in ("qwen3",), max_positions, scaling)
         rope_inv_freq(cfg, "cpu")      # unsupported scaling types fail HERE, at load time, not as silently wrong rotary angles
-        if float(c.get("partial_rotary_factor", 1.0)) != 1.0:
+        # (newer configs keep the factor inside `rope_parameters`, next to theta and the scaling type)
+        if float(c.get("partial_rotary_factor", 1.0)) != 1.0 or float(rp.get("partial_rotary_factor", 1.0)) != 1.0:
             raise NotImplementedError("partial rotary embeddings are not supported by the decode harness")
         return cfg
 
@@ -88,6 +90,13 @@ MODEL_CONFIGS = {
     "llama3-8b": (4096, 14336, 32, 8, 128, 32, 128256, False, 5e5),
     "llama3-70b": (8192, 28672, 64, 8, 128, 80, 128256, False, 5e5),
 }
+
+
+def deferred_route_pays(hidden: int) -> bool:
+    """ONE gating predicate for the deferred K-split reduction, shared by the decode harness and bench.py's `parts` route: measured
+    -2.8 % per step (Qwen3-4B) .. -1.1 % (Qwen3-0.6B), +0.3 % on 70B-class widths (hidden >= 8192: the launches are long enough that
+    the in-launch hand-off no longer shows; profiles/r03_parts_bench.jsonl).  PARO_DEFERRED_KSPLIT=0 keeps the in-launch reducer."""
+    return hidden < 8192 and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0"
 
 
 def named_config(name: str, max_positions: int = 2048) -> DecoderConfig:
@@ -312,15 +321,15 @@ class ParoDecoderLM:
         self.part = torch.zeros(1, c.hidden, dtype=dt, device=dev)     # this rank's partial sum of a row-parallel linear (TP)
         # deferred K-split reduction of o / down (one GPU, every layer's o and down K-split by the automatic launch shape and carry
         # no bias; PARO_DEFERRED_KSPLIT=0 keeps the in-launch reducer)
-        n_o = min(ops.gemv_parts_count(L.o, dt) for L in self.layers)
-        n_d = min(ops.gemv_parts_count(L.down, dt) for L in self.layers)
-        self.deferred = self.tp_world == 1 and n_o >= 2 and n_d >= 2 and os.environ.get("PARO_DEFERRED_KSPLIT", "1") != "0"
+        n_o = min((ops.gemv_parts_count(L.o, dt) for L in self.layers), default=0)
+        n_d = min((ops.gemv_parts_count(L.down, dt) for L in self.layers), default=0)
+        self.deferred = self.tp_world == 1 and n_o >= 2 and n_d >= 2 and deferred_route_pays(c.hidden)
         if self.deferred:
             self.parts_o = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
             self.parts_d = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
         # ... and of qkv (2-way in the launch shape nobody polls in): its consumer is the attention kernel, where each q / k / v element
         # is read by ONE workgroup; the RMSNorm scalar travels as the K-slices' sums of squares (row N).  PARO_DEFERRED_QKV=0: off
-        self.deferred_qkv = self.deferred and min(ops.gemv_parts_count(L.qkv, dt) for L in self.layers) >= 2 \
+        self.deferred_qkv = self.deferred and min((ops.gemv_parts_count(L.qkv, dt) for L in self.layers), default=0) >= 2 \
             and os.environ.get("PARO_DEFERRED_QKV", "1") != "0"
         if self.deferred_qkv:
             self.parts_q = torch.zeros(qkv_w + 1, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)

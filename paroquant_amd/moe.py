@@ -16,6 +16,7 @@ and run ONE grouped W4A16 GEMM per projection over the expert segments (``paro_w
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -25,6 +26,7 @@ from . import ops
 from .linear import PackedParoWeights
 
 _DECODE_SLOTS = 64      # (tokens x experts-per-token) up to which the slot kernels are used
+_DEBUG_CHECKS = os.environ.get("PARO_DEBUG_CHECKS", "0") == "1"
 
 
 class ParoMoEExperts:
@@ -70,6 +72,7 @@ class ParoMoEExperts:
         e.expert_idx, e.n_slots, e.x_slot_div = idx.data_ptr(), int(idx.numel()), int(x_div)
         e.wq_stride_bytes, e.sz_stride_bytes = wq.stride(0) * 4, sz.stride(0) * 4
         e.x_slot_stride, e.y_slot_stride = x.stride(0), y.stride(0)
+        e.n_experts = self.E
         ws = pk0.workspace
         with torch.cuda.device(x.device):
             nat.check(lib.paro_w4a16_gemv_experts(ctypes.byref(d), x.data_ptr(), y.data_ptr(), 1, ws.data_ptr(),
@@ -81,18 +84,17 @@ class ParoMoEExperts:
         T, k = indices.shape
         x = x.reshape(T, self.H).contiguous()
         out = torch.empty(T, k, self.H, dtype=x.dtype, device=x.device)
+        # Expert ids are validated ON THE DEVICE (paro_experts_t.n_experts, paro_w4a16_gemm_grouped's n_experts: an id outside [0, E) never
+        # reads out of bounds and its outputs are NaN) -- no device->host sync per MoE block, and the same guarantee under HIP-graph replay,
+        # where a host check cannot run.  PARO_DEBUG_CHECKS=1 adds the eager host check (IndexError) for debugging.
+        if _DEBUG_CHECKS and not torch.cuda.is_current_stream_capturing() and bool((indices.min() < 0) | (indices.max() >= self.E)):
+            raise IndexError(f"expert indices must lie in [0, {self.E})")
         if T * k <= _DECODE_SLOTS:
-            if not torch.cuda.is_current_stream_capturing() and bool((indices.min() < 0) | (indices.max() >= self.E)):
-                raise IndexError(f"expert indices must lie in [0, {self.E})")      # an id >= E would be an out-of-bounds weight read
             idx = indices.reshape(-1).to(torch.int32).contiguous()
             gu = torch.empty(T * k, 2 * self.I, dtype=x.dtype, device=x.device)
             self._slots(self.gate_up[0], self.gu_wq, self.gu_sz, x, gu, idx, k, nat.PROLOGUE_NONE)
             self._slots(self.down[0], self.dn_wq, self.dn_sz, gu, out.view(T * k, self.H), idx, 1, nat.PROLOGUE_SILU_MUL)
             return out
-        if indices.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-            bad = (indices.min() < 0) | (indices.max() >= self.E)      # an id >= E would be an out-of-bounds weight read
-            if bool(bad):
-                raise IndexError(f"expert indices must lie in [0, {self.E})")
         return self._grouped_prefill(x, indices, out)
 
     def _grouped_prefill(self, x: torch.Tensor, indices: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -104,9 +106,11 @@ class ParoMoEExperts:
         T, k = indices.shape
         S, E, dev, dt = T * k, self.E, x.device, x.dtype
         BM = 64 if S // E < 96 else 128                              # row block of the grouped GEMM (static: shapes only)
-        max_rows = (S + E * (BM - 1) + BM - 1) // BM * BM            # every expert's segment padded up to a block
-        flat = indices.reshape(-1).to(torch.int64)
-        counts = torch.zeros(E, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
+        max_rows = (S + (E + 1) * (BM - 1) + BM - 1) // BM * BM      # every expert's segment (+ the bucket of invalid ids) padded up to a block
+        raw = indices.reshape(-1).to(torch.int64)
+        bad = (raw < 0) | (raw >= E)
+        flat = torch.where(bad, torch.full_like(raw, E), raw)        # ids outside [0, E): bucket E -- the kernel skips its blocks (n_experts), NaN below
+        counts = torch.zeros(E + 1, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
         padded = (counts + (BM - 1)) // BM * BM
         pend = torch.cumsum(padded, 0)
         pstart, ustart = pend - padded, torch.cumsum(counts, 0) - counts
@@ -126,13 +130,14 @@ class ParoMoEExperts:
                               pk0.channel_scales, None, 0, group_size=pk0.group_size)
             with torch.cuda.device(dev):
                 nat.check(lib.paro_w4a16_gemm_grouped(ctypes.byref(d), xin.data_ptr(), yout.data_ptr(), max_rows, BM, block_expert.data_ptr(),
-                                                      wq.stride(0) * 4, sz.stride(0) * 4, nat.current_stream_ptr(dev)))
+                                                      wq.stride(0) * 4, sz.stride(0) * 4, E, nat.current_stream_ptr(dev)))
         grouped(gu0, self.gu_wq, self.gu_sz, xs, gu)
         act = torch.nn.functional.silu(gu[:, :self.I]) * gu[:, self.I:]
         ar = torch.ops.rotation.rotate(act.contiguous(), dn0.pairs[0], dn0.theta[0], dn0.channel_scales[0], 128)
         yd = torch.empty(max_rows, self.H, dtype=dt, device=dev)
         grouped(dn0, self.dn_wq, self.dn_sz, ar, yd)
         out.view(S, self.H).index_copy_(0, order, yd.index_select(0, dest))
+        out.view(S, self.H).masked_fill_(bad.unsqueeze(1), float("nan"))      # invalid ids: loud, like the decode slots
         return out
 
     def per_expert_prefill(self, x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:

@@ -447,14 +447,42 @@ def test_gemm_bf16(dev):
     assert po.rel_err(_np(y), ideal) < TIGHT_BF16
 
 
+# ---------------------------------------------------------------- the north star's shapes against the oracle, directly
+
+@pytest.mark.parametrize("K,sizes", [(4096, [4096]), (4096, [1024]), (4096, [4096, 1024, 1024]), (4096, [14336, 14336]), (14336, [4096])])
+def test_north_star_shapes_match_c_oracle(dev, K, sizes):
+    """BASELINE.json: "batch-1 INT4 GEMV at Llama-3-8B q/k/v/o/mlp shapes ... numerics within 1e-2 of CPU reference": every row of
+    BASELINE.md section 3 at one row (and three) against oracle/paro_cpu.c -- the C restatement of the reference algorithm
+    (rotation.cuh:91-173 half path, per-stage rounding; (q - z) s dequant; fp32 accumulation), itself checked against the numpy oracle
+    in tests/test_oracle_c.py -- through the per-call operator and, for the K-split shapes, the deferred-reduction route."""
+    from oracle import paro_cpu as pc
+    from paroquant_amd import ops
+    L = po.make_layer(K + sum(sizes), K, sizes)
+    pk = _packed(L, dev)
+    rng = np.random.default_rng(K ^ sum(sizes))
+    for rows in (1, 3):
+        x = rng.standard_normal((rows, K)).astype(np.float16)
+        ref = pc.linear_f16(x, dict(L, sizes=sizes)).astype(np.float32)
+        got = _np(pk.apply(_t(x, dev)))
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        assert po.rel_err(got, ref) < REL_TOL, (rows, po.rel_err(got, ref))
+        assert np.allclose(got, ref, rtol=1e-2, atol=1e-2 * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))))   # SURVEY 8c's second form
+    n = ops.gemv_parts_count(pk)
+    if n >= 2:          # the route the decoder harness takes for this shape: partial sums completed by paro_parts_finish
+        parts = torch.zeros(sum(sizes), 4, device=dev, dtype=torch.float32)
+        ops.w4a16_gemv_fused(_t(x[:1], dev), pk, 0, parts_out=parts, parts_n=n)
+        fin = ops.parts_finish(parts, out=torch.empty(sum(sizes), device=dev, dtype=torch.float16))
+        assert po.rel_err(_np(fin)[None], pc.linear_f16(x[:1], dict(L, sizes=sizes)).astype(np.float32)) < REL_TOL
+
+
 # ---------------------------------------------------------------- full-size properties (BASELINE shapes)
 
 @pytest.mark.parametrize("K,sizes", [(4096, [14336, 14336]), (14336, [4096]), (8192, [8192]),
                                      (8192, [28672, 28672]), (28672, [8192]), (8192, [8192, 1024, 1024])])
 def test_full_size_consistency_and_linearity(dev, K, sizes):
-    """At Llama-3-8B / 70B-class shapes the oracle is too slow, so use size-independent properties:
-    (i) fused == rotate-op -> dense matmul on the GPU-dequantised weights (each piece is separately
-    oracle-checked above); (ii) linearity in x."""
+    """Size-independent properties at Llama-3-8B / 70B-class shapes (the north star's named shapes are ALSO compared with the
+    oracle directly: test_north_star_shapes_match_c_oracle below): (i) fused == rotate-op -> dense matmul on the GPU-dequantised
+    weights (each piece is separately oracle-checked above); (ii) linearity in x."""
     from paroquant_amd import ops
     rng = np.random.default_rng(K)
     N = sum(sizes)

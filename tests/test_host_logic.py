@@ -452,3 +452,8 @@ def test_decoder_rope_scaling_and_unsupported_configs():
         DecoderConfig.from_hf({**base, "rope_scaling": {"rope_type": "yarn", "factor": 4.0}})
     with _pt.raises(NotImplementedError, match="partial rotary"):
         DecoderConfig.from_hf({**base, "partial_rotary_factor": 0.25})
+    with _pt.raises(NotImplementedError, match="partial rotary"):        # ... also where newer configs keep it: inside rope_parameters
+        DecoderConfig.from_hf({k: v for k, v in base.items() if k != "rope_theta"} | {"rope_parameters": {"rope_theta": 500000.0, "partial_rotary_factor": 0.5}})
+    # a default-type rope_parameters with the factor at 1.0 is fine and does not leak the key into `scaling`
+    ok = DecoderConfig.from_hf({k: v for k, v in base.items() if k != "rope_theta"} | {"rope_parameters": {"rope_theta": 500000.0, "partial_rotary_factor": 1.0, **sc}})
+    assert "partial_rotary_factor" not in (ok.rope_scaling or {})

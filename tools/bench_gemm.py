@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prefill-path microbench: fused linear at large M (rotate pre-pass + W4A16 MFMA GEMM), TFLOP/s = 2*M*K*N / time.
 
-    python tools/bench_gemm.py [--model llama3-8b] [--rows 2048,8192,65536] [--variants 0,2,4] [--dtype f16] [--rounds 3]
+    python tools/bench_gemm.py [--model llama3-8b] [--rows 2048,8192,65536] [--variants 0,1,2,4] [--dtype f16] [--rounds 3]
 
 Variants (include/paro_abi.h) are timed INTERLEAVED in one process, `rounds` rounds of `reps` calls each, and the
 median + min are reported (cdna guide rule 24: perf deltas come from within-probe interleaved rounds).
@@ -45,6 +45,9 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     variants = [int(v) for v in args.variants.split(",")]
+    bad = [v for v in variants if v not in (0, 1, 2, 4)]       # (variant 3 was removed in ABI v11)
+    if bad:
+        raise SystemExit(f"--variants: unknown GEMM variant(s) {bad}; the library builds 0 (auto), 1, 2 and 4")
     for name, K, sizes, _ in layer_shapes(args.model):
         if args.only and name not in args.only.split(","):
             continue
@@ -56,7 +59,7 @@ def main():
                 x.zero_()
             fns = {}
             for v in variants:
-                if v in (2, 3) and dt != torch.float16:
+                if v == 2 and dt != torch.float16:       # variant 2 keeps exact fp16 weights in registers: f16 only
                     continue
                 fns[v] = (lambda v=v: pk.apply(x)) if v == 0 else (lambda v=v: ops.w4a16_gemm_forced(x, pk, variant=v))
             for fn in fns.values():           # warm-up (also builds lazy state)
