@@ -412,6 +412,44 @@ int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t* C, int64_t
  * launch (the stage kernel behind rotation::rotate, rotation.cu:10-43). */
 int paro_rotate_parts(const paro_linear_t* L, const void* x, void* x_rot, int64_t rows, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Persistent decode engine (v13): a CHAIN of linears at batch 1 in ONE launch.  The reference issues `rotate -> INT4 GEMM` per
+ * linear (transformers/modules.py:57-71, vllm/plugin.py:281-311; RotateQuantizedLinear x 3 + activation inside an HF MLP block,
+ * transformers' LlamaMLP.forward); at one row that is a chain of dependent launches of a few microseconds each.  Here one resident
+ * grid (one 16-wave workgroup per compute unit) runs the whole chain: every CU requests its INT4 tiles of linear i + 1 while linear
+ * i's outputs are still being handed over, each 128-channel group is rotated ONCE per partition (by one wave, from the producers'
+ * fp32 partial sums) and handed to the CUs that multiply by it -- csrc/engine.hip describes the protocol.
+ *   phase i :  y_i = rotate_i(x_i * cs_i) @ dequant(W_i) + bias_i,  rounded once to the activation type (what the linear would have
+ *              stored);  x_0 = x,  x_{i+1} = y_i[in_col0_{i+1} : in_col0_{i+1} + K_{i+1}]
+ * One row; krot <= 8; quantisation group_size 128; in_col0 even.  All layers of a chain share the activation type.
+ *   paro_engine_plan   host only: chooses the work split for `n_cus` compute units (0 = the current device's) and fills `out`
+ *                      (sizes of the plan blob and of the workspace).
+ *   paro_engine_build  host only: writes the plan blob (plan_bytes) into HOST memory; the caller copies it to the device.  The
+ *                      blob holds the layers' device pointers (wq / sz / rot / channel_scales / bias): they must stay alive and in
+ *                      place while the plan is in use.
+ *   paro_engine_run    one launch on `stream`; HIP-graph capturable, no host work on replay.  workspace: workspace_bytes,
+ *                      zero-filled ONCE by the caller, private to this engine instance (launches of one instance must not overlap).
+ *                      Workspace word 1 is the sticky status of the hand-offs (PARO_WS_STATUS_GIVEUP: a wait was abandoned after
+ *                      its bound and the outputs are NaN -- impossible while the whole grid is resident, which the call checks).
+ *   paro_engine_describe  the split the planner chose for one phase (K-chunks, most / fewest tiles per CU): tooling and tests. */
+typedef struct paro_engine_phase {
+  const struct paro_linear* L;
+  int64_t in_col0;       /* first column of the previous phase's output that this linear reads (0 for phase 0) */
+  int32_t flags;         /* reserved, 0 */
+  int32_t reserved0;
+} paro_engine_phase_t;
+typedef struct paro_engine {
+  int32_t n_phases, n_cus, act_dtype, last_split;
+  int64_t plan_bytes, workspace_bytes, in_features, out_features, last_out_offset;
+  const void* last_bias;
+} paro_engine_t;
+int paro_engine_plan(const paro_engine_phase_t* phases, int n_phases, int n_cus, paro_engine_t* out);
+int paro_engine_build(const paro_engine_phase_t* phases, const paro_engine_t* e, void* plan_host);
+int paro_engine_describe(const paro_engine_phase_t* phases, const paro_engine_t* e, int phase, int32_t* out_split,
+                         int32_t* out_max_tiles, int32_t* out_min_tiles);
+int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */
 int paro_dequant_packed(const paro_linear_t* L, void* out_w, void* stream);

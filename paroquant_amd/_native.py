@@ -63,6 +63,10 @@ EXPORTS = (
     "paro_allreduce_buffer_destroy",
     "paro_allreduce_status",
     "paro_allreduce_oneshot",
+    "paro_engine_plan",
+    "paro_engine_build",
+    "paro_engine_describe",
+    "paro_engine_run",
 )
 
 
@@ -104,6 +108,20 @@ class ParoExperts(Structure):
     _fields_ = [("expert_idx", c_void_p), ("n_slots", c_int32), ("x_slot_div", c_int32), ("wq_stride_bytes", c_int64),
                 ("sz_stride_bytes", c_int64), ("x_slot_stride", c_int64), ("y_slot_stride", c_int64), ("n_experts", c_int32),
                 ("reserved0", c_int32)]
+
+
+class ParoEnginePhase(Structure):
+    """``paro_engine_phase_t`` (include/paro_abi.h)."""
+
+    _fields_ = [("L", POINTER(ParoLinearDesc)), ("in_col0", c_int64), ("flags", c_int32), ("reserved0", c_int32)]
+
+
+class ParoEngine(Structure):
+    """``paro_engine_t`` (include/paro_abi.h)."""
+
+    _fields_ = [("n_phases", c_int32), ("n_cus", c_int32), ("act_dtype", c_int32), ("last_split", c_int32), ("plan_bytes", c_int64),
+                ("workspace_bytes", c_int64), ("in_features", c_int64), ("out_features", c_int64), ("last_out_offset", c_int64),
+                ("last_bias", c_void_p)]
 
 
 class ParoChain(Structure):
@@ -224,6 +242,14 @@ def load() -> ctypes.CDLL:
     lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.paro_dequant_packed.restype = c_int
     lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
+    lib.paro_engine_plan.restype = c_int
+    lib.paro_engine_plan.argtypes = [POINTER(ParoEnginePhase), c_int, c_int, POINTER(ParoEngine)]
+    lib.paro_engine_build.restype = c_int
+    lib.paro_engine_build.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_void_p]
+    lib.paro_engine_describe.restype = c_int
+    lib.paro_engine_describe.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
+    lib.paro_engine_run.restype = c_int
+    lib.paro_engine_run.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:
         raise RuntimeError(f"paroquant_amd: ABI version mismatch (library {lib.paro_abi_version()}, "
                            f"binding {PARO_ABI_VERSION})")

@@ -1,0 +1,695 @@
+// Persistent decode engine for gfx950: a whole CHAIN of ParoQuant linears (batch 1) in ONE launch.
+//
+// The reference runs `rotate -> INT4 GEMM` per linear (transformers/modules.py:57-71, vllm/plugin.py:281-311): at batch 1 that is
+// a chain of dependent launches, each of which pays the kernel boundary, its ramp and the first-byte latency before it streams a few
+// MB (round 1..3: 2.4 us + bytes / 7.5 TB/s per launch even for kernels that only stream; profiles/r03_overlap_probe2.jsonl).  The
+// weights never depend on the activations, so one RESIDENT grid can run ahead on them:
+//
+//   * grid = one 16-wave workgroup per CU, alive for the whole chain; phase = one linear;
+//   * per phase a CU owns (K-chunk s of `S`) x (a run of 16-column tiles inside ONE rotation partition): it needs the rotated x of
+//     its own few 128-channel groups only, and its tiles are requested one unit AHEAD -- across phase boundaries -- so that when a
+//     phase's x arrives its first tiles are already in registers (the run-ahead credit of the guide's engine, with the VGPR file as
+//     the ring: 15 waves x 2 units x 4 KiB per CU);
+//   * an edge (linear i -> linear i + 1) is two small hand-offs through memory, both as data-tagged 8-byte granules
+//     {tag, value} written with ONE write-through store and polled with relaxed agent-scope loads (cdna guide G16 recipe R2):
+//       hop 1  every CU's K-chunk partial sums {fp32}  ->  the ONE wave (service wave of some CU) that owns group g of partition p
+//              of the consumer: it adds the `S_prev` slots in order (+ bias), rounds once to the activation type -- the value the
+//              reference's linear would have stored --, multiplies by channel_scales and runs the eight Givens stages in registers;
+//       hop 2  that wave publishes the rotated group {2 activations}  ->  the CUs whose K-chunk contains g gather it into LDS.
+//     So a group is rotated ONCE per partition per phase (the fused GEMV re-rotated all of x in every workgroup: 20 MB of schedule
+//     words through the CUs next to 8 MB of weights on Qwen3-4B qkv), and nothing is all-gathered: a CU reads
+//     ng x 512 B.
+//   * tags count phases inside the launch on top of an epoch word in the workspace that the LAST phase's finisher advances: a
+//     captured launch replays without host work and no granule is ever re-armed.
+//
+// Numerics: per (K-chunk, column) the groups are accumulated in a fixed order (wave order is static), the K-chunks are added in slot
+// order, one rounding to the activation type per linear: deterministic, and within the parity tolerance of the oracle
+// (tests/test_gpu_engine.py); NOT bit-identical to the per-call kernels, whose K partition differs.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "chain_impl.hpp"
+
+namespace paro {
+
+constexpr int kEngWaves = 16;          // waves per workgroup: 15 compute + 1 service
+constexpr int kEngCompute = 15;
+constexpr int kEngTw = 4;              // tiles per unit (two units of 4 KiB in flight per wave)
+constexpr int kEngMaxSplit = 4;        // K-chunks per linear
+constexpr int kEngMaxGroups = 128;     // groups of one K-chunk (LDS: 272 B each)
+constexpr int kEngMaxTiles = 60;       // tiles of one CU and phase (publishing threads: 60 x 16 <= 15 waves)
+constexpr unsigned kEngSpin = 1u << 21;
+constexpr int kEngXsStride = 136;      // halves per group row in LDS (128 + 8 pad: the fragment reads of different rows spread over banks)
+int validate_linear(const paro_linear_t* L);   // gemv.hip
+
+struct alignas(16) EngPhase {          // 144 bytes, one per phase, read with scalar loads
+  const u32x4* wq;
+  const unsigned* sz;
+  const unsigned* rot;
+  const unsigned short* cs;            // [P][K]
+  const unsigned short* bias_prev;     // bias of the linear that produced this phase's input (added where its partial sums are completed)
+  unsigned wq_bytes, sz_bytes;
+  int G, T, tstride, gstride;          // tile (t, g) = chunk t * tstride + g * gstride
+  int szrow;                           // words per group row of the scale / zero array
+  int P, S, S_prev;
+  int in_col0;                         // channel c of this phase = column in_col0 + c of the previous phase's output
+  int N, K, n_tasks;
+  int work_off, N_prev, pad0, pad1;    // work_off: first EngWork of this phase
+  // Every phase has its OWN hop buffers (granule offsets into the workspace): nothing is reused inside a launch, so a CU that lags
+  // behind -- e.g. one whose outputs the next linear does not read (k / v columns in a chain without attention) -- can never find a
+  // granule it still waits for overwritten by a later phase.
+  long long yoff, yoff_prev;           // partial sums {tag, fp32}: slot s at yoff + s * N
+  long long xoff, pad2;                // rotated input {tag, two activations}: partition p, group g at xoff + p * (K / 2) + g * 64
+};
+static_assert(sizeof(EngPhase) == 144, "phase record");
+
+struct alignas(16) EngWork {           // 32 bytes per (phase shape, CU)
+  short s, p, g0, ng;                  // K-chunk, partition, first group, groups (0: no units in this phase)
+  int t0;                              // first tile (global tile index)
+  int tz0;                             // its padded scale / zero tile
+  short nt, nb, tw, pad0;              // tiles; column blocks (1, 3, 5 or 15) of `tw` tiles each
+  int pad[2];
+};
+static_assert(sizeof(EngWork) == 32, "work record");
+
+struct EngArgs {
+  const EngPhase* phases;
+  const EngWork* work;
+  const unsigned short* x;             // [K of phase 0]
+  unsigned short* y;                   // [N of the last phase]
+  unsigned* ctl;                       // [0] epoch, [1] status, [2] CUs that have read the epoch
+  unsigned long long* gran;            // the hop buffers (EngPhase::yoff / xoff)
+  const unsigned short* bias_last;
+  long long yoff_last;
+  int n_phases, ncu, N_last, S_last;
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned long long ld_gran(const T* p) {
+  return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_gran(unsigned long long* p, unsigned tag, unsigned v) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename AT>
+__global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a) {
+  typedef Act<AT> A;
+  typedef typename A::vec8 vec8;
+  constexpr int XS_STRIDE = kEngXsStride;
+  constexpr int XS_BYTES = (kEngMaxGroups + 1) * XS_STRIDE * 2;         // + the zero row
+  constexpr int RED_BYTES = kEngCompute * kEngTw * 16 * 4;
+  constexpr int SVC_BYTES = 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XS_BYTES + RED_BYTES + SVC_BYTES];
+  unsigned short* xs = (unsigned short*)lds;
+  unsigned short* zrow = xs + kEngMaxGroups * XS_STRIDE;
+  float* red = (float*)(lds + XS_BYTES);
+  unsigned short* svc = (unsigned short*)(lds + XS_BYTES + RED_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cu = blockIdx.x;
+  const bool service = wave == kEngCompute;
+  // the launch's base tag: advanced by the previous launch's finisher, which first waits until every CU has read it (ctl[2]; the add's
+  // operand depends on the value read, so it cannot overtake the read)
+  const unsigned epoch = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    unsigned one = 1u;
+    asm volatile("" : "+v"(one) : "v"(epoch));             // a data dependency the compiler cannot fold away
+    __hip_atomic_fetch_add(a.ctl + 2, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const unsigned nan2 = (unsigned)A::from_f32(__builtin_nanf("")) * 0x10001u;
+  if (tid < XS_STRIDE / 4) *(u32x2*)(zrow + 4 * tid) = (u32x2){0u, 0u};
+
+  // A-fragment addressing of a one-row product: MFMA row 0 carries x, the other fifteen rows read the zero row
+  const int mrow = lane & 15, mq = lane >> 4, n16 = lane & 15;
+  const bool avalid = mrow == 0;
+  const typename A::Unpack upk = A::unpack_consts();
+
+  struct TBuf {
+    u32x4 q[kEngTw];
+    unsigned szw[kEngTw];
+  };
+  // tile requests of one unit: `tw` tiles of group g from tile t (the unused slots of a narrower unit point OUTSIDE the buffer: a
+  // buffer load beyond num_records returns zeros and fetches nothing, so the request count stays static for the vmcnt bookkeeping)
+  auto load_unit = [&](TBuf& b, const EngPhase& ph, int g, int t, int tz, int n) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)ph.wq, 0, (int)ph.wq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph.sz, 0, (int)ph.sz_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < kEngTw; ++j) {
+      const unsigned off = j < n ? ((unsigned)((t + j) * ph.tstride + g * ph.gstride) * 1024u + (unsigned)lane * 16u) : 0xfffffff0u;
+      b.q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 2));   // aux 2 = nt: streamed once
+    }
+#pragma unroll
+    for (int j = 0; j < kEngTw; ++j) {
+      const int ts = tz + j;
+      const unsigned off = j < n ? ((unsigned)(g * ph.szrow) + (unsigned)(((ts >> 2) * 16 + n16) * 4 + (ts & 3))) * 4u : 0xfffffff0u;
+      b.szw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+    }
+  };
+  // this wave's place among the units of (phase, CU): column block b, rank r among the block's `nwb` waves
+  auto place = [&](const EngWork& w, int& b, int& r, int& nwb) {
+    const int nb = w.nb;
+    if (nb == 1) { b = 0; r = wave; }
+    else if (nb == 3) { b = wave % 3; r = wave / 3; }
+    else if (nb == 5) { b = wave % 5; r = wave / 5; }
+    else { b = wave; r = 0; }
+    nwb = kEngCompute / nb;
+  };
+
+  TBuf tc, tn;
+  // ---- the first unit of phase 0 (compute waves): requested before anything is waited for
+  {
+    const EngPhase& ph = a.phases[0];
+    const EngWork& w = a.work[ph.work_off + cu];
+    int b, r, nwb;
+    place(w, b, r, nwb);
+    const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
+    const bool has = !service && r < w.ng && nt_b > 0;
+    load_unit(tc, ph, w.g0 + (has ? r : 0), w.t0 + b * w.tw, w.tz0 + b * w.tw, has ? nt_b : 0);
+  }
+
+  for (int pi = 0; pi < a.n_phases; ++pi) {
+    const EngPhase& ph = a.phases[pi];
+    const EngWork& w = a.work[ph.work_off + cu];
+    const unsigned tag = epoch + (unsigned)pi + 1u;        // of this phase's OUTPUT and of its rotated input
+    const unsigned tag_in = epoch + (unsigned)pi;          // of the previous phase's partial sums
+    unsigned long long* xr = a.gran + ph.xoff;
+    const unsigned long long* yin = a.gran + ph.yoff_prev;
+    unsigned long long* yout = a.gran + ph.yoff;
+    const long long xpart = ph.K / 2;
+
+    // ---- service wave: the rotation tasks of this phase that live on this CU (task = (partition, group); task id = CU, CU + ncu, ...)
+    if (service) {
+      for (int task = cu; task < ph.n_tasks; task += a.ncu) {
+        const int p = task / ph.G, g = task - p * ph.G;
+        GivensRegs<AT, 1> gr;
+        gr.load((CGP<unsigned>)ph.rot, (unsigned)(p * ph.G + g), lane);
+        const unsigned csv = *(CGP<unsigned>)(ph.cs + (unsigned)(p * ph.K + g * 128 + 2 * lane));
+        float x0, x1;
+        if (pi == 0) {
+          const unsigned xv = *(CGP<unsigned>)(a.x + (unsigned)(g * 128 + 2 * lane));
+          x0 = A::to_f32(xv & 0xffffu);
+          x1 = A::to_f32(xv >> 16);
+        } else {
+          // hop 1: the S_prev partial sums of this lane's two channels, every slot polled in one batch
+          const unsigned long long* src = yin + (unsigned)(ph.in_col0 + g * 128 + 2 * lane);
+          unsigned long long g0[kEngMaxSplit], g1[kEngMaxSplit];
+          bool ok = false;
+          for (unsigned spin = 0; !ok; ++spin) {
+            ok = true;
+#pragma unroll
+            for (int s = 0; s < kEngMaxSplit; ++s)
+              if (s < ph.S_prev) {
+                g0[s] = ld_gran(src + (long long)s * ph.N_prev);
+                g1[s] = ld_gran(src + (long long)s * ph.N_prev + 1);
+              }
+#pragma unroll
+            for (int s = 0; s < kEngMaxSplit; ++s)
+              if (s < ph.S_prev) ok = ok && (unsigned)(g0[s] >> 32) == tag_in && (unsigned)(g1[s] >> 32) == tag_in;
+            ok = __all(ok);
+            if (!ok) {
+              if (spin > kEngSpin) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+          for (int s = 0; s < kEngMaxSplit; ++s)
+            if (s < ph.S_prev) {
+              v0 += __builtin_bit_cast(float, (unsigned)g0[s]);
+              v1 += __builtin_bit_cast(float, (unsigned)g1[s]);
+            }
+          if (!ok) v0 = v1 = __builtin_nanf("");            // a hand-off that gave up is never a silently wrong number
+          if (ph.bias_prev) {
+            const unsigned bv = *(CGP<unsigned>)(ph.bias_prev + (unsigned)(ph.in_col0 + g * 128 + 2 * lane));
+            v0 += A::to_f32(bv & 0xffffu);
+            v1 += A::to_f32(bv >> 16);
+          }
+          x0 = A::to_f32(A::from_f32(v0));                  // the one rounding of the producing linear
+          x1 = A::to_f32(A::from_f32(v1));
+        }
+        gr.prepare();
+        gr.seed(0, x0, x1, csv);
+        gr.stages();
+        gr.finish(svc);                                     // natural channel order, 128 halves
+        __builtin_amdgcn_wave_barrier();
+        const unsigned pr = *(const unsigned*)(svc + 2 * lane);
+        __builtin_amdgcn_wave_barrier();
+        st_gran(xr + (long long)p * xpart + (unsigned)(g * 64 + lane), tag, pr);   // hop 2: the data IS the flag
+      }
+    }
+
+    // ---- hop 2, consumer side: the rotated groups of this CU's K-chunk into LDS (every wave takes groups wave, wave + 16, ...)
+    if (w.ng > 0) {
+      const unsigned long long* src = xr + (long long)w.p * xpart + (unsigned)(w.g0 * 64 + lane);
+      for (int i0 = wave; i0 < w.ng; i0 += kEngWaves * 4) {
+        unsigned long long gq[4];
+        bool ok = false;
+        for (unsigned spin = 0; !ok; ++spin) {
+          ok = true;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * kEngWaves;
+            if (i < w.ng) gq[q] = ld_gran(src + i * 64);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * kEngWaves;
+            if (i < w.ng) ok = ok && (unsigned)(gq[q] >> 32) == tag;
+          }
+          ok = __all(ok);
+          if (!ok) {
+            if (spin > kEngSpin) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q * kEngWaves;
+          if (i < w.ng) *(unsigned*)(xs + i * XS_STRIDE + 2 * lane) = ok ? (unsigned)gq[q] : nan2;   // (gave up: NaN)
+        }
+      }
+    }
+    lds_barrier();                                          // B1: x of this phase is staged
+
+    // ---- compute waves: units (group, column block); the NEXT unit's tiles -- of this phase or the first of the next -- in flight
+    float acc[kEngTw] = {0.f, 0.f, 0.f, 0.f};
+    if (!service) {
+      int b, r, nwb;
+      place(w, b, r, nwb);
+      const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
+      const int tb = w.t0 + b * w.tw, tzb = w.tz0 + b * w.tw;
+      const bool has = nt_b > 0;
+      for (int gi = r; gi < w.ng && has; gi += nwb) {
+        const bool more = gi + nwb < w.ng;
+        if (more) {
+          load_unit(tn, ph, w.g0 + gi + nwb, tb, tzb, nt_b);
+        } else if (pi + 1 < a.n_phases) {
+          const EngPhase& ph2 = a.phases[pi + 1];
+          const EngWork& w2 = a.work[ph2.work_off + cu];
+          int b2, r2, nwb2;
+          place(w2, b2, r2, nwb2);
+          const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
+          const bool has2 = r2 < w2.ng && nt2 > 0;
+          load_unit(tn, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
+        }
+        // fragments of the rotated group, the two sums, unpack -> MFMA -> scale / zero (gemv_impl.hpp's unit, one row)
+        vec8 af[4];
+        {
+          const unsigned short* afrag = (avalid ? xs + gi * XS_STRIDE : zrow) + 8 * mq;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
+        }
+        f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
+        {
+          const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+          const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
+            so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kEngTw; ++j) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned w4[4];
+            A::unpack_fast(tc.q[j][i], w4, upk);
+            const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+            d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+          }
+          const float s = f16_bits_to_f32(tc.szw[j] & 0xffffu), zf = f16_bits_to_f32(tc.szw[j] >> 16);
+          acc[j] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[0], d[0] - so[0]), acc[j]);
+        }
+        tc = tn;
+      }
+      // a wave without units in this phase still owes the NEXT phase its first unit's requests
+      if (!(has && r < w.ng) && pi + 1 < a.n_phases) {
+        const EngPhase& ph2 = a.phases[pi + 1];
+        const EngWork& w2 = a.work[ph2.work_off + cu];
+        int b2, r2, nwb2;
+        place(w2, b2, r2, nwb2);
+        const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
+        const bool has2 = r2 < w2.ng && nt2 > 0;
+        load_unit(tc, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < kEngTw; ++j) red[(wave * kEngTw + j) * 16 + lane] = acc[j];
+      }
+    }
+    lds_barrier();                                          // B2: every wave's partial sums are staged
+
+    // ---- hop 1, producer side: this CU's outputs over its K-chunk, one {tag, fp32} granule each (wave order = group order: static)
+    if (tid < w.nt * 16) {
+      const int j = tid >> 4, n = tid & 15;
+      const int b = j / w.tw, jj = j - b * w.tw;
+      const int nwb = kEngCompute / w.nb;
+      float v = 0.f;
+      for (int r = 0; r < nwb; ++r) v += red[((r * w.nb + b) * kEngTw + jj) * 16 + n];
+      st_gran(yout + (long long)w.s * ph.N + (unsigned)((w.t0 + j) * 16 + n), tag, __builtin_bit_cast(unsigned, v));
+    }
+    // (red is rewritten only behind the next phase's B1, which every publishing thread reaches after its reads)
+  }
+
+  // ---- the last phase's outputs: completed like a rotation task's input (slots in order, bias, one rounding), 128 columns per task
+  if (service) {
+    const unsigned tag_in = epoch + (unsigned)a.n_phases;
+    const unsigned long long* yin = a.gran + a.yoff_last;
+    const int n_fin = (a.N_last + 127) / 128;
+    for (int task = cu; task < n_fin; task += a.ncu) {
+      const int c = task * 128 + 2 * lane;
+      if (c < a.N_last) {
+        unsigned long long g0[kEngMaxSplit], g1[kEngMaxSplit];
+        bool ok = false;
+        for (unsigned spin = 0; !ok; ++spin) {
+          ok = true;
+#pragma unroll
+          for (int s = 0; s < kEngMaxSplit; ++s)
+            if (s < a.S_last) {
+              g0[s] = ld_gran(yin + (long long)s * a.N_last + c);
+              g1[s] = ld_gran(yin + (long long)s * a.N_last + c + 1);
+              ok = ok && (unsigned)(g0[s] >> 32) == tag_in && (unsigned)(g1[s] >> 32) == tag_in;
+            }
+          if (!ok) {
+            if (spin > kEngSpin) { a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < kEngMaxSplit; ++s)
+          if (s < a.S_last) {
+            v0 += __builtin_bit_cast(float, (unsigned)g0[s]);
+            v1 += __builtin_bit_cast(float, (unsigned)g1[s]);
+          }
+        if (!ok) v0 = v1 = __builtin_nanf("");
+        if (a.bias_last) {
+          const unsigned bv = *(CGP<unsigned>)(a.bias_last + c);
+          v0 += A::to_f32(bv & 0xffffu);
+          v1 += A::to_f32(bv >> 16);
+        }
+        *(unsigned*)(a.y + c) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
+      }
+    }
+    // The next launch's tags start above this launch's.  Whoever advances the word must know that every CU has read it: CU 0's
+    // service wave waits for the arrival count (bounded), clears it and stores the new epoch; the kernel boundary publishes both.
+    if (cu == 0) {
+      unsigned seen = 0;
+      for (unsigned spin = 0; seen != (unsigned)a.ncu && spin < kEngSpin; ++spin) {
+        seen = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen != (unsigned)a.ncu) __builtin_amdgcn_s_sleep(8);
+      }
+      if (lane == 0) {
+        if (seen != (unsigned)a.ncu) a.ctl[1] = PARO_WS_STATUS_GIVEUP;
+        unsigned e2 = epoch + (unsigned)a.n_phases + 2u;
+        if (e2 < epoch) e2 = 1u;                            // wrap (tags of older launches are long overwritten)
+        __hip_atomic_store(a.ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ctl, e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host: the plan
+struct PhasePlan {
+  int S = 1;
+  std::vector<int> g0, ng;           // per K-chunk
+  std::vector<EngWork> work;         // per CU
+  long long cost = 0;
+};
+
+static int pick_blocks(int nt, int ng, int& nb, int& tw) {
+  // column blocks (1, 3, 5, 15) x rank waves: fewest unit steps per wave, then the fewest tiles per step
+  long long best = -1;
+  for (int cand : {1, 3, 5, 15}) {
+    const int t = (nt + cand - 1) / cand;
+    if (t > kEngTw || t < 1) continue;
+    const int nwb = kEngCompute / cand;
+    const int steps = (ng + nwb - 1) / nwb;
+    const long long c = (long long)steps * (150 + 130 * t);  // a unit step in cycles: fragments + the two sums, then ~130 per tile (unpack + MFMA)
+    if (best < 0 || c < best) { best = c; nb = cand; tw = t; }
+  }
+  return best < 0 ? -1 : 0;
+}
+
+static bool plan_phase(const paro_linear_t* L, int ncu, int S, PhasePlan& out) {
+  const int G = (int)(L->K / 128), P = L->n_parts;
+  if (S < 1 || S > kEngMaxSplit || S > G || ncu / S < P) return false;
+  const int per = ncu / S;                                   // CUs per K-chunk
+  PartTable pt;
+  if (!fill_part_table(pt, P, L->part_cols, 1)) return false;
+  // CUs of a K-chunk over the partitions, proportional to their tiles (largest remainder), at least one each
+  std::vector<int> cp(P, 1);
+  {
+    int left = per - P;
+    std::vector<double> want(P);
+    for (int p = 0; p < P; ++p) want[p] = (double)per * (pt.tile_start[p + 1] - pt.tile_start[p]) / pt.tiles;
+    while (left > 0) {
+      int bi = 0;
+      double bd = -1e30;
+      for (int p = 0; p < P; ++p) {
+        const double d = want[p] - cp[p];
+        if (d > bd) { bd = d; bi = p; }
+      }
+      cp[bi]++;
+      left--;
+    }
+    for (int p = 0; p < P; ++p) cp[p] = std::min(cp[p], pt.tile_start[p + 1] - pt.tile_start[p]);   // never more CUs than tiles
+  }
+  out.S = S;
+  out.g0.resize(S);
+  out.ng.resize(S);
+  {
+    EngWork idle{};
+    idle.nb = 1;
+    idle.tw = 1;                                             // (a CU without work in a phase: ng = nt = 0; the divisors stay sane)
+    out.work.assign(ncu, idle);
+  }
+  long long worst = 0;
+  for (int s = 0; s < S; ++s) {
+    out.g0[s] = (int)((long long)G * s / S);
+    out.ng[s] = (int)((long long)G * (s + 1) / S) - out.g0[s];
+    if (out.ng[s] > kEngMaxGroups) return false;
+    int c = s * per;
+    for (int p = 0; p < P; ++p) {
+      const int T = pt.tile_start[p + 1] - pt.tile_start[p];
+      for (int i = 0; i < cp[p]; ++i, ++c) {
+        const int a0 = (int)((long long)T * i / cp[p]), a1 = (int)((long long)T * (i + 1) / cp[p]);
+        EngWork& w = out.work[c];
+        w.s = (short)s; w.p = (short)p; w.g0 = (short)out.g0[s]; w.ng = (short)out.ng[s];
+        w.t0 = pt.tile_start[p] + a0;
+        w.tz0 = pt.szt_start[p] + a0;
+        w.nt = (short)(a1 - a0);
+        if (w.nt > kEngMaxTiles || w.nt < 1) return false;
+        int nb = 1, tw = 1;
+        if (pick_blocks(w.nt, w.ng, nb, tw) != 0) return false;
+        w.nb = (short)nb; w.tw = (short)tw;
+        const int nwb = kEngCompute / nb;
+        const long long steps = (w.ng + nwb - 1) / nwb;
+        // cycles: a CU ingests a 1 KiB tile in ~96 cycles (25 GB/s); its slowest wave then runs `steps` unit steps
+        worst = std::max(worst, 96ll * w.nt * w.ng + steps * (150 + 130 * tw));
+      }
+    }
+  }
+  out.cost = worst + 50ll * S;                                // (a split costs its hand-off volume: ties go to fewer chunks)
+  return true;
+}
+
+struct EnginePlanHost {
+  std::vector<EngPhase> phases;
+  std::vector<EngWork> work;
+  long long granules = 0, yoff_last = 0;
+  int S_last = 1;
+};
+
+static int build_plan(const paro_engine_phase_t* ph, int n, int ncu, EnginePlanHost& H) {
+  if (!ph || n < 1 || n > 4096) return fail(PARO_ERR_INVALID, "engine: 1..4096 phases");
+  if (ncu < kEngMaxSplit * PARO_MAX_PARTS) return fail(PARO_ERR_UNSUPPORTED, "engine: needs at least %d compute units", kEngMaxSplit * PARO_MAX_PARTS);
+  for (int i = 0; i < n; ++i) {
+    const paro_linear_t* L = ph[i].L;
+    int rc = validate_linear(L);
+    if (rc != PARO_OK) return rc;
+    if (L->krot > 8) return fail(PARO_ERR_UNSUPPORTED, "engine: krot <= 8 (packed rotation schedule)");
+    if (quant_group(L->group_size) != 128) return fail(PARO_ERR_UNSUPPORTED, "engine: quantisation group_size 128");
+    if (L->act_dtype != ph[0].L->act_dtype) return fail(PARO_ERR_INVALID, "engine: one activation type per chain");
+    if (i > 0) {
+      const paro_linear_t* Lp = ph[i - 1].L;
+      if (ph[i].in_col0 < 0 || (ph[i].in_col0 & 1) || ph[i].in_col0 + L->K > Lp->N)
+        return fail(PARO_ERR_INVALID, "engine: phase %d reads columns %lld..%lld of a %lld-column predecessor", i, (long long)ph[i].in_col0,
+                    (long long)(ph[i].in_col0 + L->K), (long long)Lp->N);
+    } else if (ph[i].in_col0 != 0) {
+      return fail(PARO_ERR_INVALID, "engine: phase 0 reads x from its first element");
+    }
+    if ((long long)L->K * L->N / 2 > 0x7fffffffll) return fail(PARO_ERR_UNSUPPORTED, "engine: packed weights of one linear must stay below 2 GiB");
+  }
+  H.phases.resize(n);
+  H.work.clear();
+  // identical linears (same shape) share one work table
+  struct Key { long long K, N; int P; int cols[PARO_MAX_PARTS]; int off; int S; };
+  std::vector<Key> seen;
+  int S_prev = 1;
+  long long gran = 0, yoff_prev = 0;
+  for (int i = 0; i < n; ++i) {
+    const paro_linear_t* L = ph[i].L;
+    const int G = (int)(L->K / 128);
+    int off = -1, S = 1;
+    for (const Key& k : seen) {
+      bool same = k.K == L->K && k.N == L->N && k.P == L->n_parts;
+      for (int p = 0; same && p < L->n_parts; ++p) same = k.cols[p] == L->part_cols[p];
+      if (same) { off = k.off; S = k.S; break; }
+    }
+    if (off < 0) {
+      PhasePlan best;
+      bool any = false;
+      for (int s = 1; s <= kEngMaxSplit; ++s) {
+        PhasePlan cand;
+        if (!plan_phase(L, ncu, s, cand)) continue;
+        if (!any || cand.cost < best.cost) { best = cand; any = true; }
+      }
+      if (!any) return fail(PARO_ERR_UNSUPPORTED, "engine: no work split for a [%lld, %lld] linear on %d compute units", (long long)L->K, (long long)L->N, ncu);
+      off = (int)H.work.size();
+      S = best.S;
+      H.work.insert(H.work.end(), best.work.begin(), best.work.end());
+      Key k{L->K, L->N, L->n_parts, {0}, off, S};
+      for (int p = 0; p < L->n_parts; ++p) k.cols[p] = L->part_cols[p];
+      seen.push_back(k);
+    }
+    EngPhase& e = H.phases[i];
+    memset(&e, 0, sizeof(e));
+    PartTable pt;
+    fill_part_table(pt, L->n_parts, L->part_cols, 1);
+    e.wq = (const u32x4*)L->wq; e.sz = (const unsigned*)L->sz; e.rot = (const unsigned*)L->rot; e.cs = (const unsigned short*)L->channel_scales;
+    e.bias_prev = i > 0 ? (const unsigned short*)ph[i - 1].L->bias : nullptr;
+    e.wq_bytes = (unsigned)(L->K * L->N / 2);
+    e.sz_bytes = (unsigned)((long long)G * pt.tsz * 16 * 4);
+    e.G = G; e.T = pt.tiles;
+    e.tstride = L->wq_order ? 1 : G;
+    e.gstride = L->wq_order ? pt.tiles : 1;
+    e.szrow = (pt.tsz >> 2) * 64;
+    e.P = L->n_parts; e.S = S; e.S_prev = S_prev;
+    e.in_col0 = (int)ph[i].in_col0;
+    e.N = (int)L->N; e.K = (int)L->K;
+    e.n_tasks = G * L->n_parts;
+    e.work_off = off;
+    e.N_prev = i > 0 ? (int)ph[i - 1].L->N : 0;
+    e.xoff = gran;
+    gran += (long long)L->n_parts * (L->K / 2);
+    e.yoff = gran;
+    gran += (long long)S * L->N;
+    e.yoff_prev = yoff_prev;
+    yoff_prev = e.yoff;
+    S_prev = S;
+  }
+  H.S_last = S_prev;
+  H.yoff_last = yoff_prev;
+  H.granules = gran;
+  return PARO_OK;
+}
+
+static long long plan_bytes_of(const EnginePlanHost& H) { return (long long)(H.phases.size() * sizeof(EngPhase) + H.work.size() * sizeof(EngWork)); }
+static long long ws_bytes_of(const EnginePlanHost& H) { return 256 + H.granules * 8; }
+
+}  // namespace paro
+
+extern "C" int paro_engine_plan(const paro_engine_phase_t* phases, int n_phases, int n_cus, paro_engine_t* out) {
+  using namespace paro;
+  if (!out) return fail(PARO_ERR_INVALID, "null pointer");
+  if (n_cus <= 0) n_cus = device_cu_count();
+  EnginePlanHost H;
+  int rc = build_plan(phases, n_phases, n_cus, H);
+  if (rc != PARO_OK) return rc;
+  out->n_phases = n_phases;
+  out->n_cus = n_cus;
+  out->act_dtype = phases[0].L->act_dtype;
+  out->last_split = H.S_last;
+  out->last_out_offset = H.yoff_last;
+  out->last_bias = phases[n_phases - 1].L->bias;
+  out->plan_bytes = plan_bytes_of(H);
+  out->workspace_bytes = ws_bytes_of(H);
+  out->in_features = phases[0].L->K;
+  out->out_features = phases[n_phases - 1].L->N;
+  return PARO_OK;
+}
+
+extern "C" int paro_engine_build(const paro_engine_phase_t* phases, const paro_engine_t* e, void* plan_host) {
+  using namespace paro;
+  if (!e || !plan_host) return fail(PARO_ERR_INVALID, "null pointer");
+  EnginePlanHost H;
+  int rc = build_plan(phases, e->n_phases, e->n_cus, H);
+  if (rc != PARO_OK) return rc;
+  if (plan_bytes_of(H) != e->plan_bytes) return fail(PARO_ERR_INVALID, "engine descriptor does not belong to these phases");
+  unsigned char* dst = (unsigned char*)plan_host;
+  memcpy(dst, H.phases.data(), H.phases.size() * sizeof(EngPhase));
+  memcpy(dst + H.phases.size() * sizeof(EngPhase), H.work.data(), H.work.size() * sizeof(EngWork));
+  return PARO_OK;
+}
+
+extern "C" int paro_engine_describe(const paro_engine_phase_t* phases, const paro_engine_t* e, int phase, int32_t* out_split,
+                                    int32_t* out_max_tiles, int32_t* out_min_tiles) {
+  using namespace paro;
+  if (!e || phase < 0 || phase >= e->n_phases) return fail(PARO_ERR_INVALID, "bad phase");
+  EnginePlanHost H;
+  int rc = build_plan(phases, e->n_phases, e->n_cus, H);
+  if (rc != PARO_OK) return rc;
+  const EngPhase& p = H.phases[phase];
+  int mx = 0, mn = 1 << 30;
+  for (int c = 0; c < e->n_cus; ++c) {
+    const EngWork& w = H.work[p.work_off + c];
+    const int t = w.nt * w.ng;
+    mx = std::max(mx, t);
+    mn = std::min(mn, t);
+  }
+  if (out_split) *out_split = p.S;
+  if (out_max_tiles) *out_max_tiles = mx;
+  if (out_min_tiles) *out_min_tiles = mn;
+  return PARO_OK;
+}
+
+extern "C" int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  using namespace paro;
+  if (!e || !plan_dev || !x || !y || !workspace) return fail(PARO_ERR_INVALID, "null pointer");
+  if (workspace_bytes < e->workspace_bytes) return fail(PARO_ERR_INVALID, "engine workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)e->workspace_bytes);
+  if (e->n_phases < 1 || e->last_split < 1 || e->last_split > kEngMaxSplit || e->plan_bytes < (int64_t)e->n_phases * (int64_t)sizeof(EngPhase))
+    return fail(PARO_ERR_INVALID, "engine descriptor was not produced by paro_engine_plan");
+  if (e->act_dtype != PARO_DTYPE_F16 && e->act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  EngArgs a;
+  a.phases = (const EngPhase*)plan_dev;
+  a.work = (const EngWork*)((const unsigned char*)plan_dev + (size_t)e->n_phases * sizeof(EngPhase));
+  a.x = (const unsigned short*)x;
+  a.y = (unsigned short*)y;
+  a.ctl = (unsigned*)workspace;
+  a.gran = (unsigned long long*)((unsigned char*)workspace + 256);
+  a.bias_last = (const unsigned short*)e->last_bias;
+  a.yoff_last = e->last_out_offset;
+  a.n_phases = e->n_phases;
+  a.ncu = e->n_cus;
+  a.N_last = (int)e->out_features;
+  a.S_last = e->last_split;
+  // every workgroup of the grid must be resident at once (they wait for each other): one 16-wave workgroup per CU
+  {
+    static int per_cu[3] = {-1, -1, -1};
+    int& per = per_cu[e->act_dtype];
+    if (per < 0) {
+      int v = 0;
+      hipError_t er = e->act_dtype == PARO_DTYPE_F16
+                          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<f16>, kEngWaves * 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<bf16>, kEngWaves * 64, 0);
+      per = (er == hipSuccess && v >= 1) ? v : 0;
+    }
+    if (per < 1) return fail(PARO_ERR_UNSUPPORTED, "engine: the kernel does not fit a compute unit");
+    if (e->n_cus > device_cu_count()) return fail(PARO_ERR_UNSUPPORTED, "engine: planned for %d compute units, the device has %d", e->n_cus, device_cu_count());
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (e->act_dtype == PARO_DTYPE_F16)
+    hipLaunchKernelGGL(engine_kernel<f16>, dim3((unsigned)e->n_cus), dim3(kEngWaves * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL(engine_kernel<bf16>, dim3((unsigned)e->n_cus), dim3(kEngWaves * 64), 0, st, a);
+  return check_launch("paro_engine_run");
+}

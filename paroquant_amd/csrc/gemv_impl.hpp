@@ -686,6 +686,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           // SLOWER -- and round 3 in the 8- / 16-wave builds only: down_proj -0.1 .. -0.3 us at one row, but the 16-wave build for
           // 2..4 rows came out of the compiler with nondeterministic results (tools/_stress-style loop: 136 mismatching runs of 150,
           // none without it; profiles/NOTES.md).  The compare stays.)
+#ifdef PARO_KROT8_FASTPATH   // experiment builds (make EXTRA=-DPARO_KROT8_FASTPATH[=variant]): profiles/NOTES.md, round 4, "the reverted fast path"
+          constexpr int FPV = PARO_KROT8_FASTPATH + 0;   // 1 plain, 2 + LDS-counter drain after every stage, 4 only the 8-wave builds, 5 only the 16-wave builds
+          constexpr bool FP_ON = FPV == 4 ? WAVES == 8 : (FPV == 5 ? WAVES == 16 : WAVES >= 8);
+          if (FP_ON && h.krot == 8) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              stage(pc, t, sa, sb);
+              if constexpr (FPV == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+          } else
+#endif
           {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {

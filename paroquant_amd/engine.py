@@ -1,0 +1,82 @@
+"""``DecodeEngine`` -- a chain of ParoQuant linears at batch 1 in ONE persistent launch (``paro_engine_*``, csrc/engine.hip).
+
+The reference runs ``rotate -> INT4 GEMM`` per linear (``transformers/modules.py:57-71``, ``vllm/plugin.py:281-311``); an HF MLP block is
+three such linears plus the activation (``down(act(gate(x)) * up(x))``).  At one row those are dependent launches of a few microseconds
+each; the engine keeps one resident grid that requests the next linear's INT4 tiles while the current linear's outputs are handed over,
+and rotates every 128-channel group once per partition.
+
+    eng = DecodeEngine([pk_a, pk_b, ...], in_col0=[0, c1, ...])      # linear i + 1 reads columns c .. c + K of linear i's output
+    y = eng(x)                                                        # x [1, K_0] fp16 / bf16  ->  y [1, N_last]
+
+The packed weights (``PackedParoWeights``) must stay alive while the engine is (the plan holds their device pointers)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import ops
+
+
+class DecodeEngine:
+    def __init__(self, layers: Sequence, in_col0: Optional[Sequence[int]] = None, dtype: torch.dtype = torch.float16, n_cus: int = 0):
+        lib = nat.load()
+        if not layers:
+            raise ValueError("DecodeEngine needs at least one linear")
+        self.layers = list(layers)
+        dev = self.layers[0].wq.device
+        if dev.type != "cuda":
+            raise RuntimeError("DecodeEngine needs the packed weights on a GPU (there is no CPU path)")
+        self.device, self.dtype = dev, dtype
+        n = len(self.layers)
+        in_col0 = [0] * n if in_col0 is None else [int(c) for c in in_col0]
+        if len(in_col0) != n:
+            raise ValueError("in_col0 needs one entry per linear")
+        self._descs = [ops.make_desc(pk.K, pk.partition_sizes, int(pk.pairs.size(1)), dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
+                                     pk.channel_scales, (pk.bias.to(dtype) if pk.bias is not None else None), pk.wq_order,
+                                     group_size=pk.group_size) for pk in self.layers]
+        self._bias = [pk.bias.to(dtype) if pk.bias is not None else None for pk in self.layers]   # (keeps converted biases alive)
+        for d, b in zip(self._descs, self._bias):
+            d.bias = b.data_ptr() if b is not None else None
+        self._phases = (nat.ParoEnginePhase * n)()
+        for i, d in enumerate(self._descs):
+            self._phases[i].L = ctypes.pointer(d)
+            self._phases[i].in_col0 = in_col0[i]
+            self._phases[i].flags = 0
+        self._e = nat.ParoEngine()
+        with torch.cuda.device(dev):
+            nat.check(lib.paro_engine_plan(self._phases, n, int(n_cus), ctypes.byref(self._e)))
+            host = np.zeros(int(self._e.plan_bytes), dtype=np.uint8)
+            nat.check(lib.paro_engine_build(self._phases, ctypes.byref(self._e), host.ctypes.data_as(ctypes.c_void_p)))
+        self.plan = torch.from_numpy(host).to(dev)
+        self.workspace = torch.zeros(int(self._e.workspace_bytes), dtype=torch.uint8, device=dev)     # zero-filled ONCE
+        self.K, self.N = int(self._e.in_features), int(self._e.out_features)
+        self.y = torch.empty(1, self.N, dtype=dtype, device=dev)
+
+    def describe(self):
+        """[(K-chunks, most tiles per CU, fewest tiles per CU)] per phase: what the planner chose."""
+        lib, out = nat.load(), []
+        for i in range(len(self.layers)):
+            s, mx, mn = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            nat.check(lib.paro_engine_describe(self._phases, ctypes.byref(self._e), i, ctypes.byref(s), ctypes.byref(mx), ctypes.byref(mn)))
+            out.append((s.value, mx.value, mn.value))
+        return out
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x.dtype != self.dtype or x.numel() != self.K or not x.is_contiguous() or x.device != self.device:
+            raise ValueError(f"DecodeEngine expects one contiguous row of {self.K} {self.dtype} activations on {self.device}")
+        y = self.y if out is None else out
+        if y.dtype != self.dtype or y.numel() != self.N or not y.is_contiguous():
+            raise ValueError(f"out must be a contiguous row of {self.N} {self.dtype} values")
+        with torch.cuda.device(self.device):
+            nat.check(nat.load().paro_engine_run(ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                                 self.workspace.data_ptr(), self.workspace.numel(), nat.current_stream_ptr(self.device)))
+        return y
+
+    def status_ok(self) -> bool:
+        """False once a hand-off inside a launch gave up waiting (outputs of that launch are NaN).  Synchronises."""
+        return int(self.workspace[4:8].view(torch.int32).item()) == 0

@@ -457,3 +457,80 @@ def test_decoder_rope_scaling_and_unsupported_configs():
     # a default-type rope_parameters with the factor at 1.0 is fine and does not leak the key into `scaling`
     ok = DecoderConfig.from_hf({k: v for k, v in base.items() if k != "rope_theta"} | {"rope_parameters": {"rope_theta": 500000.0, "partial_rotary_factor": 1.0, **sc}})
     assert "partial_rotary_factor" not in (ok.rope_scaling or {})
+
+
+def test_engine_planner_covers_every_tile_once(lib):
+    """`paro_engine_plan / _build` (host only; csrc/engine.hip): for the bench models' decoder layers on 256 CUs and a small odd case
+    on 64, the plan blob is decoded here and checked -- every (group, 16-column tile) of every linear belongs to exactly ONE compute
+    unit, a CU's tiles lie inside one rotation partition, the K-chunks partition the groups, unit blocks cover a CU's tiles, and no two
+    hop buffers overlap."""
+    import ctypes
+    import numpy as np
+    from paroquant_amd import _native as nat
+
+    def desc(K, sizes):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.group_size = K, sum(sizes), len(sizes), 8, 1, 128
+        for i, n in enumerate(sizes):
+            d.part_cols[i] = n
+        d.wq_order = 1 if d.N // 16 >= 1024 else 0
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)        # never dereferenced on the host
+        return d
+
+    phase_dt = np.dtype([("ptrs", "<u8", 5), ("wq_bytes", "<u4"), ("sz_bytes", "<u4"), ("G", "<i4"), ("T", "<i4"), ("tstride", "<i4"),
+                         ("gstride", "<i4"), ("szrow", "<i4"), ("P", "<i4"), ("S", "<i4"), ("S_prev", "<i4"), ("in_col0", "<i4"), ("N", "<i4"),
+                         ("K", "<i4"), ("n_tasks", "<i4"), ("work_off", "<i4"), ("N_prev", "<i4"), ("pad", "<i4", 2), ("yoff", "<i8"),
+                         ("yoff_prev", "<i8"), ("xoff", "<i8"), ("pad2", "<i8")])
+    work_dt = np.dtype([("s", "<i2"), ("p", "<i2"), ("g0", "<i2"), ("ng", "<i2"), ("t0", "<i4"), ("tz0", "<i4"), ("nt", "<i2"), ("nb", "<i2"),
+                        ("tw", "<i2"), ("pad0", "<i2"), ("pad", "<i4", 2)])
+    assert phase_dt.itemsize == 144 and work_dt.itemsize == 32
+    cases = {256: [[(2560, [4096, 1024, 1024]), (4096, [2560]), (2560, [9728, 9728]), (9728, [2560])] * 2,
+                   [(4096, [4096, 1024, 1024]), (4096, [4096]), (4096, [14336, 14336]), (14336, [4096])],
+                   [(1024, [2048, 1024, 1024]), (2048, [1024]), (1024, [3072, 3072]), (3072, [1024])],
+                   [(8192, [8192, 1024, 1024]), (8192, [8192]), (8192, [28672, 28672]), (28672, [8192])]],
+             64: [[(512, [400, 112]), (512, [384]), (384, [128, 64, 16])]]}
+    for ncu, chains in cases.items():
+        for shapes in chains:
+            descs = [desc(*s) for s in shapes]
+            ph = (nat.ParoEnginePhase * len(descs))()
+            for i, d in enumerate(descs):
+                ph[i].L, ph[i].in_col0 = ctypes.pointer(d), 0
+            e = nat.ParoEngine()
+            assert lib.paro_engine_plan(ph, len(descs), ncu, ctypes.byref(e)) == 0, lib.paro_last_error()
+            blob = np.zeros(e.plan_bytes, dtype=np.uint8)
+            assert lib.paro_engine_build(ph, ctypes.byref(e), blob.ctypes.data_as(ctypes.c_void_p)) == 0, lib.paro_last_error()
+            phases = blob[: len(descs) * 144].view(phase_dt)
+            work = blob[len(descs) * 144:].view(work_dt)
+            spans = []
+            for i, (K, sizes) in enumerate(shapes):
+                p = phases[i]
+                G, T = K // 128, sum(sizes) // 16
+                assert (p["G"], p["T"], p["K"], p["N"], p["P"]) == (G, T, K, sum(sizes), len(sizes)) and 1 <= p["S"] <= 4
+                assert p["S_prev"] == (phases[i - 1]["S"] if i else 1) and p["n_tasks"] == G * len(sizes)
+                cover = np.zeros((G, T), dtype=np.int32)
+                tstart = np.concatenate([[0], np.cumsum(np.asarray(sizes) // 16)])
+                for c in range(ncu):
+                    w = work[p["work_off"] + c]
+                    if w["ng"] == 0 or w["nt"] == 0:
+                        continue
+                    cover[w["g0"]:w["g0"] + w["ng"], w["t0"]:w["t0"] + w["nt"]] += 1
+                    assert tstart[w["p"]] <= w["t0"] and w["t0"] + w["nt"] <= tstart[w["p"] + 1]          # inside ONE partition
+                    assert w["nb"] in (1, 3, 5, 15) and 1 <= w["tw"] <= 4 and w["nb"] * w["tw"] >= w["nt"]  # the unit blocks cover the tiles
+                    assert w["ng"] <= 128 and w["nt"] <= 60 and 0 <= w["s"] < p["S"]
+                    # padded scale / zero tile space: partitions start at multiples of 8 tiles
+                    assert w["tz0"] == sum((n // 16 + 7) // 8 * 8 for n in sizes[:w["p"]]) + (w["t0"] - tstart[w["p"]])
+                assert (cover == 1).all(), (ncu, i, K, sizes)
+                spans += [(int(p["xoff"]), int(p["xoff"]) + len(sizes) * K // 2), (int(p["yoff"]), int(p["yoff"]) + int(p["S"]) * sum(sizes))]
+                assert p["yoff_prev"] == (phases[i - 1]["yoff"] if i else 0)
+            spans.sort()
+            assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:])) and 256 + spans[-1][1] * 8 == e.workspace_bytes
+            assert e.last_split == phases[-1]["S"] and e.last_out_offset == phases[-1]["yoff"]
+    # argument errors (host side): a consumer wider than its producer, group_size 64, an odd window start
+    a, b = desc(256, [128]), desc(256, [64])
+    ph = (nat.ParoEnginePhase * 2)()
+    ph[0].L, ph[1].L = ctypes.pointer(a), ctypes.pointer(b)
+    e = nat.ParoEngine()
+    assert lib.paro_engine_plan(ph, 2, 256, ctypes.byref(e)) == -1 and b"reads columns" in lib.paro_last_error()
+    a.group_size = 64
+    assert lib.paro_engine_plan(ph, 1, 256, ctypes.byref(e)) == -2

@@ -42,6 +42,13 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):
                 d1 = (y.float() - y_first.float()).abs().max().item(); d2 = (y2.float() - y2_first.float()).abs().max().item()
                 rowsbad = [(r, (y2[r].float() - y2_first[r].float()).abs().max().item()) for r in range(rows)]
                 print("MISMATCH iter", it, key, "dy", d1, "dy2", d2, rowsbad, flush=True)
+                if bad <= 6:     # the pattern of the first few: which columns (tile = col // 16), and is a whole row off by one factor (the RMSNorm scalar)?
+                    for r in range(rows):
+                        df = (y2[r] != y2_first[r]).nonzero().flatten()
+                        if df.numel():
+                            ratio = (y2[r].float()[df] / y2_first[r].float()[df].clamp_min(1e-6))
+                            print("   row", r, "differing columns", int(df.numel()), "of", int(y2.shape[1]), "first", df[:12].tolist(), "tiles", sorted(set((df // 16).tolist()))[:12],
+                                  "ratio min/max", float(ratio.min()), float(ratio.max()), flush=True)
 # ---- the deferred K-split reduction: producer (parts_out) -> consumer (RMSNorm prologue + parts_in + x_out), qkv as an RMSNorm producer
 Lp, Lc = po.make_layer(91, 4096, [2560]), po.make_layer(92, 2560, [4096, 1024, 1024])
 mk = lambda L_: PackedParoWeights(t(L_["qweight"]), t(L_["qzeros"]), t(L_["scales"]), t(L_["theta"]), t(L_["pairs"]), t(L_["channel_scales"]), L_["sizes"])
