@@ -449,6 +449,12 @@ int paro_engine_describe(const paro_engine_phase_t* phases, const paro_engine_t*
                          int32_t* out_max_tiles, int32_t* out_min_tiles);
 int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
                     int64_t workspace_bytes, void* stream);
+/* Diagnostic twin of paro_engine_run (its own kernel instantiation; never on the hot path): the same launch, and every compute unit
+ * stamps eight events per phase with the chip-wide 100 MHz counter into trace: uint64 [n_phases][n_cus][8] --
+ * service wave: 0 phase entered, 1 partial sums arrived, 2 rotated group published; wave 0: 3 gather entered, 4 gathered, 5 past the
+ * first barrier, 6 units done, 7 outputs published (tools/engine_timeline.py turns them into the per-edge timeline). */
+int paro_engine_trace(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                      int64_t workspace_bytes, void* trace, void* stream);
 
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */

@@ -67,6 +67,7 @@ EXPORTS = (
     "paro_engine_build",
     "paro_engine_describe",
     "paro_engine_run",
+    "paro_engine_trace",
 )
 
 
@@ -250,6 +251,8 @@ def load() -> ctypes.CDLL:
     lib.paro_engine_describe.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
     lib.paro_engine_run.restype = c_int
     lib.paro_engine_run.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.paro_engine_trace.restype = c_int
+    lib.paro_engine_trace.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:
         raise RuntimeError(f"paroquant_amd: ABI version mismatch (library {lib.paro_abi_version()}, "
                            f"binding {PARO_ABI_VERSION})")

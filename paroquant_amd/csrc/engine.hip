@@ -69,7 +69,7 @@ struct alignas(16) EngWork {           // 32 bytes per (phase shape, CU)
   short s, p, g0, ng;                  // K-chunk, partition, first group, groups (0: no units in this phase)
   int t0;                              // first tile (global tile index)
   int tz0;                             // its padded scale / zero tile
-  short nt, nb, tw, pad0;              // tiles; column blocks (1, 3, 5 or 15) of `tw` tiles each
+  short nt, nb, tw, pad0;              // tiles; column blocks (1..15) of `tw` tiles each
   int pad[2];
 };
 static_assert(sizeof(EngWork) == 32, "work record");
@@ -84,6 +84,7 @@ struct EngArgs {
   const unsigned short* bias_last;
   long long yoff_last;
   int n_phases, ncu, N_last, S_last;
+  unsigned long long* trace;           // TRACE builds: [n_phases][ncu][8] stamps of the 100 MHz real-time counter (paro_engine_trace)
 };
 
 template <typename T>
@@ -94,7 +95,19 @@ __device__ __forceinline__ void st_gran(unsigned long long* p, unsigned tag, uns
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename AT>
+// The plan (phase and work records) is CONSTANT while the kernel runs: read it through the constant address space, i.e. with scalar
+// loads into SGPRs.  Left to itself the compiler reads the records with VECTOR loads (the kernel also stores to global memory, so it may
+// not assume the plan unchanged) -- and a vector load returns in order behind the wave's outstanding HBM tile requests: every `ph.G`
+// became a wait for the run-ahead tiles (first build: 11 us per phase).
+template <typename T>
+__device__ __forceinline__ T ld_plan(const T* p) {
+  typedef const __attribute__((address_space(4))) T* CP;
+  T v;
+  __builtin_memcpy(&v, (CP)(unsigned long long)p, sizeof(T));
+  return v;
+}
+
+template <typename AT, bool TRACE = false>
 __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a) {
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -111,78 +124,68 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cu = blockIdx.x;
-  const bool service = wave == kEngCompute;
+  // TRACE: stamp `slot` of (phase, CU) with the chip-wide 100 MHz counter -- service wave: 0 phase entered, 1 partial sums arrived,
+  // 2 rotated group published; wave 0: 3 gather entered, 4 gathered, 5 past B1, 6 units done, 7 outputs published
+  auto stamp = [&](int pi, int slot) {
+    if constexpr (TRACE) {
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) a.trace[((long long)pi * a.ncu + blockIdx.x) * 8 + slot] = t;
+    }
+  };
   // the launch's base tag: advanced by the previous launch's finisher, which first waits until every CU has read it (ctl[2]; the add's
   // operand depends on the value read, so it cannot overtake the read)
   const unsigned epoch = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 0) {
+  if (tid == kEngCompute * 64) {
     unsigned one = 1u;
     asm volatile("" : "+v"(one) : "v"(epoch));             // a data dependency the compiler cannot fold away
     __hip_atomic_fetch_add(a.ctl + 2, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const unsigned nan2 = (unsigned)A::from_f32(__builtin_nanf("")) * 0x10001u;
-  if (tid < XS_STRIDE / 4) *(u32x2*)(zrow + 4 * tid) = (u32x2){0u, 0u};
 
-  // A-fragment addressing of a one-row product: MFMA row 0 carries x, the other fifteen rows read the zero row
-  const int mrow = lane & 15, mq = lane >> 4, n16 = lane & 15;
-  const bool avalid = mrow == 0;
-  const typename A::Unpack upk = A::unpack_consts();
-
-  struct TBuf {
-    u32x4 q[kEngTw];
-    unsigned szw[kEngTw];
-  };
-  // tile requests of one unit: `tw` tiles of group g from tile t (the unused slots of a narrower unit point OUTSIDE the buffer: a
-  // buffer load beyond num_records returns zeros and fetches nothing, so the request count stays static for the vmcnt bookkeeping)
-  auto load_unit = [&](TBuf& b, const EngPhase& ph, int g, int t, int tz, int n) {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)ph.wq, 0, (int)ph.wq_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph.sz, 0, (int)ph.sz_bytes, 0x00020000);
+  // hop 2, consumer side: the rotated groups of this CU's K-chunk into LDS (every wave takes groups wave, wave + 16, ...)
+  auto gather = [&](const EngPhase& ph, const EngWork& w, unsigned tag) {
+    if (w.ng <= 0) return;
+    const unsigned long long* src = a.gran + ph.xoff + (long long)w.p * (ph.K / 2) + (unsigned)(w.g0 * 64 + lane);
+    for (int i0 = wave; i0 < w.ng; i0 += kEngWaves * 4) {
+      unsigned long long gq[4];
+      bool ok = false;
+      for (unsigned spin = 0; !ok; ++spin) {
+        ok = true;
 #pragma unroll
-    for (int j = 0; j < kEngTw; ++j) {
-      const unsigned off = j < n ? ((unsigned)((t + j) * ph.tstride + g * ph.gstride) * 1024u + (unsigned)lane * 16u) : 0xfffffff0u;
-      b.q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 2));   // aux 2 = nt: streamed once
-    }
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q * kEngWaves;
+          if (i < w.ng) gq[q] = ld_gran(src + i * 64);
+        }
 #pragma unroll
-    for (int j = 0; j < kEngTw; ++j) {
-      const int ts = tz + j;
-      const unsigned off = j < n ? ((unsigned)(g * ph.szrow) + (unsigned)(((ts >> 2) * 16 + n16) * 4 + (ts & 3))) * 4u : 0xfffffff0u;
-      b.szw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q * kEngWaves;
+          if (i < w.ng) ok = ok && (unsigned)(gq[q] >> 32) == tag;
+        }
+        ok = __all(ok);
+        if (!ok) {
+          if (spin > kEngSpin) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * kEngWaves;
+        if (i < w.ng) *(unsigned*)(xs + i * XS_STRIDE + 2 * lane) = ok ? (unsigned)gq[q] : nan2;   // (gave up: NaN)
+      }
     }
   };
-  // this wave's place among the units of (phase, CU): column block b, rank r among the block's `nwb` waves
-  auto place = [&](const EngWork& w, int& b, int& r, int& nwb) {
-    const int nb = w.nb;
-    if (nb == 1) { b = 0; r = wave; }
-    else if (nb == 3) { b = wave % 3; r = wave / 3; }
-    else if (nb == 5) { b = wave % 5; r = wave / 5; }
-    else { b = wave; r = 0; }
-    nwb = kEngCompute / nb;
-  };
 
-  TBuf tc, tn;
-  // ---- the first unit of phase 0 (compute waves): requested before anything is waited for
-  {
-    const EngPhase& ph = a.phases[0];
-    const EngWork& w = a.work[ph.work_off + cu];
-    int b, r, nwb;
-    place(w, b, r, nwb);
-    const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
-    const bool has = !service && r < w.ng && nt_b > 0;
-    load_unit(tc, ph, w.g0 + (has ? r : 0), w.t0 + b * w.tw, w.tz0 + b * w.tw, has ? nt_b : 0);
-  }
-
-  for (int pi = 0; pi < a.n_phases; ++pi) {
-    const EngPhase& ph = a.phases[pi];
-    const EngWork& w = a.work[ph.work_off + cu];
-    const unsigned tag = epoch + (unsigned)pi + 1u;        // of this phase's OUTPUT and of its rotated input
-    const unsigned tag_in = epoch + (unsigned)pi;          // of the previous phase's partial sums
-    unsigned long long* xr = a.gran + ph.xoff;
-    const unsigned long long* yin = a.gran + ph.yoff_prev;
-    unsigned long long* yout = a.gran + ph.yoff;
-    const long long xpart = ph.K / 2;
-
-    // ---- service wave: the rotation tasks of this phase that live on this CU (task = (partition, group); task id = CU, CU + ncu, ...)
-    if (service) {
+  if (wave == kEngCompute) {
+    // =================================================================== the SERVICE wave: rotation tasks, gathers, the final outputs
+    // (its own loop, so that no register of the compute waves' tile buffers is live across the rotation: the first build shared one
+    // loop and spilled the just-requested tiles to scratch -- a wait for HBM in front of everything)
+    for (int pi = 0; pi < a.n_phases; ++pi) {
+      const EngPhase ph = ld_plan(a.phases + pi);
+      const EngWork w = ld_plan(a.work + ph.work_off + cu);
+      const unsigned tag = epoch + (unsigned)pi + 1u;      // of this phase's rotated input (and of its output)
+      const unsigned tag_in = epoch + (unsigned)pi;        // of the previous phase's partial sums
+      stamp(pi, 0);
+      // the rotation tasks of this phase that live on this CU (task = (partition, group); task id = CU, CU + ncu, ...)
       for (int task = cu; task < ph.n_tasks; task += a.ncu) {
         const int p = task / ph.G, g = task - p * ph.G;
         GivensRegs<AT, 1> gr;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
           x1 = A::to_f32(xv >> 16);
         } else {
           // hop 1: the S_prev partial sums of this lane's two channels, every slot polled in one batch
-          const unsigned long long* src = yin + (unsigned)(ph.in_col0 + g * 128 + 2 * lane);
+          const unsigned long long* src = a.gran + ph.yoff_prev + (unsigned)(ph.in_col0 + g * 128 + 2 * lane);
           unsigned long long g0[kEngMaxSplit], g1[kEngMaxSplit];
           bool ok = false;
           for (unsigned spin = 0; !ok; ++spin) {
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
           x0 = A::to_f32(A::from_f32(v0));                  // the one rounding of the producing linear
           x1 = A::to_f32(A::from_f32(v1));
         }
+        if (task == cu) stamp(pi, 1);
         gr.prepare();
         gr.seed(0, x0, x1, csv);
         gr.stages();
@@ -238,127 +242,14 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
         __builtin_amdgcn_wave_barrier();
         const unsigned pr = *(const unsigned*)(svc + 2 * lane);
         __builtin_amdgcn_wave_barrier();
-        st_gran(xr + (long long)p * xpart + (unsigned)(g * 64 + lane), tag, pr);   // hop 2: the data IS the flag
+        st_gran(a.gran + ph.xoff + (long long)p * (ph.K / 2) + (unsigned)(g * 64 + lane), tag, pr);   // hop 2: the data IS the flag
+        if (task == cu) stamp(pi, 2);
       }
+      gather(ph, w, tag);
+      lds_barrier();                                        // B1
+      lds_barrier();                                        // B2
     }
-
-    // ---- hop 2, consumer side: the rotated groups of this CU's K-chunk into LDS (every wave takes groups wave, wave + 16, ...)
-    if (w.ng > 0) {
-      const unsigned long long* src = xr + (long long)w.p * xpart + (unsigned)(w.g0 * 64 + lane);
-      for (int i0 = wave; i0 < w.ng; i0 += kEngWaves * 4) {
-        unsigned long long gq[4];
-        bool ok = false;
-        for (unsigned spin = 0; !ok; ++spin) {
-          ok = true;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * kEngWaves;
-            if (i < w.ng) gq[q] = ld_gran(src + i * 64);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * kEngWaves;
-            if (i < w.ng) ok = ok && (unsigned)(gq[q] >> 32) == tag;
-          }
-          ok = __all(ok);
-          if (!ok) {
-            if (spin > kEngSpin) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = i0 + q * kEngWaves;
-          if (i < w.ng) *(unsigned*)(xs + i * XS_STRIDE + 2 * lane) = ok ? (unsigned)gq[q] : nan2;   // (gave up: NaN)
-        }
-      }
-    }
-    lds_barrier();                                          // B1: x of this phase is staged
-
-    // ---- compute waves: units (group, column block); the NEXT unit's tiles -- of this phase or the first of the next -- in flight
-    float acc[kEngTw] = {0.f, 0.f, 0.f, 0.f};
-    if (!service) {
-      int b, r, nwb;
-      place(w, b, r, nwb);
-      const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
-      const int tb = w.t0 + b * w.tw, tzb = w.tz0 + b * w.tw;
-      const bool has = nt_b > 0;
-      for (int gi = r; gi < w.ng && has; gi += nwb) {
-        const bool more = gi + nwb < w.ng;
-        if (more) {
-          load_unit(tn, ph, w.g0 + gi + nwb, tb, tzb, nt_b);
-        } else if (pi + 1 < a.n_phases) {
-          const EngPhase& ph2 = a.phases[pi + 1];
-          const EngWork& w2 = a.work[ph2.work_off + cu];
-          int b2, r2, nwb2;
-          place(w2, b2, r2, nwb2);
-          const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
-          const bool has2 = r2 < w2.ng && nt2 > 0;
-          load_unit(tn, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
-        }
-        // fragments of the rotated group, the two sums, unpack -> MFMA -> scale / zero (gemv_impl.hpp's unit, one row)
-        vec8 af[4];
-        {
-          const unsigned short* afrag = (avalid ? xs + gi * XS_STRIDE : zrow) + 8 * mq;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
-        }
-        f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
-        {
-          const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
-          const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
-            so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kEngTw; ++j) {
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            unsigned w4[4];
-            A::unpack_fast(tc.q[j][i], w4, upk);
-            const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
-            d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
-          }
-          const float s = f16_bits_to_f32(tc.szw[j] & 0xffffu), zf = f16_bits_to_f32(tc.szw[j] >> 16);
-          acc[j] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[0], d[0] - so[0]), acc[j]);
-        }
-        tc = tn;
-      }
-      // a wave without units in this phase still owes the NEXT phase its first unit's requests
-      if (!(has && r < w.ng) && pi + 1 < a.n_phases) {
-        const EngPhase& ph2 = a.phases[pi + 1];
-        const EngWork& w2 = a.work[ph2.work_off + cu];
-        int b2, r2, nwb2;
-        place(w2, b2, r2, nwb2);
-        const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
-        const bool has2 = r2 < w2.ng && nt2 > 0;
-        load_unit(tc, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < kEngTw; ++j) red[(wave * kEngTw + j) * 16 + lane] = acc[j];
-      }
-    }
-    lds_barrier();                                          // B2: every wave's partial sums are staged
-
-    // ---- hop 1, producer side: this CU's outputs over its K-chunk, one {tag, fp32} granule each (wave order = group order: static)
-    if (tid < w.nt * 16) {
-      const int j = tid >> 4, n = tid & 15;
-      const int b = j / w.tw, jj = j - b * w.tw;
-      const int nwb = kEngCompute / w.nb;
-      float v = 0.f;
-      for (int r = 0; r < nwb; ++r) v += red[((r * w.nb + b) * kEngTw + jj) * 16 + n];
-      st_gran(yout + (long long)w.s * ph.N + (unsigned)((w.t0 + j) * 16 + n), tag, __builtin_bit_cast(unsigned, v));
-    }
-    // (red is rewritten only behind the next phase's B1, which every publishing thread reaches after its reads)
-  }
-
-  // ---- the last phase's outputs: completed like a rotation task's input (slots in order, bias, one rounding), 128 columns per task
-  if (service) {
+    // ---- the last phase's outputs: completed like a rotation task's input (slots in order, bias, one rounding), 128 columns per task
     const unsigned tag_in = epoch + (unsigned)a.n_phases;
     const unsigned long long* yin = a.gran + a.yoff_last;
     const int n_fin = (a.N_last + 127) / 128;
@@ -413,6 +304,131 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
         __hip_atomic_store(a.ctl, e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    return;
+  }
+
+  // ======================================================================= the fifteen COMPUTE waves
+  if (tid < XS_STRIDE / 4) *(u32x2*)(zrow + 4 * tid) = (u32x2){0u, 0u};   // (first read behind B1)
+  // A-fragment addressing of a one-row product: MFMA row 0 carries x, the other fifteen rows read the zero row
+  const int mq = lane >> 4, n16 = lane & 15;
+  const bool avalid = n16 == 0;
+  const typename A::Unpack upk = A::unpack_consts();
+
+  struct TBuf {
+    u32x4 q[kEngTw];
+    unsigned szw[kEngTw];
+  };
+  // tile requests of one unit: `n` tiles of group g from tile t (the unused slots of a narrower unit point OUTSIDE the buffer: a
+  // buffer load beyond num_records returns zeros and fetches nothing, so the request count stays static for the vmcnt bookkeeping)
+  auto load_unit = [&](TBuf& b, const EngPhase& ph, int g, int t, int tz, int n) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)ph.wq, 0, (int)ph.wq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph.sz, 0, (int)ph.sz_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < kEngTw; ++j) {
+      const unsigned off = j < n ? ((unsigned)((t + j) * ph.tstride + g * ph.gstride) * 1024u + (unsigned)lane * 16u) : 0xfffffff0u;
+      b.q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 2));   // aux 2 = nt: streamed once
+    }
+#pragma unroll
+    for (int j = 0; j < kEngTw; ++j) {
+      const int ts = tz + j;
+      const unsigned off = j < n ? ((unsigned)(g * ph.szrow) + (unsigned)(((ts >> 2) * 16 + n16) * 4 + (ts & 3))) * 4u : 0xfffffff0u;
+      b.szw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+    }
+  };
+  // this wave's place among the units of (phase, CU): column block b, rank r among the block's `nwb` waves
+  auto place = [&](const EngWork& w, int& b, int& r, int& nwb) {
+    const int nb = w.nb;                                    // 1..15 column blocks; block b is shared by the waves b, b + nb, ...
+    r = wave / nb;
+    b = wave - r * nb;
+    nwb = (kEngCompute - b + nb - 1) / nb;
+  };
+  // the first unit of (phase, this wave): requested one phase ahead
+  auto first_unit = [&](TBuf& b, int pi) {
+    const EngPhase ph2 = ld_plan(a.phases + pi);
+    const EngWork w2 = ld_plan(a.work + ph2.work_off + cu);
+    int b2, r2, nwb2;
+    place(w2, b2, r2, nwb2);
+    const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
+    const bool has2 = r2 < w2.ng && nt2 > 0;
+    load_unit(b, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
+  };
+
+  TBuf tc, tn;
+  first_unit(tc, 0);                                        // before anything is waited for
+
+  for (int pi = 0; pi < a.n_phases; ++pi) {
+    const EngPhase ph = ld_plan(a.phases + pi);
+    const EngWork w = ld_plan(a.work + ph.work_off + cu);
+    const unsigned tag = epoch + (unsigned)pi + 1u;
+    if (wave == 0) stamp(pi, 3);
+    gather(ph, w, tag);
+    if (wave == 0) stamp(pi, 4);
+    lds_barrier();                                          // B1: x of this phase is staged
+    if (wave == 0) stamp(pi, 5);
+
+    // ---- units (group, column block); the NEXT unit's tiles -- of this phase or the first of the next -- in flight
+    float acc[kEngTw] = {0.f, 0.f, 0.f, 0.f};
+    int b, r, nwb;
+    place(w, b, r, nwb);
+    const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
+    const int tb = w.t0 + b * w.tw, tzb = w.tz0 + b * w.tw;
+    const bool has = nt_b > 0 && r < w.ng;
+    for (int gi = r; gi < w.ng && has; gi += nwb) {
+      const bool more = gi + nwb < w.ng;
+      if (more) load_unit(tn, ph, w.g0 + gi + nwb, tb, tzb, nt_b);
+      // fragments of the rotated group, the two sums, unpack -> MFMA -> scale / zero (gemv_impl.hpp's unit, one row)
+      vec8 af[4];
+      {
+        const unsigned short* afrag = (avalid ? xs + gi * XS_STRIDE : zrow) + 8 * mq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
+      }
+      f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
+      {
+        const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+        const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
+          so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kEngTw; ++j) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned w4[4];
+          A::unpack_fast(tc.q[j][i], w4, upk);
+          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+        }
+        const float s = f16_bits_to_f32(tc.szw[j] & 0xffffu), zf = f16_bits_to_f32(tc.szw[j] >> 16);
+        acc[j] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[0], d[0] - so[0]), acc[j]);
+      }
+      if (more) tc = tn;     // (a register copy waits for the requests it copies: only where the next unit is consumed straight away)
+    }
+    // The NEXT phase's first unit, requested behind this phase's last consume and INTO `tc`: the first build requested it into `tn` ahead
+    // of the last unit and copied -- the copy is a wait for HBM, 2 us in front of every publish (profiles/r04_engine_timeline_v1.jsonl)
+    if (pi + 1 < a.n_phases) first_unit(tc, pi + 1);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < kEngTw; ++j) red[(wave * kEngTw + j) * 16 + lane] = acc[j];
+    }
+    if (wave == 0) stamp(pi, 6);
+    lds_barrier();                                          // B2: every wave's partial sums are staged
+
+    // ---- hop 1, producer side: this CU's outputs over its K-chunk, one {tag, fp32} granule each (wave order = group order: static)
+    if (tid < w.nt * 16) {
+      const int j = tid >> 4, n = tid & 15;
+      const int bj = j / w.tw, jj = j - bj * w.tw;
+      const int nw = (kEngCompute - bj + w.nb - 1) / w.nb;
+      float v = 0.f;
+      for (int rr = 0; rr < nw; ++rr) v += red[((rr * w.nb + bj) * kEngTw + jj) * 16 + n];
+      st_gran(a.gran + ph.yoff + (long long)w.s * ph.N + (unsigned)((w.t0 + j) * 16 + n), tag, __builtin_bit_cast(unsigned, v));
+    }
+    if (wave == 0) stamp(pi, 7);
+    // (red is rewritten only behind the next phase's B1, which every publishing thread reaches after its reads)
   }
 }
 
@@ -425,14 +441,14 @@ struct PhasePlan {
 };
 
 static int pick_blocks(int nt, int ng, int& nb, int& tw) {
-  // column blocks (1, 3, 5, 15) x rank waves: fewest unit steps per wave, then the fewest tiles per step
+  // column blocks (1..15; block b is shared by the waves b, b + nb, ...) of `tw` <= 4 tiles: the slowest wave's unit steps, in cycles
   long long best = -1;
-  for (int cand : {1, 3, 5, 15}) {
+  for (int cand = 1; cand <= kEngCompute; ++cand) {
     const int t = (nt + cand - 1) / cand;
-    if (t > kEngTw || t < 1) continue;
-    const int nwb = kEngCompute / cand;
-    const int steps = (ng + nwb - 1) / nwb;
-    const long long c = (long long)steps * (150 + 130 * t);  // a unit step in cycles: fragments + the two sums, then ~130 per tile (unpack + MFMA)
+    if (t > kEngTw || t < 1 || (cand - 1) * t >= nt) continue;           // (no empty blocks)
+    const int nwb_min = kEngCompute / cand;                               // the blocks with the fewest waves
+    const int steps = (ng + nwb_min - 1) / nwb_min;
+    const long long c = (long long)steps * (150 + 130 * t);              // a unit step: fragments + the two sums, then ~130 per tile
     if (best < 0 || c < best) { best = c; nb = cand; tw = t; }
   }
   return best < 0 ? -1 : 0;
@@ -490,7 +506,7 @@ static bool plan_phase(const paro_linear_t* L, int ncu, int S, PhasePlan& out) {
         int nb = 1, tw = 1;
         if (pick_blocks(w.nt, w.ng, nb, tw) != 0) return false;
         w.nb = (short)nb; w.tw = (short)tw;
-        const int nwb = kEngCompute / nb;
+        const int nwb = kEngCompute / nb;                    // (the blocks with the fewest waves)
         const long long steps = (w.ng + nwb - 1) / nwb;
         // cycles: a CU ingests a 1 KiB tile in ~96 cycles (25 GB/s); its slowest wave then runs `steps` unit steps
         worst = std::max(worst, 96ll * w.nt * w.ng + steps * (150 + 130 * tw));
@@ -651,9 +667,9 @@ extern "C" int paro_engine_describe(const paro_engine_phase_t* phases, const par
   return PARO_OK;
 }
 
-extern "C" int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
-  using namespace paro;
+namespace paro {
+static int engine_launch(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace, int64_t workspace_bytes,
+                         unsigned long long* trace, void* stream) {
   if (!e || !plan_dev || !x || !y || !workspace) return fail(PARO_ERR_INVALID, "null pointer");
   if (workspace_bytes < e->workspace_bytes) return fail(PARO_ERR_INVALID, "engine workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)e->workspace_bytes);
   if (e->n_phases < 1 || e->last_split < 1 || e->last_split > kEngMaxSplit || e->plan_bytes < (int64_t)e->n_phases * (int64_t)sizeof(EngPhase))
@@ -672,6 +688,7 @@ extern "C" int paro_engine_run(const paro_engine_t* e, const void* plan_dev, con
   a.ncu = e->n_cus;
   a.N_last = (int)e->out_features;
   a.S_last = e->last_split;
+  a.trace = trace;
   // every workgroup of the grid must be resident at once (they wait for each other): one 16-wave workgroup per CU
   {
     static int per_cu[3] = {-1, -1, -1};
@@ -679,17 +696,33 @@ extern "C" int paro_engine_run(const paro_engine_t* e, const void* plan_dev, con
     if (per < 0) {
       int v = 0;
       hipError_t er = e->act_dtype == PARO_DTYPE_F16
-                          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<f16>, kEngWaves * 64, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<bf16>, kEngWaves * 64, 0);
+                          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<f16, false>, kEngWaves * 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, engine_kernel<bf16, false>, kEngWaves * 64, 0);
       per = (er == hipSuccess && v >= 1) ? v : 0;
     }
     if (per < 1) return fail(PARO_ERR_UNSUPPORTED, "engine: the kernel does not fit a compute unit");
     if (e->n_cus > device_cu_count()) return fail(PARO_ERR_UNSUPPORTED, "engine: planned for %d compute units, the device has %d", e->n_cus, device_cu_count());
   }
   hipStream_t st = (hipStream_t)stream;
-  if (e->act_dtype == PARO_DTYPE_F16)
-    hipLaunchKernelGGL(engine_kernel<f16>, dim3((unsigned)e->n_cus), dim3(kEngWaves * 64), 0, st, a);
-  else
-    hipLaunchKernelGGL(engine_kernel<bf16>, dim3((unsigned)e->n_cus), dim3(kEngWaves * 64), 0, st, a);
+  const dim3 grid((unsigned)e->n_cus), block(kEngWaves * 64);
+  if (trace) {
+    if (e->act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL((engine_kernel<f16, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((engine_kernel<bf16, true>), grid, block, 0, st, a);
+  } else {
+    if (e->act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL((engine_kernel<f16, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((engine_kernel<bf16, false>), grid, block, 0, st, a);
+  }
   return check_launch("paro_engine_run");
+}
+}  // namespace paro
+
+extern "C" int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  return paro::engine_launch(e, plan_dev, x, y, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int paro_engine_trace(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                                 int64_t workspace_bytes, void* trace, void* stream) {
+  if (!trace) return paro::fail(PARO_ERR_INVALID, "null trace buffer");
+  return paro::engine_launch(e, plan_dev, x, y, workspace, workspace_bytes, (unsigned long long*)trace, stream);
 }

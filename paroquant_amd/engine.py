@@ -77,6 +77,17 @@ class DecodeEngine:
                                                  self.workspace.data_ptr(), self.workspace.numel(), nat.current_stream_ptr(self.device)))
         return y
 
+    @torch.no_grad()
+    def trace(self, x: torch.Tensor) -> torch.Tensor:
+        """One launch of the diagnostic twin (``paro_engine_trace``): int64 [n_phases, n_cus, 8] stamps of the 100 MHz counter."""
+        tr = torch.zeros(len(self.layers), int(self._e.n_cus), 8, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.load().paro_engine_trace(ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), self.y.data_ptr(),
+                                                  self.workspace.data_ptr(), self.workspace.numel(), tr.data_ptr(),
+                                                  nat.current_stream_ptr(self.device)))
+        torch.cuda.synchronize(self.device)
+        return tr
+
     def status_ok(self) -> bool:
         """False once a hand-off inside a launch gave up waiting (outputs of that launch are NaN).  Synchronises."""
         return int(self.workspace[4:8].view(torch.int32).item()) == 0

@@ -516,7 +516,7 @@ def test_engine_planner_covers_every_tile_once(lib):
                         continue
                     cover[w["g0"]:w["g0"] + w["ng"], w["t0"]:w["t0"] + w["nt"]] += 1
                     assert tstart[w["p"]] <= w["t0"] and w["t0"] + w["nt"] <= tstart[w["p"] + 1]          # inside ONE partition
-                    assert w["nb"] in (1, 3, 5, 15) and 1 <= w["tw"] <= 4 and w["nb"] * w["tw"] >= w["nt"]  # the unit blocks cover the tiles
+                    assert 1 <= w["nb"] <= 15 and 1 <= w["tw"] <= 4 and w["nb"] * w["tw"] >= w["nt"] > (w["nb"] - 1) * w["tw"]  # unit blocks cover the tiles, none empty
                     assert w["ng"] <= 128 and w["nt"] <= 60 and 0 <= w["s"] < p["S"]
                     # padded scale / zero tile space: partitions start at multiples of 8 tiles
                     assert w["tz0"] == sum((n // 16 + 7) // 8 * 8 for n in sizes[:w["p"]]) + (w["t0"] - tstart[w["p"]])
