@@ -421,7 +421,8 @@ int paro_rotate_parts(const paro_linear_t* L, const void* x, void* x_rot, int64_
  * fp32 partial sums) and handed to the CUs that multiply by it -- csrc/engine.hip describes the protocol.
  *   phase i :  y_i = rotate_i(x_i * cs_i) @ dequant(W_i) + bias_i,  rounded once to the activation type (what the linear would have
  *              stored);  x_0 = x,  x_{i+1} = y_i[in_col0_{i+1} : in_col0_{i+1} + K_{i+1}]
- * One row; krot <= 8; quantisation group_size 128; in_col0 even.  All layers of a chain share the activation type.
+ * One row; krot <= 8; quantisation group_size 128; in_col0 even; at most 448 phases of at most 8 distinct linear shapes per chain
+ * (the plan is cached on chip).  All layers of a chain share the activation type.
  *   paro_engine_plan   host only: chooses the work split for `n_cus` compute units (0 = the current device's) and fills `out`
  *                      (sizes of the plan blob and of the workspace).
  *   paro_engine_build  host only: writes the plan blob (plan_bytes) into HOST memory; the caller copies it to the device.  The
@@ -442,6 +443,8 @@ typedef struct paro_engine {
   int32_t n_phases, n_cus, act_dtype, last_split;
   int64_t plan_bytes, workspace_bytes, in_features, out_features, last_out_offset;
   const void* last_bias;
+  int32_t n_shapes, shape_off[8];   /* distinct linear shapes of the chain and where their work tables start in the plan */
+  int32_t reserved0;
 } paro_engine_t;
 int paro_engine_plan(const paro_engine_phase_t* phases, int n_phases, int n_cus, paro_engine_t* out);
 int paro_engine_build(const paro_engine_phase_t* phases, const paro_engine_t* e, void* plan_host);
@@ -450,9 +453,10 @@ int paro_engine_describe(const paro_engine_phase_t* phases, const paro_engine_t*
 int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
                     int64_t workspace_bytes, void* stream);
 /* Diagnostic twin of paro_engine_run (its own kernel instantiation; never on the hot path): the same launch, and every compute unit
- * stamps eight events per phase with the chip-wide 100 MHz counter into trace: uint64 [n_phases][n_cus][8] --
+ * stamps its events per phase with the chip-wide 100 MHz counter into trace: uint64 [n_phases][n_cus][32] (16 events, then the shader-clock counter at the same 16 events) --
  * service wave: 0 phase entered, 1 partial sums arrived, 2 rotated group published; wave 0: 3 gather entered, 4 gathered, 5 past the
- * first barrier, 6 units done, 7 outputs published (tools/engine_timeline.py turns them into the per-edge timeline). */
+ * first barrier, 8 its units consumed, 6 partial sums staged, 9 past the second barrier, 7 outputs published (tools/engine_timeline.py
+ * turns them into the per-edge timeline). */
 int paro_engine_trace(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
                       int64_t workspace_bytes, void* trace, void* stream);
 

@@ -122,7 +122,7 @@ class ParoEngine(Structure):
 
     _fields_ = [("n_phases", c_int32), ("n_cus", c_int32), ("act_dtype", c_int32), ("last_split", c_int32), ("plan_bytes", c_int64),
                 ("workspace_bytes", c_int64), ("in_features", c_int64), ("out_features", c_int64), ("last_out_offset", c_int64),
-                ("last_bias", c_void_p)]
+                ("last_bias", c_void_p), ("n_shapes", c_int32), ("shape_off", c_int32 * 8), ("reserved0", c_int32)]
 
 
 class ParoChain(Structure):

@@ -25,6 +25,7 @@
 // Numerics: per (K-chunk, column) the groups are accumulated in a fixed order (wave order is static), the K-chunks are added in slot
 // order, one rounding to the activation type per linear: deterministic, and within the parity tolerance of the oracle
 // (tests/test_gpu_engine.py); NOT bit-identical to the per-call kernels, whose K partition differs.
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -41,28 +42,52 @@ constexpr int kEngMaxSplit = 4;        // K-chunks per linear
 constexpr int kEngMaxGroups = 128;     // groups of one K-chunk (LDS: 272 B each)
 constexpr int kEngMaxTiles = 60;       // tiles of one CU and phase (publishing threads: 60 x 16 <= 15 waves)
 constexpr unsigned kEngSpin = 1u << 21;
+constexpr int kEngPlanCap = 448;       // phases whose records fit the LDS copy of the plan (Llama-3-70B: 320)
+constexpr int kEngMaxShapes = 8;       // distinct linear shapes of a chain (their work rows are cached per CU)
 constexpr int kEngXsStride = 136;      // halves per group row in LDS (128 + 8 pad: the fragment reads of different rows spread over banks)
 int validate_linear(const paro_linear_t* L);   // gemv.hip
 
-struct alignas(16) EngPhase {          // 144 bytes, one per phase, read with scalar loads
+struct alignas(16) EngPhase {          // 144 bytes, one per phase (cached in LDS)
+  // ---- what a compute wave needs (the first 64 bytes: read as one piece)
   const u32x4* wq;
   const unsigned* sz;
-  const unsigned* rot;
-  const unsigned short* cs;            // [P][K]
-  const unsigned short* bias_prev;     // bias of the linear that produced this phase's input (added where its partial sums are completed)
   unsigned wq_bytes, sz_bytes;
-  int G, T, tstride, gstride;          // tile (t, g) = chunk t * tstride + g * gstride
+  int tstride, gstride;                // tile (t, g) = chunk t * tstride + g * gstride
   int szrow;                           // words per group row of the scale / zero array
-  int P, S, S_prev;
-  int in_col0;                         // channel c of this phase = column in_col0 + c of the previous phase's output
-  int N, K, n_tasks;
-  int work_off, N_prev, pad0, pad1;    // work_off: first EngWork of this phase
+  int shape;                           // index among the chain's distinct linears (work rows, wave plans)
+  int K, N;
   // Every phase has its OWN hop buffers (granule offsets into the workspace): nothing is reused inside a launch, so a CU that lags
   // behind -- e.g. one whose outputs the next linear does not read (k / v columns in a chain without attention) -- can never find a
   // granule it still waits for overwritten by a later phase.
-  long long yoff, yoff_prev;           // partial sums {tag, fp32}: slot s at yoff + s * N
-  long long xoff, pad2;                // rotated input {tag, two activations}: partition p, group g at xoff + p * (K / 2) + g * 64
+  long long xoff;                      // rotated input {tag, two activations}: partition p, group g at xoff + p * (K / 2) + g * 64
+  long long yoff;                      // partial sums {tag, fp32}: slot s at yoff + s * N
+  // ---- the service wave's
+  const unsigned* rot;
+  const unsigned short* cs;            // [P][K]
+  const unsigned short* bias_prev;     // bias of the linear that produced this phase's input (added where its partial sums are completed)
+  int G, P, S, S_prev;
+  int in_col0;                         // channel c of this phase = column in_col0 + c of the previous phase's output
+  int n_tasks, N_prev, T;
+  long long yoff_prev;
+  int work_off, pad[3];                // work_off: first EngWork of this phase's shape
 };
+struct EngPhaseC {                     // the compute waves' view: the first 64 bytes of an EngPhase
+  const u32x4* wq;
+  const unsigned* sz;
+  unsigned wq_bytes, sz_bytes;
+  int tstride, gstride, szrow, shape, K, N;
+  long long xoff, yoff;
+};
+static_assert(sizeof(EngPhaseC) == 64 && offsetof(EngPhase, rot) == 64, "compute view");
+// a compute wave's share of (shape, CU): written once per launch into LDS by the wave itself
+struct alignas(16) EngWave {
+  int nu;                              // its units in a phase of this shape (0: none)
+  int r, nwb;                          // unit k is group g0 + r + k * nwb of the CU's K-chunk
+  int g0;
+  int nt_b, tb, tzb;                   // its column block: tiles, first tile, first padded scale / zero tile
+  int pad;
+};
+static_assert(sizeof(EngWave) == 32, "wave plan");
 static_assert(sizeof(EngPhase) == 144, "phase record");
 
 struct alignas(16) EngWork {           // 32 bytes per (phase shape, CU)
@@ -70,7 +95,8 @@ struct alignas(16) EngWork {           // 32 bytes per (phase shape, CU)
   int t0;                              // first tile (global tile index)
   int tz0;                             // its padded scale / zero tile
   short nt, nb, tw, pad0;              // tiles; column blocks (1..15) of `tw` tiles each
-  int pad[2];
+  int inv_tw;                          // ceil(65536 / tw): j / tw == (j * inv_tw) >> 16 for j < 64
+  int pad;
 };
 static_assert(sizeof(EngWork) == 32, "work record");
 
@@ -84,6 +110,7 @@ struct EngArgs {
   const unsigned short* bias_last;
   long long yoff_last;
   int n_phases, ncu, N_last, S_last;
+  int n_shapes, shape_off[kEngMaxShapes];   // first EngWork of every distinct shape
   unsigned long long* trace;           // TRACE builds: [n_phases][ncu][8] stamps of the 100 MHz real-time counter (paro_engine_trace)
 };
 
@@ -95,15 +122,20 @@ __device__ __forceinline__ void st_gran(unsigned long long* p, unsigned tag, uns
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The plan (phase and work records) is CONSTANT while the kernel runs: read it through the constant address space, i.e. with scalar
-// loads into SGPRs.  Left to itself the compiler reads the records with VECTOR loads (the kernel also stores to global memory, so it may
-// not assume the plan unchanged) -- and a vector load returns in order behind the wave's outstanding HBM tile requests: every `ph.G`
-// became a wait for the run-ahead tiles (first build: 11 us per phase).
+// The plan (phase records, this CU's work rows) is copied into LDS when the kernel starts and read from there: a record is needed
+// two or three times per phase on the critical path (the wave that has just consumed a unit needs the NEXT phase's record to request
+// its tiles), and a read from memory there measured ~1500 cycles each -- scalar loads through the constant cache, 3500 cycles between
+// "unit consumed" and "partial sums staged" (profiles/r04_engine_timeline_v3.jsonl) -- while vector loads would queue behind the
+// wave's outstanding HBM tile requests.  The values are wave-uniform: pulled back into scalar registers after the LDS read.
 template <typename T>
-__device__ __forceinline__ T ld_plan(const T* p) {
-  typedef const __attribute__((address_space(4))) T* CP;
+__device__ __forceinline__ T lds_uniform(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  unsigned w[sizeof(T) / 4];
+  __builtin_memcpy(w, p, sizeof(T));
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)w[i]);
   T v;
-  __builtin_memcpy(&v, (CP)(unsigned long long)p, sizeof(T));
+  __builtin_memcpy(&v, w, sizeof(T));
   return v;
 }
 
@@ -115,21 +147,43 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
   constexpr int XS_BYTES = (kEngMaxGroups + 1) * XS_STRIDE * 2;         // + the zero row
   constexpr int RED_BYTES = kEngCompute * kEngTw * 16 * 4;
   constexpr int SVC_BYTES = 256;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[XS_BYTES + RED_BYTES + SVC_BYTES];
+  constexpr int XSUM_BYTES = kEngMaxGroups * 8;                          // per gathered group: sum(x), sum(x * unpack offset)
+  constexpr int PLAN_BYTES = kEngPlanCap * (int)sizeof(EngPhase) + kEngMaxShapes * (int)sizeof(EngWork) + kEngMaxShapes * kEngWaves * (int)sizeof(EngWave);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XS_BYTES + RED_BYTES + SVC_BYTES + PLAN_BYTES + XSUM_BYTES];
+  float* xsum = (float*)(lds + XS_BYTES + RED_BYTES + SVC_BYTES + PLAN_BYTES);
   unsigned short* xs = (unsigned short*)lds;
   unsigned short* zrow = xs + kEngMaxGroups * XS_STRIDE;
   float* red = (float*)(lds + XS_BYTES);
   unsigned short* svc = (unsigned short*)(lds + XS_BYTES + RED_BYTES);
+  const EngPhase* lphase = (const EngPhase*)(lds + XS_BYTES + RED_BYTES + SVC_BYTES);
+  const EngWork* lwork = (const EngWork*)(lds + XS_BYTES + RED_BYTES + SVC_BYTES + kEngPlanCap * (int)sizeof(EngPhase));
+  EngWave* lwave = (EngWave*)(lds + XS_BYTES + RED_BYTES + SVC_BYTES + kEngPlanCap * (int)sizeof(EngPhase) + kEngMaxShapes * (int)sizeof(EngWork));
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cu = blockIdx.x;
-  // TRACE: stamp `slot` of (phase, CU) with the chip-wide 100 MHz counter -- service wave: 0 phase entered, 1 partial sums arrived,
-  // 2 rotated group published; wave 0: 3 gather entered, 4 gathered, 5 past B1, 6 units done, 7 outputs published
+  {
+    // the plan into LDS: every thread moves 16-byte pieces (phase records: n_phases x 144 B; this CU's work row of every shape)
+    const u32x4* src = (const u32x4*)a.phases;
+    u32x4* dst = (u32x4*)(lds + XS_BYTES + RED_BYTES + SVC_BYTES);
+    const int n16 = a.n_phases * (int)(sizeof(EngPhase) / 16);
+    for (int i = tid; i < n16; i += kEngWaves * 64) dst[i] = src[i];
+    if (tid < a.n_shapes * 2) {
+      const int sh = tid >> 1, half = tid & 1;
+      ((u32x4*)lwork)[tid] = ((const u32x4*)(a.work + a.shape_off[sh] + cu))[half];
+    }
+    __syncthreads();
+  }
+  // TRACE: stamp `slot` (of 16; + 16: the shader-clock counter at the same event) of (phase, CU) with the chip-wide 100 MHz counter -- service wave: 0 phase entered, 1 partial sums
+  // arrived, 2 rotated group published; wave 0: 3 gather entered, 4 gathered, 5 past B1, 8 its units consumed, 6 partial sums staged,
+  // 9 past B2, 7 outputs published
   auto stamp = [&](int pi, int slot) {
     if constexpr (TRACE) {
-      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0) a.trace[((long long)pi * a.ncu + blockIdx.x) * 8 + slot] = t;
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime(), c = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        a.trace[((long long)pi * a.ncu + blockIdx.x) * 32 + slot] = t;
+        a.trace[((long long)pi * a.ncu + blockIdx.x) * 32 + 16 + slot] = c;   // the shader clock at the same event
+      }
     }
   };
   // the launch's base tag: advanced by the previous launch's finisher, which first waits until every CU has read it (ctl[2]; the add's
@@ -143,9 +197,9 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
   const unsigned nan2 = (unsigned)A::from_f32(__builtin_nanf("")) * 0x10001u;
 
   // hop 2, consumer side: the rotated groups of this CU's K-chunk into LDS (every wave takes groups wave, wave + 16, ...)
-  auto gather = [&](const EngPhase& ph, const EngWork& w, unsigned tag) {
+  auto gather = [&](long long xoff, int K, const EngWork& w, unsigned tag) {
     if (w.ng <= 0) return;
-    const unsigned long long* src = a.gran + ph.xoff + (long long)w.p * (ph.K / 2) + (unsigned)(w.g0 * 64 + lane);
+    const unsigned long long* src = a.gran + xoff + (long long)w.p * (K / 2) + (unsigned)(w.g0 * 64 + lane);
     for (int i0 = wave; i0 < w.ng; i0 += kEngWaves * 4) {
       unsigned long long gq[4];
       bool ok = false;
@@ -170,7 +224,18 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = i0 + q * kEngWaves;
-        if (i < w.ng) *(unsigned*)(xs + i * XS_STRIDE + 2 * lane) = ok ? (unsigned)gq[q] : nan2;   // (gave up: NaN)
+        if (i < w.ng) {
+          const unsigned xv = ok ? (unsigned)gq[q] : nan2;                                          // (gave up: NaN)
+          *(unsigned*)(xs + i * XS_STRIDE + 2 * lane) = xv;
+          // The two sums the dequantisation needs per group -- sum(x) for the zero points, sum(x * off) for the offsets the cheap unpack
+          // leaves in (common.hpp: 1024 / 64 alternating per register for fp16, 128 for bf16) -- ONCE per group and CU, on the VALU,
+          // by the wave that gathered it: the units used to spend 8 of their 24 matrix instructions on them, and the burst after a
+          // hand-off is matrix-pipe bound (profiles/r04_engine_timeline_v5.jsonl)
+          const float x01 = A::to_f32(xv & 0xffffu) + A::to_f32(xv >> 16);
+          const float offl = A::to_f32((unsigned short)((lane & 1) ? (A::kOffFrag1 & 0xffffu) : (A::kOffFrag0 & 0xffffu)));
+          const float sx = wave_sum_dpp(x01), so = wave_sum_dpp(x01 * offl);                         // totals in lane 63
+          if (lane == 63) *(f32x2*)(xsum + 2 * i) = (f32x2){sx, so};
+        }
       }
     }
   };
@@ -180,8 +245,8 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
     // (its own loop, so that no register of the compute waves' tile buffers is live across the rotation: the first build shared one
     // loop and spilled the just-requested tiles to scratch -- a wait for HBM in front of everything)
     for (int pi = 0; pi < a.n_phases; ++pi) {
-      const EngPhase ph = ld_plan(a.phases + pi);
-      const EngWork w = ld_plan(a.work + ph.work_off + cu);
+      const EngPhase ph = lds_uniform(lphase + pi);
+      const EngWork w = lds_uniform(lwork + ph.shape);
       const unsigned tag = epoch + (unsigned)pi + 1u;      // of this phase's rotated input (and of its output)
       const unsigned tag_in = epoch + (unsigned)pi;        // of the previous phase's partial sums
       stamp(pi, 0);
@@ -245,7 +310,7 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
         st_gran(a.gran + ph.xoff + (long long)p * (ph.K / 2) + (unsigned)(g * 64 + lane), tag, pr);   // hop 2: the data IS the flag
         if (task == cu) stamp(pi, 2);
       }
-      gather(ph, w, tag);
+      gather(ph.xoff, ph.K, w, tag);
       lds_barrier();                                        // B1
       lds_barrier();                                        // B2
     }
@@ -308,7 +373,25 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
   }
 
   // ======================================================================= the fifteen COMPUTE waves
+  // Bookkeeping is what a phase costs here, not arithmetic: sixteen waves share ONE scalar unit per CU, and the first builds spent
+  // 3300 cycles between "unit consumed" and "partial sums staged" on cursor arithmetic, integer divisions, 36-dword record reads and
+  // waterfall loops around buffer descriptors that had ended up in vector registers (profiles/r04_engine_timeline_v3.jsonl).  So: the
+  // wave's share of every SHAPE is worked out once per launch (EngWave, in LDS), a phase needs 16 + 8 dwords from LDS, the descriptors
+  // are pinned into scalar registers, and nothing divides.
   if (tid < XS_STRIDE / 4) *(u32x2*)(zrow + 4 * tid) = (u32x2){0u, 0u};   // (first read behind B1)
+  for (int sh = 0; sh < a.n_shapes; ++sh) {
+    const EngWork w = lds_uniform(lwork + sh);
+    const int nb = w.nb;
+    const int r = wave / nb, b = wave - r * nb;
+    const int nwb = (kEngCompute - b + nb - 1) / nb;
+    const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
+    EngWave e;
+    e.nu = (nt_b > 0 && r < w.ng) ? (w.ng - r + nwb - 1) / nwb : 0;
+    e.r = r; e.nwb = nwb; e.g0 = w.g0;
+    e.nt_b = nt_b; e.tb = w.t0 + b * w.tw; e.tzb = w.tz0 + b * w.tw;
+    e.pad = 0;
+    if (lane == 0) lwave[sh * kEngWaves + wave] = e;        // read back by this wave only (a wave's LDS operations stay in order)
+  }
   // A-fragment addressing of a one-row product: MFMA row 0 carries x, the other fifteen rows read the zero row
   const int mq = lane >> 4, n16 = lane & 15;
   const bool avalid = n16 == 0;
@@ -320,111 +403,130 @@ __global__ __launch_bounds__(kEngWaves * 64) void engine_kernel(const EngArgs a)
   };
   // tile requests of one unit: `n` tiles of group g from tile t (the unused slots of a narrower unit point OUTSIDE the buffer: a
   // buffer load beyond num_records returns zeros and fetches nothing, so the request count stays static for the vmcnt bookkeeping)
-  auto load_unit = [&](TBuf& b, const EngPhase& ph, int g, int t, int tz, int n) {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)ph.wq, 0, (int)ph.wq_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph.sz, 0, (int)ph.sz_bytes, 0x00020000);
+  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto load_unit = [&](TBuf& b, const EngPhaseC& ph, int g_, int t_, int tz_, int n_) {
+    // every operand pinned into a scalar register HERE: a cursor that lives across loop iterations ends up in vector registers, and a
+    // buffer descriptor in vector registers makes the compiler wrap each load in a waterfall loop
+    const unsigned long long wqp = (unsigned long long)ph.wq, szp = (unsigned long long)ph.sz;
+    const unsigned long long wq_s = ((unsigned long long)(unsigned)rfl((int)(wqp >> 32)) << 32) | (unsigned)rfl((int)wqp);
+    const unsigned long long sz_s = ((unsigned long long)(unsigned)rfl((int)(szp >> 32)) << 32) | (unsigned)rfl((int)szp);
+    const int g = rfl(g_), t = rfl(t_), tz = rfl(tz_), n = rfl(n_), tstride = rfl(ph.tstride);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wq_s, 0, rfl((int)ph.wq_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sz_s, 0, rfl((int)ph.sz_bytes), 0x00020000);
+    const unsigned base = (unsigned)(t * tstride + g * rfl(ph.gstride)) * 1024u + (unsigned)lane * 16u;
+    const unsigned step = (unsigned)tstride * 1024u;
 #pragma unroll
-    for (int j = 0; j < kEngTw; ++j) {
-      const unsigned off = j < n ? ((unsigned)((t + j) * ph.tstride + g * ph.gstride) * 1024u + (unsigned)lane * 16u) : 0xfffffff0u;
-      b.q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 2));   // aux 2 = nt: streamed once
-    }
+    for (int j = 0; j < kEngTw; ++j)
+      b.q[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, j < n ? base + (unsigned)j * step : 0xfffffff0u, 0, 2));   // aux 2 = nt
+    const unsigned zbase = (unsigned)(g * rfl(ph.szrow)) * 4u + (unsigned)n16 * 16u;
 #pragma unroll
     for (int j = 0; j < kEngTw; ++j) {
       const int ts = tz + j;
-      const unsigned off = j < n ? ((unsigned)(g * ph.szrow) + (unsigned)(((ts >> 2) * 16 + n16) * 4 + (ts & 3))) * 4u : 0xfffffff0u;
-      b.szw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+      b.szw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, j < n ? zbase + (unsigned)((ts >> 2) * 256 + (ts & 3) * 4) : 0xfffffff0u, 0, 0);
     }
   };
-  // this wave's place among the units of (phase, CU): column block b, rank r among the block's `nwb` waves
-  auto place = [&](const EngWork& w, int& b, int& r, int& nwb) {
-    const int nb = w.nb;                                    // 1..15 column blocks; block b is shared by the waves b, b + nb, ...
-    r = wave / nb;
-    b = wave - r * nb;
-    nwb = (kEngCompute - b + nb - 1) / nb;
+  // A wave's units form ONE stream across the phases: (phase 0: groups g0 + r, + nwb, ...), (phase 1: ...), ...  The REQUEST cursor
+  // runs two units ahead of the consuming loop -- unit k lives in buffer k & 1, and the buffer a unit has just been consumed from is
+  // re-requested at once with unit k + 2, whatever phase that is in.  So when a phase's x arrives, the wave's next two units (all a
+  // Qwen3-4B phase has for it) are in registers or in flight.
+  struct Cur {
+    int pi, k;
+    EngPhaseC ph;
+    EngWave wv;
   };
-  // the first unit of (phase, this wave): requested one phase ahead
-  auto first_unit = [&](TBuf& b, int pi) {
-    const EngPhase ph2 = ld_plan(a.phases + pi);
-    const EngWork w2 = ld_plan(a.work + ph2.work_off + cu);
-    int b2, r2, nwb2;
-    place(w2, b2, r2, nwb2);
-    const int nt2 = min((int)w2.tw, (int)w2.nt - b2 * (int)w2.tw);
-    const bool has2 = r2 < w2.ng && nt2 > 0;
-    load_unit(b, ph2, w2.g0 + (has2 ? r2 : 0), w2.t0 + b2 * w2.tw, w2.tz0 + b2 * w2.tw, has2 ? nt2 : 0);
+  auto seek = [&](Cur& c) {                                 // onto the next phase with a unit for this wave (pi == n_phases: exhausted)
+    while (c.pi < a.n_phases) {
+      c.ph = lds_uniform((const EngPhaseC*)(lphase + c.pi));
+      c.wv = lds_uniform(lwave + c.ph.shape * kEngWaves + wave);
+      if (c.wv.nu > 0) break;
+      ++c.pi;
+    }
+    c.k = 0;
+  };
+  auto request = [&](TBuf& b, Cur& c) {                     // the cursor's unit into `b`, then the cursor moves on
+    const bool live = c.pi < a.n_phases;
+    load_unit(b, c.ph, c.wv.g0 + c.wv.r + c.k * c.wv.nwb, c.wv.tb, c.wv.tzb, live ? c.wv.nt_b : 0);
+    if (live && ++c.k >= c.wv.nu) {
+      ++c.pi;
+      seek(c);
+    }
   };
 
-  TBuf tc, tn;
-  first_unit(tc, 0);                                        // before anything is waited for
+  TBuf tA, tB;
+  Cur rq;
+  rq.pi = 0;
+  seek(rq);
+  request(tA, rq);                                          // before anything is waited for
+  request(tB, rq);
+  int par = 0;                                              // buffer of the next unit to consume
 
   for (int pi = 0; pi < a.n_phases; ++pi) {
-    const EngPhase ph = ld_plan(a.phases + pi);
-    const EngWork w = ld_plan(a.work + ph.work_off + cu);
+    const EngPhaseC ph = lds_uniform((const EngPhaseC*)(lphase + pi));
+    const EngWork w = lds_uniform(lwork + ph.shape);
+    const EngWave wv = lds_uniform(lwave + ph.shape * kEngWaves + wave);
     const unsigned tag = epoch + (unsigned)pi + 1u;
     if (wave == 0) stamp(pi, 3);
-    gather(ph, w, tag);
+    gather(ph.xoff, ph.K, w, tag);
     if (wave == 0) stamp(pi, 4);
     lds_barrier();                                          // B1: x of this phase is staged
     if (wave == 0) stamp(pi, 5);
 
-    // ---- units (group, column block); the NEXT unit's tiles -- of this phase or the first of the next -- in flight
     float acc[kEngTw] = {0.f, 0.f, 0.f, 0.f};
-    int b, r, nwb;
-    place(w, b, r, nwb);
-    const int nt_b = min((int)w.tw, (int)w.nt - b * (int)w.tw);
-    const int tb = w.t0 + b * w.tw, tzb = w.tz0 + b * w.tw;
-    const bool has = nt_b > 0 && r < w.ng;
-    for (int gi = r; gi < w.ng && has; gi += nwb) {
-      const bool more = gi + nwb < w.ng;
-      if (more) load_unit(tn, ph, w.g0 + gi + nwb, tb, tzb, nt_b);
-      // fragments of the rotated group, the two sums, unpack -> MFMA -> scale / zero (gemv_impl.hpp's unit, one row)
+    // one unit: fragments of the rotated group, the two sums, unpack -> MFMA -> scale / zero (gemv_impl.hpp's unit, one row), then the
+    // buffer is handed back to the request cursor
+    const int nt_u = wv.nt_b;
+    auto unit = [&](TBuf& tc, int gi) {
       vec8 af[4];
       {
         const unsigned short* afrag = (avalid ? xs + gi * XS_STRIDE : zrow) + 8 * mq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
       }
-      f32x4 sx = {0.f, 0.f, 0.f, 0.f}, so = {0.f, 0.f, 0.f, 0.f};
-      {
-        const u32x4 ones = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
-        const u32x4 offs = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          sx = A::mfma(af[i], __builtin_bit_cast(vec8, ones), sx);
-          so = A::mfma(af[i], __builtin_bit_cast(vec8, offs), so);
-        }
-      }
+      const f32x2 sums = *(const f32x2*)(xsum + 2 * gi);      // {sum(x), sum(x * off)} of the group (gather)
 #pragma unroll
       for (int j = 0; j < kEngTw; ++j) {
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (j < nt_u) {                                      // (uniform: the unit's tile count; empty slots cost no matrix instructions)
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned w4[4];
-          A::unpack_fast(tc.q[j][i], w4, upk);
-          const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
-          d = A::mfma(af[i], __builtin_bit_cast(vec8, wv), d);
+          for (int i = 0; i < 4; ++i) {
+            unsigned w4[4];
+            A::unpack_fast(tc.q[j][i], w4, upk);
+            const u32x4 wv4 = {w4[0], w4[1], w4[2], w4[3]};
+            d = A::mfma(af[i], __builtin_bit_cast(vec8, wv4), d);
+          }
+          const float s = f16_bits_to_f32(tc.szw[j] & 0xffffu), zf = f16_bits_to_f32(tc.szw[j] >> 16);
+          acc[j] = __builtin_fmaf(s, __builtin_fmaf(-zf, sums[0], d[0] - sums[1]), acc[j]);
         }
-        const float s = f16_bits_to_f32(tc.szw[j] & 0xffffu), zf = f16_bits_to_f32(tc.szw[j] >> 16);
-        acc[j] = __builtin_fmaf(s, __builtin_fmaf(-zf, sx[0], d[0] - so[0]), acc[j]);
       }
-      if (more) tc = tn;     // (a register copy waits for the requests it copies: only where the next unit is consumed straight away)
+      if (wave == 0) stamp(pi, 11);
+      request(tc, rq);
+    };
+    if (wave == 0) stamp(pi, 10);
+    for (int k = 0; k < wv.nu; ++k) {
+      const int gi = wv.r + k * wv.nwb;
+      if (par) unit(tB, gi); else unit(tA, gi);
+      par ^= 1;
     }
-    // The NEXT phase's first unit, requested behind this phase's last consume and INTO `tc`: the first build requested it into `tn` ahead
-    // of the last unit and copied -- the copy is a wait for HBM, 2 us in front of every publish (profiles/r04_engine_timeline_v1.jsonl)
-    if (pi + 1 < a.n_phases) first_unit(tc, pi + 1);
+    if (wave == 0) stamp(pi, 8);
     if (lane < 16) {
 #pragma unroll
       for (int j = 0; j < kEngTw; ++j) red[(wave * kEngTw + j) * 16 + lane] = acc[j];
     }
     if (wave == 0) stamp(pi, 6);
     lds_barrier();                                          // B2: every wave's partial sums are staged
+    if (wave == 0) stamp(pi, 9);
 
     // ---- hop 1, producer side: this CU's outputs over its K-chunk, one {tag, fp32} granule each (wave order = group order: static)
     if (tid < w.nt * 16) {
       const int j = tid >> 4, n = tid & 15;
-      const int bj = j / w.tw, jj = j - bj * w.tw;
+      const int bj = (j * w.inv_tw) >> 16, jj = j - bj * w.tw;      // j / tw without a division (inv_tw = ceil(65536 / tw), j < 64)
       const int nw = (kEngCompute - bj + w.nb - 1) / w.nb;
+      float part[kEngCompute];
+#pragma unroll
+      for (int rr = 0; rr < kEngCompute; ++rr) part[rr] = red[((min(rr, nw - 1) * w.nb + bj) * kEngTw + jj) * 16 + n];   // all reads in flight at once
       float v = 0.f;
-      for (int rr = 0; rr < nw; ++rr) v += red[((rr * w.nb + bj) * kEngTw + jj) * 16 + n];
+#pragma unroll
+      for (int rr = 0; rr < kEngCompute; ++rr) v += rr < nw ? part[rr] : 0.f;
       st_gran(a.gran + ph.yoff + (long long)w.s * ph.N + (unsigned)((w.t0 + j) * 16 + n), tag, __builtin_bit_cast(unsigned, v));
     }
     if (wave == 0) stamp(pi, 7);
@@ -485,6 +587,7 @@ static bool plan_phase(const paro_linear_t* L, int ncu, int S, PhasePlan& out) {
     EngWork idle{};
     idle.nb = 1;
     idle.tw = 1;                                             // (a CU without work in a phase: ng = nt = 0; the divisors stay sane)
+    idle.inv_tw = 65536;
     out.work.assign(ncu, idle);
   }
   long long worst = 0;
@@ -506,6 +609,7 @@ static bool plan_phase(const paro_linear_t* L, int ncu, int S, PhasePlan& out) {
         int nb = 1, tw = 1;
         if (pick_blocks(w.nt, w.ng, nb, tw) != 0) return false;
         w.nb = (short)nb; w.tw = (short)tw;
+        w.inv_tw = (65536 + tw - 1) / tw;
         const int nwb = kEngCompute / nb;                    // (the blocks with the fewest waves)
         const long long steps = (w.ng + nwb - 1) / nwb;
         // cycles: a CU ingests a 1 KiB tile in ~96 cycles (25 GB/s); its slowest wave then runs `steps` unit steps
@@ -520,12 +624,13 @@ static bool plan_phase(const paro_linear_t* L, int ncu, int S, PhasePlan& out) {
 struct EnginePlanHost {
   std::vector<EngPhase> phases;
   std::vector<EngWork> work;
+  std::vector<int> shape_off;
   long long granules = 0, yoff_last = 0;
   int S_last = 1;
 };
 
 static int build_plan(const paro_engine_phase_t* ph, int n, int ncu, EnginePlanHost& H) {
-  if (!ph || n < 1 || n > 4096) return fail(PARO_ERR_INVALID, "engine: 1..4096 phases");
+  if (!ph || n < 1 || n > kEngPlanCap) return fail(PARO_ERR_INVALID, "engine: 1..%d phases (the plan is cached in LDS; longer chains: one engine per part)", kEngPlanCap);
   if (ncu < kEngMaxSplit * PARO_MAX_PARTS) return fail(PARO_ERR_UNSUPPORTED, "engine: needs at least %d compute units", kEngMaxSplit * PARO_MAX_PARTS);
   for (int i = 0; i < n; ++i) {
     const paro_linear_t* L = ph[i].L;
@@ -547,18 +652,18 @@ static int build_plan(const paro_engine_phase_t* ph, int n, int ncu, EnginePlanH
   H.phases.resize(n);
   H.work.clear();
   // identical linears (same shape) share one work table
-  struct Key { long long K, N; int P; int cols[PARO_MAX_PARTS]; int off; int S; };
+  struct Key { long long K, N; int P; int cols[PARO_MAX_PARTS]; int off; int S; int shape; };
   std::vector<Key> seen;
   int S_prev = 1;
   long long gran = 0, yoff_prev = 0;
   for (int i = 0; i < n; ++i) {
     const paro_linear_t* L = ph[i].L;
     const int G = (int)(L->K / 128);
-    int off = -1, S = 1;
+    int off = -1, S = 1, shape = -1;
     for (const Key& k : seen) {
       bool same = k.K == L->K && k.N == L->N && k.P == L->n_parts;
       for (int p = 0; same && p < L->n_parts; ++p) same = k.cols[p] == L->part_cols[p];
-      if (same) { off = k.off; S = k.S; break; }
+      if (same) { off = k.off; S = k.S; shape = k.shape; break; }
     }
     if (off < 0) {
       PhasePlan best;
@@ -569,10 +674,13 @@ static int build_plan(const paro_engine_phase_t* ph, int n, int ncu, EnginePlanH
         if (!any || cand.cost < best.cost) { best = cand; any = true; }
       }
       if (!any) return fail(PARO_ERR_UNSUPPORTED, "engine: no work split for a [%lld, %lld] linear on %d compute units", (long long)L->K, (long long)L->N, ncu);
+      if ((int)seen.size() >= kEngMaxShapes) return fail(PARO_ERR_UNSUPPORTED, "engine: more than %d distinct linear shapes in one chain", kEngMaxShapes);
       off = (int)H.work.size();
       S = best.S;
+      shape = (int)seen.size();
+      H.shape_off.push_back(off);
       H.work.insert(H.work.end(), best.work.begin(), best.work.end());
-      Key k{L->K, L->N, L->n_parts, {0}, off, S};
+      Key k{L->K, L->N, L->n_parts, {0}, off, S, shape};
       for (int p = 0; p < L->n_parts; ++p) k.cols[p] = L->part_cols[p];
       seen.push_back(k);
     }
@@ -593,6 +701,7 @@ static int build_plan(const paro_engine_phase_t* ph, int n, int ncu, EnginePlanH
     e.N = (int)L->N; e.K = (int)L->K;
     e.n_tasks = G * L->n_parts;
     e.work_off = off;
+    e.shape = shape;
     e.N_prev = i > 0 ? (int)ph[i - 1].L->N : 0;
     e.xoff = gran;
     gran += (long long)L->n_parts * (L->K / 2);
@@ -624,6 +733,8 @@ extern "C" int paro_engine_plan(const paro_engine_phase_t* phases, int n_phases,
   out->n_cus = n_cus;
   out->act_dtype = phases[0].L->act_dtype;
   out->last_split = H.S_last;
+  out->n_shapes = (int)H.shape_off.size();
+  for (int i = 0; i < 8; ++i) out->shape_off[i] = i < (int)H.shape_off.size() ? H.shape_off[i] : 0;
   out->last_out_offset = H.yoff_last;
   out->last_bias = phases[n_phases - 1].L->bias;
   out->plan_bytes = plan_bytes_of(H);
@@ -689,6 +800,9 @@ static int engine_launch(const paro_engine_t* e, const void* plan_dev, const voi
   a.N_last = (int)e->out_features;
   a.S_last = e->last_split;
   a.trace = trace;
+  if (e->n_shapes < 1 || e->n_shapes > kEngMaxShapes || e->n_phases > kEngPlanCap) return fail(PARO_ERR_INVALID, "engine descriptor was not produced by paro_engine_plan");
+  a.n_shapes = e->n_shapes;
+  for (int i = 0; i < kEngMaxShapes; ++i) a.shape_off[i] = e->shape_off[i];
   // every workgroup of the grid must be resident at once (they wait for each other): one 16-wave workgroup per CU
   {
     static int per_cu[3] = {-1, -1, -1};

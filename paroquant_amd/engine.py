@@ -79,8 +79,8 @@ class DecodeEngine:
 
     @torch.no_grad()
     def trace(self, x: torch.Tensor) -> torch.Tensor:
-        """One launch of the diagnostic twin (``paro_engine_trace``): int64 [n_phases, n_cus, 8] stamps of the 100 MHz counter."""
-        tr = torch.zeros(len(self.layers), int(self._e.n_cus), 8, dtype=torch.int64, device=self.device)
+        """One launch of the diagnostic twin (``paro_engine_trace``): int64 [n_phases, n_cus, 32] stamps (16 events: 100 MHz counter, then the shader clock at the same events) of the 100 MHz counter."""
+        tr = torch.zeros(len(self.layers), int(self._e.n_cus), 32, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             nat.check(nat.load().paro_engine_trace(ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), self.y.data_ptr(),
                                                   self.workspace.data_ptr(), self.workspace.numel(), tr.data_ptr(),

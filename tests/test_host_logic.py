@@ -478,12 +478,13 @@ def test_engine_planner_covers_every_tile_once(lib):
             setattr(d, f, 0x1000)        # never dereferenced on the host
         return d
 
-    phase_dt = np.dtype([("ptrs", "<u8", 5), ("wq_bytes", "<u4"), ("sz_bytes", "<u4"), ("G", "<i4"), ("T", "<i4"), ("tstride", "<i4"),
-                         ("gstride", "<i4"), ("szrow", "<i4"), ("P", "<i4"), ("S", "<i4"), ("S_prev", "<i4"), ("in_col0", "<i4"), ("N", "<i4"),
-                         ("K", "<i4"), ("n_tasks", "<i4"), ("work_off", "<i4"), ("N_prev", "<i4"), ("pad", "<i4", 2), ("yoff", "<i8"),
-                         ("yoff_prev", "<i8"), ("xoff", "<i8"), ("pad2", "<i8")])
+    phase_dt = np.dtype([("wq", "<u8"), ("sz", "<u8"), ("wq_bytes", "<u4"), ("sz_bytes", "<u4"), ("tstride", "<i4"), ("gstride", "<i4"),
+                         ("szrow", "<i4"), ("shape", "<i4"), ("K", "<i4"), ("N", "<i4"), ("xoff", "<i8"), ("yoff", "<i8"),
+                         ("rot", "<u8"), ("cs", "<u8"), ("bias_prev", "<u8"), ("G", "<i4"), ("P", "<i4"), ("S", "<i4"), ("S_prev", "<i4"),
+                         ("in_col0", "<i4"), ("n_tasks", "<i4"), ("N_prev", "<i4"), ("T", "<i4"), ("yoff_prev", "<i8"), ("work_off", "<i4"),
+                         ("pad", "<i4", 3)])
     work_dt = np.dtype([("s", "<i2"), ("p", "<i2"), ("g0", "<i2"), ("ng", "<i2"), ("t0", "<i4"), ("tz0", "<i4"), ("nt", "<i2"), ("nb", "<i2"),
-                        ("tw", "<i2"), ("pad0", "<i2"), ("pad", "<i4", 2)])
+                        ("tw", "<i2"), ("pad0", "<i2"), ("inv_tw", "<i4"), ("pad", "<i4")])
     assert phase_dt.itemsize == 144 and work_dt.itemsize == 32
     cases = {256: [[(2560, [4096, 1024, 1024]), (4096, [2560]), (2560, [9728, 9728]), (9728, [2560])] * 2,
                    [(4096, [4096, 1024, 1024]), (4096, [4096]), (4096, [14336, 14336]), (14336, [4096])],
@@ -518,6 +519,7 @@ def test_engine_planner_covers_every_tile_once(lib):
                     assert tstart[w["p"]] <= w["t0"] and w["t0"] + w["nt"] <= tstart[w["p"] + 1]          # inside ONE partition
                     assert 1 <= w["nb"] <= 15 and 1 <= w["tw"] <= 4 and w["nb"] * w["tw"] >= w["nt"] > (w["nb"] - 1) * w["tw"]  # unit blocks cover the tiles, none empty
                     assert w["ng"] <= 128 and w["nt"] <= 60 and 0 <= w["s"] < p["S"]
+                    assert all((j * int(w["inv_tw"])) >> 16 == j // int(w["tw"]) for j in range(64))       # the publish loop's j / tw
                     # padded scale / zero tile space: partitions start at multiples of 8 tiles
                     assert w["tz0"] == sum((n // 16 + 7) // 8 * 8 for n in sizes[:w["p"]]) + (w["t0"] - tstart[w["p"]])
                 assert (cover == 1).all(), (ncu, i, K, sizes)

@@ -8,7 +8,8 @@ published the previous phase's outputs (the edge's time zero), the median / late
   got     the rotating wave has all partial sums of its group          (hop 1: store flight + poll)
   rotpub  it has published the rotated group                           (8 Givens stages, LDS transpose, store)
   gath    a CU has gathered its groups' rotated x into LDS             (hop 2)
-  units   its waves have consumed their tiles
+  b1      it is past the first barrier (every wave of the CU has gathered)
+  w0units wave 0 has consumed its units;   units  ... and staged its partial sums;   b2  the CU is past the second barrier
   pub     it has published its outputs = the next edge's time zero     (phase duration)"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,9 +46,19 @@ def main():
             row = {"got_med": np.median(tr[p, rot, 1]) - t0, "got_max": tr[p, rot, 1].max() - t0,
                    "rotpub_med": np.median(tr[p, rot, 2]) - t0, "rotpub_max": tr[p, rot, 2].max() - t0,
                    "gath_med": np.median(tr[p, :, 4]) - t0, "gath_max": tr[p, :, 4].max() - t0,
+                   "b1_med": np.median(tr[p, :, 5]) - t0, "b1_max": tr[p, :, 5].max() - t0,
+                   "w0units_med": np.median(tr[p, :, 8]) - t0,
                    "units_med": np.median(tr[p, :, 6]) - t0, "units_max": tr[p, :, 6].max() - t0,
+                   "b2_med": np.median(tr[p, :, 9]) - t0, "b2_max": tr[p, :, 9].max() - t0,
                    "pub_med": np.median(tr[p, :, 7]) - t0, "pub_max": tr[p, :, 7].max() - t0,
-                   "entered_med": np.median(tr[p, :, 3]) - t0}
+                   "entered_med": np.median(tr[p, :, 3]) - t0,
+                   "u0_med": np.median(tr[p, :, 10]) - t0, "u1_med": np.median(tr[p, :, 11]) - t0,
+                   # shader clocks per 10 ns tick between two far-apart events of one CU (2.4 GHz = 24): is the chip clocked down while it polls?
+                   "clk_per_tick": float(np.median((tr[p, :, 16 + 7] - tr[p, :, 16 + 3]) / np.maximum(tr[p, :, 7] - tr[p, :, 3], 1))) * 100.0,
+                   "unit_cycles": float(np.median(tr[p, :, 16 + 11] - tr[p, :, 16 + 10])) * 100.0,
+                   "b1_to_u0_cycles": float(np.median(tr[p, :, 16 + 10] - tr[p, :, 16 + 5])) * 100.0,
+                   "u1_to_staged_cycles": float(np.median(tr[p, :, 16 + 6] - tr[p, :, 16 + 11])) * 100.0,
+                   "b2_to_pub_cycles": float(np.median(tr[p, :, 16 + 7] - tr[p, :, 16 + 9])) * 100.0}
             for k, v in row.items():
                 acc.setdefault(kind, {}).setdefault(k, []).append(float(v) * 0.01)      # -> microseconds
     for kind in names:
