@@ -27,6 +27,9 @@
 // (tests/test_gpu_engine.py); NOT bit-identical to the per-call kernels, whose K partition differs.
 #include <stddef.h>
 #include <string.h>
+#ifndef PARO_ENG_WAVES
+#define PARO_ENG_WAVES 16
+#endif
 
 #include <algorithm>
 #include <vector>
@@ -35,12 +38,12 @@
 
 namespace paro {
 
-constexpr int kEngWaves = 16;          // waves per workgroup: 15 compute + 1 service
-constexpr int kEngCompute = 15;
-constexpr int kEngTw = 4;              // tiles per unit (two units of 4 KiB in flight per wave)
+constexpr int kEngWaves = PARO_ENG_WAVES;          // waves per workgroup: all but one compute, the last is the service wave
+constexpr int kEngCompute = kEngWaves - 1;
+constexpr int kEngTw = kEngWaves == 16 ? 4 : 8;   // tiles per unit (two units in flight per wave: 16 waves x 128 VGPRs, or 8 x 256)
 constexpr int kEngMaxSplit = 4;        // K-chunks per linear
 constexpr int kEngMaxGroups = 128;     // groups of one K-chunk (LDS: 272 B each)
-constexpr int kEngMaxTiles = 60;       // tiles of one CU and phase (publishing threads: 60 x 16 <= 15 waves)
+constexpr int kEngMaxTiles = kEngCompute * 4;   // tiles of one CU and phase (publishing threads: 16 per tile, compute waves only)
 constexpr unsigned kEngSpin = 1u << 21;
 constexpr int kEngPlanCap = 448;       // phases whose records fit the LDS copy of the plan (Llama-3-70B: 320)
 constexpr int kEngMaxShapes = 8;       // distinct linear shapes of a chain (their work rows are cached per CU)
