@@ -584,9 +584,17 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     (cli/benchmark.py:8-26: 2 warm-up + 5 runs, 128 new tokens; inference/base.py:62-77: tps = decode tokens /
     (t_end - t_first_token)).  Synthetic weights of the architecture, full vocabulary."""
     from paroquant_amd.decoder import MODEL_CONFIGS, ParoDecoderLM
-    if model not in MODEL_CONFIGS:
+    hybrid = model in HYBRID
+    if model not in MODEL_CONFIGS and not hybrid:
         return None
-    lm = ParoDecoderLM.random(model, dev, max_positions=prompt + new + 8, tp_rank=tp_rank, tp_world=tp_world, allreduce=allreduce)
+    if hybrid:
+        if tp_world != 1:
+            return None
+        from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM       # gated delta net + gated head_dim-256 attention (csrc/gdn.hip)
+        lm = ParoQwen35DecoderLM.random(model, dev, max_positions=prompt + new + 8)
+        lm.deferred, lm.fused_allreduce = False, False
+    else:
+        lm = ParoDecoderLM.random(model, dev, max_positions=prompt + new + 8, tp_rank=tp_rank, tp_world=tp_world, allreduce=allreduce)
     ids = torch.randint(0, lm.cfg.vocab, (prompt,), device=dev, generator=torch.Generator(device=dev).manual_seed(11))  # same prompt on every rank
     stats = []
     for i in range(warmup + runs):
@@ -599,7 +607,8 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
     return {"value": round(tps, 1), "unit": "tokens/s", "ms_per_token": round(ms, 4),
             "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
             "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
-            "launches_per_token": (5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3 + (1 if lm.deferred else 0),
+            "launches_per_token": (sum(5 if L.full else 6 for L in lm.layers) + 3) if hybrid else
+                                  ((5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3 + (1 if lm.deferred else 0)),
             "deferred_ksplit_reduction": bool(lm.deferred),   # o / down leave partial sums, gate_up / the next qkv complete them (decoder.py)
             "parallelism": f"tp{tp_world}" + (" (bytes_per_token and GBps are per rank)" if tp_world > 1 else ""),
             "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),

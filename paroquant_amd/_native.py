@@ -68,6 +68,9 @@ EXPORTS = (
     "paro_engine_describe",
     "paro_engine_run",
     "paro_engine_trace",
+    "paro_gdn_prep",
+    "paro_gdn_step",
+    "paro_attn_decode_gated",
 )
 
 
@@ -251,6 +254,14 @@ def load() -> ctypes.CDLL:
     lib.paro_engine_describe.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
     lib.paro_engine_run.restype = c_int
     lib.paro_engine_run.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    f32 = ctypes.c_float
+    lib.paro_gdn_prep.restype = c_int
+    lib.paro_gdn_prep.argtypes = [c_void_p, c_void_p, c_void_p, f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.paro_gdn_step.restype = c_int
+    lib.paro_gdn_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, f32, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.paro_attn_decode_gated.restype = c_int
+    lib.paro_attn_decode_gated.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, f32, f32, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_void_p]
     lib.paro_engine_trace.restype = c_int
     lib.paro_engine_trace.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     if lib.paro_abi_version() != PARO_ABI_VERSION:
