@@ -24,7 +24,13 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    lm = ParoDecoderLM.random(args.model, dev, n_layers=args.layers or None, max_positions=args.prompt + args.new + 8)
+    import bench
+    if args.model in bench.HYBRID:       # Qwen3.5 family: gated delta net + gated head_dim-256 attention (paroquant_amd/decoder_qwen35.py)
+        from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM
+        lm = ParoQwen35DecoderLM.random(args.model, dev, n_layers=args.layers or None, max_positions=args.prompt + args.new + 8)
+        lm.deferred = False
+    else:
+        lm = ParoDecoderLM.random(args.model, dev, n_layers=args.layers or None, max_positions=args.prompt + args.new + 8)
     c = lm.cfg
     ids = torch.randint(0, c.vocab, (args.prompt,), device=dev)
     stats = []
