@@ -356,15 +356,17 @@ int paro_attn_decode_parts(const float* qkv_parts, int64_t norm_dim, float norm_
  *                   g_beta[h] = exp(-exp(A_log[h]) * softplus(a[h] + dt_bias[h])),  g_beta[n_v_heads + h] = sigmoid(b[h])
  *   paro_gdn_step   torch_recurrent_gated_delta_rule for one token per value head (key / value head dims 128): q, k l2-normalised (q scaled
  *                   by 128^-1/2), S *= decay, delta = (v - S^T k) beta, S += k delta^T, o = S^T q, then Qwen3_5RMSNormGated with z;
- *                   conv_out = [q heads | k heads | v heads] from paro_gdn_prep; state fp32 [n_v_heads][128][128], updated in place
+ *                   conv_out = [q heads | k heads | v heads] from paro_gdn_prep; state fp32 [n_v_heads][128][128], updated in place; four
+ *                   workgroups per value head (32 value columns each), the last to arrive normalises the head (workspace: raw outputs + tickets)
  *   paro_attn_decode_gated   Qwen3_5Attention at one row: qkv = [n_heads][2][head_dim] (query | gate per head) then k, v heads; q / k
  *                   RMSNorm with weights w (norm_plus_one: 1 + w), rotary embedding on the first rotary_dim dimensions (rope fp32
  *                   [max_positions][rotary_dim]: cos then sin), KV append at *pos (kcache / vcache act_dtype [n_kv_heads][max_positions]
  *                   [head_dim]), attention over 0..*pos, output * sigmoid(gate).  head_dim 256. */
 int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, float eps, void* conv_state, const float* conv_w, const float* A_log,
                   const float* dt_bias, void* conv_out, float* g_beta, int hidden, int conv_dim, int n_v_heads, int act_dtype, void* stream);
+int64_t paro_gdn_workspace_bytes(int n_v_heads);   /* scratch of paro_gdn_step: zero-filled ONCE by the caller (the arrival tickets return to zero) */
 int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,
-                  int n_k_heads, int n_v_heads, int act_dtype, void* stream);
+                  int n_k_heads, int n_v_heads, int act_dtype, void* workspace, void* stream);
 int paro_attn_decode_gated(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
                            const void* q_norm_w, const void* k_norm_w, int norm_plus_one, float eps, float scale, int n_heads,
                            int n_kv_heads, int head_dim, int rotary_dim, int max_positions, int act_dtype, void* stream);

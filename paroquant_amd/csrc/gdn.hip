@@ -57,14 +57,29 @@ __global__ __launch_bounds__(256) void gdn_prep_kernel(const GdnPrepArgs a) {
     *(u32x2*)(a.conv_state + 4 * c) = (u32x2){(st[1] & 0xffffu) << 16, (st[1] >> 16) | ((unsigned)xn << 16)};
     return;
   }
-  // one workgroup per row of [in_proj_a ; in_proj_b]: dot with the RMS-normalised hidden state (the norm's scalar applied last)
+  // one workgroup per row of [in_proj_a ; in_proj_b]: dot with the RMS-normalised hidden state (the norm's scalar applied last).
+  // Every load of the row is requested before anything is consumed (first build: a 16-step loop of dependent round trips, 9 us per launch)
   const int r = blockIdx.x - a.conv_blocks;
   __shared__ float red[8];
   float dot = 0.f, ssq = 0.f;
-  for (int i = tid; i < a.hidden; i += 256) {
-    const float xv = A::to_f32(a.x[i]);
-    dot = __builtin_fmaf(a.w_ab[(int64_t)r * a.hidden + i], xv, dot);
-    ssq = __builtin_fmaf(xv, xv, ssq);
+  const float* wr = a.w_ab + (int64_t)r * a.hidden;
+  for (int i0 = 0; i0 < a.hidden; i0 += 256 * 16) {                       // 16 channels per thread and pass (hidden <= 4096: one pass)
+    const int i = i0 + tid * 16;
+    f32x4 w4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    u32x4 x8[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (i + 16 <= a.hidden) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w4[q] = *(const f32x4*)(wr + i + 4 * q);
+      x8[0] = *(const u32x4*)(a.x + i);
+      x8[1] = *(const u32x4*)(a.x + i + 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned xw = x8[q >> 2][q & 3];
+      const float x0 = A::to_f32(xw & 0xffffu), x1 = A::to_f32(xw >> 16);
+      dot = __builtin_fmaf(w4[q >> 1][(q & 1) * 2], x0, __builtin_fmaf(w4[q >> 1][(q & 1) * 2 + 1], x1, dot));
+      ssq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq));
+    }
   }
   dot = wave_total(dot);
   ssq = wave_total(ssq);
@@ -90,67 +105,91 @@ struct GdnStepArgs {
   float* state;                    // [nv][128 k][128 v] fp32, updated in place
   const unsigned short* norm_w;    // [128] weight of the gated RMSNorm
   unsigned short* out;             // [value_dim]
+  float* scratch;                  // [nv][128] raw outputs of a head's four workgroups + [nv] arrival tickets (zero between launches)
   float eps;
   int nk, nv;
 };
 
+// grid = value heads x 4: a workgroup owns 32 of the head's 128 value columns (the recurrence is independent per column) -- a CU ingests
+// ~13 B / clock, so the 128 KiB a head's state moves per token (read + write) are spread over four CUs (first build: one workgroup per
+// head, 5.9 us).  Thread = (column v, one of eight 16-row slices of k).  The gated RMSNorm needs the head's 128 outputs: the LAST of the
+// four workgroups to arrive (write-through stores, agent-scope release, ticket, acquire; no spinning) normalises and stores them.
 template <typename AT>
 __global__ __launch_bounds__(256) void gdn_step_kernel(const GdnStepArgs a) {
   typedef Act<AT> A;
-  const int tid = threadIdx.x, v = tid & 127, kh2 = tid >> 7;
-  const int h = blockIdx.x, kh = h / (a.nv / a.nk);
+  const int tid = threadIdx.x, vl = tid & 31, ksl = tid >> 5;
+  const int h = blockIdx.x >> 2, c4 = blockIdx.x & 3, v = c4 * 32 + vl;
+  const int kh = h / (a.nv / a.nk);
   const int key_dim = a.nk * 128;
-  __shared__ float qs[128], ks[128], part[2][128], nrm[4];
-  float* S = a.state + ((int64_t)h * 128 + kh2 * 64) * 128 + v;
-  float s[64];
+  __shared__ float qs[128], ks[128], part[8][32], nrm[4];
+  __shared__ unsigned last;
+  float* S = a.state + ((int64_t)h * 128 + ksl * 16) * 128 + v;
+  float s[16];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) s[i] = S[i * 128];                           // in flight under the q / k normalisation
-  // q and k of this head's key head, l2-normalised (eps 1e-6), q scaled by 1 / sqrt(128)
+  for (int i = 0; i < 16; ++i) s[i] = S[i * 128];                           // in flight under the q / k normalisation
   {
-    const float x = A::to_f32(a.conv_out[(kh2 ? key_dim : 0) + kh * 128 + v]);
+    const int d = tid & 127, isk = tid >> 7;
+    const float x = A::to_f32(a.conv_out[(isk ? key_dim : 0) + kh * 128 + d]);
     const float ss = wave_total(x * x);
     if ((tid & 63) == 0) nrm[tid >> 6] = ss;
     __syncthreads();
-    const float inv = __builtin_amdgcn_rsqf(nrm[2 * kh2] + nrm[2 * kh2 + 1] + 1e-6f);
-    if (kh2) ks[v] = x * inv; else qs[v] = x * inv * 0.08838834764831845f;
+    const float inv = __builtin_amdgcn_rsqf(nrm[2 * isk] + nrm[2 * isk + 1] + 1e-6f);
+    if (isk) ks[d] = x * inv; else qs[d] = x * inv * 0.08838834764831845f;
   }
   __syncthreads();
   const float decay = a.g_beta[h], beta = a.g_beta[a.nv + h];
   float kv = 0.f;
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
+  for (int i = 0; i < 16; ++i) {
     s[i] *= decay;
-    kv = __builtin_fmaf(s[i], ks[kh2 * 64 + i], kv);
+    kv = __builtin_fmaf(s[i], ks[ksl * 16 + i], kv);
   }
-  part[kh2][v] = kv;
+  part[ksl][vl] = kv;
   __syncthreads();
+  float kvm = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) kvm += part[q][vl];
   const float vv = A::to_f32(a.conv_out[2 * key_dim + h * 128 + v]);
-  const float delta = (vv - (part[0][v] + part[1][v])) * beta;
+  const float delta = (vv - kvm) * beta;
   __syncthreads();
   float o = 0.f;
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    s[i] = __builtin_fmaf(ks[kh2 * 64 + i], delta, s[i]);
-    o = __builtin_fmaf(s[i], qs[kh2 * 64 + i], o);
+  for (int i = 0; i < 16; ++i) {
+    s[i] = __builtin_fmaf(ks[ksl * 16 + i], delta, s[i]);
+    o = __builtin_fmaf(s[i], qs[ksl * 16 + i], o);
     S[i * 128] = s[i];
   }
-  part[kh2][v] = o;
+  part[ksl][vl] = o;
   __syncthreads();
-  if (kh2 == 0) {
-    // Qwen3_5RMSNormGated on the head's 128 outputs (HF rounds the core output to the activation dtype first, normalises in fp32,
-    // multiplies by the weight in the activation dtype, then by silu(z) in fp32)
-    const float of = A::to_f32(A::from_f32(part[0][v] + part[1][v]));
-    const float ss = wave_total(of * of);
-    if ((tid & 63) == 0) nrm[tid >> 6] = ss;
+  float* raw = a.scratch + (int64_t)h * 128;
+  unsigned* ticket = (unsigned*)(a.scratch + (int64_t)a.nv * 128) + h;
+  if (tid < 32) {
+    float of = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) of += part[q][tid];
+    __hip_atomic_store(raw + c4 * 32 + tid, of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
   }
   __syncthreads();
-  if (kh2 == 0) {
-    const float of = A::to_f32(A::from_f32(part[0][v] + part[1][v]));
-    const float n = A::to_f32(A::from_f32(of * __builtin_amdgcn_rsqf((nrm[0] + nrm[1]) / 128.f + a.eps)));
-    const float wn = A::to_f32(A::from_f32(A::to_f32(a.norm_w[v]) * n));
-    const float zf = A::to_f32(a.z[h * 128 + v]);
-    a.out[h * 128 + v] = A::from_f32(wn * (zf * sigmoidf_(zf)));
+  if (tid == 0) {
+    // The raw outputs went out as write-through (agent-scope) stores of this wave and come back as agent-scope loads: once they have
+    // completed (vmcnt) the ticket may follow -- no release fence (it would write back the whole L2, the state stores of every
+    // workgroup included: the first four-workgroup build was SLOWER than one workgroup per head, 7.8 vs 5.9 us) and no acquire.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
+  if (!last || tid >= 128) return;
+  // Qwen3_5RMSNormGated on the head's 128 outputs (HF rounds the core output to the activation dtype first, normalises in fp32,
+  // multiplies by the weight in the activation dtype, then by silu(z) in fp32)
+  const float of = A::to_f32(A::from_f32(__hip_atomic_load(raw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  const float ss = wave_total(of * of);
+  if ((tid & 63) == 0) nrm[tid >> 6] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (only waves 0 and 1 are here)
+  const float n = A::to_f32(A::from_f32(of * __builtin_amdgcn_rsqf((nrm[0] + nrm[1]) / 128.f + a.eps)));
+  const float wn = A::to_f32(A::from_f32(A::to_f32(a.norm_w[tid]) * n));
+  const float zf = A::to_f32(a.z[h * 128 + tid]);
+  a.out[h * 128 + tid] = A::from_f32(wn * (zf * sigmoidf_(zf)));
 }
 
 struct AttnGatedArgs {
@@ -212,14 +251,33 @@ __global__ __launch_bounds__(256) void attn_gated_decode_kernel(const AttnGatedA
     a.vcache[((int64_t)kvh * a.T_max + pos) * HD + tid] = vnew;
   }
   __syncthreads();
-  // scores of the cached positions: a wave per position, four dimensions per lane
+  // scores of the cached positions: sixteen positions per wave and step, FOUR lanes per position (64 dimensions = eight 16-byte loads
+  // each), the four partial dots combined on the DPP path (first build: a wave per position and six ds_bpermute round trips per score,
+  // 25 us per launch at ~200 positions)
   const unsigned short* kc = a.kcache + (int64_t)kvh * a.T_max * HD;
-  const float q4[4] = {qv[4 * lane], qv[4 * lane + 1], qv[4 * lane + 2], qv[4 * lane + 3]};
-  for (int p = wave; p < pos; p += 4) {
-    const u32x2 kw = *(const u32x2*)(kc + (int64_t)p * HD + 4 * lane);
-    float d = q4[0] * A::to_f32(kw[0] & 0xffffu) + q4[1] * A::to_f32(kw[0] >> 16) + q4[2] * A::to_f32(kw[1] & 0xffffu) + q4[3] * A::to_f32(kw[1] >> 16);
-    d = wave_total(d);
-    if (lane == 0) sc[p] = d;
+  {
+    const int sub = lane & 3, pg = lane >> 2;
+    float qd[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) qd[i] = qv[sub * 64 + i];
+    for (int base = wave * 16; base < pos; base += 64) {
+      const int p = base + pg;
+      const int pc = p < pos ? p : 0;                                       // (clamped: the load count stays static)
+      u32x4 kw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kw[j] = *(const u32x4*)(kc + (int64_t)pc * HD + sub * 64 + 8 * j);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d = __builtin_fmaf(qd[8 * j + 2 * e], A::to_f32(kw[j][e] & 0xffffu), d);
+          d = __builtin_fmaf(qd[8 * j + 2 * e + 1], A::to_f32(kw[j][e] >> 16), d);
+        }
+      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+      if (sub == 0 && p < pos) sc[p] = d;
+    }
   }
   {   // the new position from registers / LDS (whoever appends may not have written it yet)
     const float d = block_sum(qv[tid] * kn[tid], 0);
@@ -241,20 +299,40 @@ __global__ __launch_bounds__(256) void attn_gated_decode_kernel(const AttnGatedA
     l += e;
   }
   l = block_sum(l, 0);
-  // P V: thread d accumulates dimension d over the positions, eight cache rows in flight
-  const unsigned short* vc = a.vcache + (int64_t)kvh * a.T_max * HD + tid;
-  float acc = 0.f;
-  int p = 0;
-  for (; p + 8 <= pos; p += 8) {
-    unsigned short vr[8];
+  // P V: wave w takes the positions w, w + 4, ...; a lane owns four dimensions (one coalesced 512-byte row per wave and load, eight rows
+  // in flight); the four waves' partial outputs meet in LDS
+  const unsigned short* vc = a.vcache + (int64_t)kvh * a.T_max * HD + 4 * lane;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p0 = wave; p0 < pos; p0 += 32) {
+    u32x2 vr[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vr[j] = vc[(int64_t)(p + j) * HD];
+    for (int j = 0; j < 8; ++j) {
+      const int p = p0 + 4 * j;
+      vr[j] = *(const u32x2*)(vc + (int64_t)(p < pos ? p : 0) * HD);
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(sc[p + j], A::to_f32(vr[j]), acc);
+    for (int j = 0; j < 8; ++j) {
+      const int p = p0 + 4 * j;
+      const float w = p < pos ? sc[p] : 0.f;
+      acc[0] = __builtin_fmaf(w, A::to_f32(vr[j][0] & 0xffffu), acc[0]);
+      acc[1] = __builtin_fmaf(w, A::to_f32(vr[j][0] >> 16), acc[1]);
+      acc[2] = __builtin_fmaf(w, A::to_f32(vr[j][1] & 0xffffu), acc[2]);
+      acc[3] = __builtin_fmaf(w, A::to_f32(vr[j][1] >> 16), acc[3]);
+    }
   }
-  for (; p < pos; ++p) acc = __builtin_fmaf(sc[p], A::to_f32(vc[(int64_t)p * HD]), acc);
-  acc = __builtin_fmaf(sc[pos], A::to_f32(vnew), acc);
-  const float o = A::to_f32(A::from_f32(acc / l));
+  __syncthreads();                                                          // (qv / kn are free now: the partial outputs take their place)
+  float* pa = (wave & 1) ? kn : qv;                                          // waves 0 / 1 first, then 2 / 3 add
+  if (wave < 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pa[4 * lane + e] = acc[e];
+  }
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pa[4 * lane + e] += acc[e];
+  }
+  __syncthreads();
+  const float o = A::to_f32(A::from_f32((qv[tid] + kn[tid] + sc[pos] * A::to_f32(vnew)) / l));
   a.out[head * HD + tid] = A::from_f32(o * sigmoidf_(gate));
 }
 
@@ -277,16 +355,19 @@ extern "C" int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, 
   return check_launch("paro_gdn_prep");
 }
 
+extern "C" int64_t paro_gdn_workspace_bytes(int n_v_heads) { return n_v_heads < 1 ? -1 : (int64_t)n_v_heads * (128 + 1) * 4; }
+
 extern "C" int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,
-                             int n_k_heads, int n_v_heads, int act_dtype, void* stream) {
+                             int n_k_heads, int n_v_heads, int act_dtype, void* workspace, void* stream) {
   using namespace paro;
-  if (!conv_out || !z || !g_beta || !state || !norm_w || !out) return fail(PARO_ERR_INVALID, "null pointer");
+  if (!conv_out || !z || !g_beta || !state || !norm_w || !out || !workspace) return fail(PARO_ERR_INVALID, "null pointer");
   if (n_k_heads < 1 || n_v_heads < n_k_heads || n_v_heads % n_k_heads) return fail(PARO_ERR_INVALID, "value heads must be a multiple of key heads");
   GdnStepArgs a;
   a.conv_out = (const unsigned short*)conv_out; a.z = (const unsigned short*)z; a.g_beta = g_beta; a.state = state;
   a.norm_w = (const unsigned short*)norm_w; a.out = (unsigned short*)out; a.eps = eps; a.nk = n_k_heads; a.nv = n_v_heads;
-  if (act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL(gdn_step_kernel<f16>, dim3((unsigned)n_v_heads), dim3(256), 0, (hipStream_t)stream, a);
-  else if (act_dtype == PARO_DTYPE_BF16) hipLaunchKernelGGL(gdn_step_kernel<bf16>, dim3((unsigned)n_v_heads), dim3(256), 0, (hipStream_t)stream, a);
+  a.scratch = (float*)workspace;
+  if (act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL(gdn_step_kernel<f16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
+  else if (act_dtype == PARO_DTYPE_BF16) hipLaunchKernelGGL(gdn_step_kernel<bf16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
   else return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
   return check_launch("paro_gdn_step");
 }

@@ -215,6 +215,7 @@ class ParoQwen35DecoderLM:
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         self.lm_ws = ops.lm_head_workspace(dev, c.vocab)
+        self.gdn_ws = torch.zeros(int(nat.load().paro_gdn_workspace_bytes(c.lin_v_heads)), dtype=torch.uint8, device=dev)   # zero-filled once
         self.fused_tail = c.hidden % 512 == 0 and c.hidden <= 4096
         self.bytes_per_token = sum(pk.nbytes() for L in self.layers for pk in (L.mix_in, L.mix_out, L.gate_up, L.down))
 
@@ -241,7 +242,8 @@ class ParoQwen35DecoderLM:
                                                 L.A_log.data_ptr(), L.dt_bias.data_ptr(), self.conv_out.data_ptr(), self.g_beta.data_ptr(), c.hidden,
                                                 self.conv_dim, c.lin_v_heads, dtc, st))
                     nat.check(lib.paro_gdn_step(self.conv_out.data_ptr(), self.qkvz.data_ptr() + 2 * self.conv_dim, self.g_beta.data_ptr(), L.state.data_ptr(),
-                                                L.gdn_norm.data_ptr(), c.rms_eps, mix.data_ptr(), c.lin_k_heads, c.lin_v_heads, dtc, st))
+                                                L.gdn_norm.data_ptr(), c.rms_eps, mix.data_ptr(), c.lin_k_heads, c.lin_v_heads, dtc,
+                                                self.gdn_ws.data_ptr(), st))
                 ops.w4a16_gemv_fused(mix, L.mix_out, 0, residual=h, out=h2)                     # h2 = h + mixer(x)
                 ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu)
                 ops.w4a16_gemv_fused(self.gu, L.down, S, residual=h2, out=h)                    # h = h2 + mlp(...)
