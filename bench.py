@@ -49,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 ROUTE_REACH = {
     "fused": "every RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply call (the reference's per-linear operator API)",
     "parts": "a caller that owns the decoder loop (paroquant_amd.decoder.ParoDecoderLM; INTEGRATION.md 5b)",
-    "engine": "a caller that hands over a whole chain of linears (paroquant_amd.engine.DecodeEngine; the HF plug-in installs it per MLP block)",
+    "engine": "a caller that hands over a whole chain of linears (paroquant_amd.engine.DecodeEngine, paro_engine_run)",
 }
 
 MODELS = {
