@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 13
+#define PARO_ABI_VERSION 14
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -255,6 +255,12 @@ typedef struct paro_fusion {
   const float* parts_in;       /* v12: fp32 [K][PARO_MAX_PARTIALS] left by the producer of x's missing term, or NULL */
   void* x_out;                 /* v12: act_dtype [K], the completed x (with parts_in), or NULL */
   int32_t parts_out_n;         /* v12: the K-split of the parts_out launch */
+  int32_t attn_head_dim;       /* v14: head_dim of the attention that produced attn_in (64, 128 or 256; divides K) */
+  const float* attn_in;        /* v14: x is the attention output handed over UN-MERGED by paro_attn_decode_split: fp32
+                                  [K][4] + [K / head_dim][8] (paro_attn_parts_floats), 16-byte aligned; `x` is ignored (may be NULL).  This launch
+                                  completes out = sum_c 2^(m_c - M) o_c / sum_c 2^(m_c - M) l_c per element while it seeds its rotation --
+                                  the same bits as paro_attn_finish followed by the plain launch.  One row, no prologue, no residual;
+                                  parts_out allowed (o_proj of a decoder layer: attention slots in, K-split partial sums out). */
 } paro_fusion_t;
 int paro_gemv_parts_count(const paro_linear_t* L);
 int paro_parts_finish(const void* x, const float* parts, int64_t K, void* out, int act_dtype, void* stream);
@@ -345,6 +351,25 @@ int paro_attn_decode_parts(const float* qkv_parts, int64_t norm_dim, float norm_
                            const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w, float eps,
                            float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* v14: split attention -- the merge over position chunks is left to the CONSUMER of the attention output.  The launch works in chunks of
+ * 128 positions, groups the active chunks into at most FOUR slots and stores per slot the un-normalised triple
+ *   attn_parts  fp32, paro_attn_parts_floats(n_heads, head_dim) elements, 16-byte aligned, zero-filled once by the caller:
+ *               [n_heads * head_dim][4]  o_c[d] = sum_{p in slot c} 2^((s_p - m_c) log2 e) v_p[d]
+ *               [n_heads][8]             m_c (slots 0..3), l_c (slots 0..3); a slot nobody filled: (-3e38, 0)
+ * (one chunk per slot up to 512 positions: no ticket, no fence; beyond that the chunks of a slot meet at a per-slot ticket).  The output is
+ *   out[j][d] = round(sum_c 2^((m_c - M) log2 e) o_c[d] / sum_c 2^((m_c - M) log2 e) l_c),  M = max_c m_c
+ * completed either by the next fused GEMV (paro_fusion_t.attn_in: o_proj reads the slots as its x) or by paro_attn_finish; both compute
+ * the same expression operation for operation (same bits).  Exactly one of qkv / qkv_parts (the two input forms above).  Why: at
+ * short contexts the in-launch merge is ~2.5 us of an ~8 us launch and one workgroup per KV head ingests the whole cache
+ * (profiles/r04_attn_stage_ablation.jsonl). */
+int64_t paro_attn_parts_floats(int n_heads, int head_dim);
+int paro_attn_decode_split(const void* qkv, const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache,
+                           float* attn_parts, const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w,
+                           float eps, float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int paro_attn_finish(const float* attn_parts, int n_heads, int head_dim, void* out, int act_dtype, void* stream);
+
 
 /* Qwen3.5 in the decode harness (v13; BASELINE configs 3 and 5): the hybrid decoder's token mixers at batch 1, following transformers'
  * models/qwen3_5 (the reference decodes any HF architecture through generate(), transformers/generator.py:37-67).

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 13
+PARO_ABI_VERSION = 14
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -43,6 +43,9 @@ EXPORTS = (
     "paro_attn_decode_workspace_bytes",
     "paro_attn_decode",
     "paro_attn_decode_parts",
+    "paro_attn_parts_floats",
+    "paro_attn_decode_split",
+    "paro_attn_finish",
     "paro_lm_head_workspace_bytes",
     "paro_lm_head",
     "paro_argmax_advance",
@@ -104,7 +107,8 @@ class ParoFusion(Structure):
 
     _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p),
                 ("ar_peers", c_void_p), ("ar_own", c_void_p), ("ar_state", c_void_p), ("ar_world", c_int32), ("ar_rank", c_int32), ("ar_max_elems", c_int64),
-                ("parts_out", c_void_p), ("parts_in", c_void_p), ("x_out", c_void_p), ("parts_out_n", c_int32)]
+                ("parts_out", c_void_p), ("parts_in", c_void_p), ("x_out", c_void_p), ("parts_out_n", c_int32), ("attn_head_dim", c_int32),
+                ("attn_in", c_void_p)]
 
 
 class ParoExperts(Structure):
@@ -200,6 +204,13 @@ def load() -> ctypes.CDLL:
     lib.paro_attn_decode_parts.restype = c_int
     lib.paro_attn_decode_parts.argtypes = [c_void_p, c_int64, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]
+    lib.paro_attn_parts_floats.restype = c_int64
+    lib.paro_attn_parts_floats.argtypes = [c_int, c_int]
+    lib.paro_attn_decode_split.restype = c_int
+    lib.paro_attn_decode_split.argtypes = [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           ctypes.c_float, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]
+    lib.paro_attn_finish.restype = c_int
+    lib.paro_attn_finish.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
     lib.paro_lm_head_workspace_bytes.restype = c_int64
     lib.paro_lm_head_workspace_bytes.argtypes = [c_int64]
     lib.paro_lm_head.restype = c_int

@@ -14,6 +14,14 @@
 // release -> ticket -> acquire; no spinning, so no dependence on dispatch order) merges them, reading eight chunks'
 // triples at a time.  The position comes from DEVICE memory, so one captured graph replays for every token: the grid
 // always covers max_positions, chunks beyond `pos` exit at once.
+//
+// SPLIT builds (paro_attn_decode_split): the merge is NOT done here.  Chunks are 128 positions; the active chunks are grouped into at
+// most FOUR slots (one chunk per slot up to 512 positions -- no ticket, no fence, the workgroup stores its (max, sum, un-normalised
+// output) triple and is done; beyond that the chunks of a slot meet at a per-slot ticket and the last one stores the slot's triple)
+// and the launch that consumes the attention output -- o_proj, `paro_fusion_t.attn_in` -- completes
+//     out[j][d] = sum_c 2^(m_c - M) o_c[d] / sum_c 2^(m_c - M) l_c
+// while it seeds its rotation: each element is read by the few workgroups whose K-slice holds it.  At short contexts that
+// removes the whole in-launch merge (~2.5 us of an ~8 us launch) and puts the chunks of a head on different CUs.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -25,6 +33,7 @@ namespace paro {
 // positions per workgroup: 256 for short caches (one chunk = no merge up to 256 positions), 128 above that (a CU
 // ingests ~13 B / clock: smaller chunks spread a context over more CUs; each extra chunk costs the in-launch merge)
 constexpr int attn_chunk(int max_positions) { return max_positions <= 512 ? 256 : 128; }
+constexpr int kAttnWsHeader = 2048;   // bytes of arrival counters in front of the partial results
 
 struct AttnArgs {
   const unsigned short* qkv;   // [(Hq + 2 Hkv) * hd]: q heads, k heads, v heads of this token
@@ -41,7 +50,9 @@ struct AttnArgs {
   const unsigned short* qnw;   // [hd] q-norm weight or null
   const unsigned short* knw;   // [hd] k-norm weight or null
   float* part;                 // workspace: [Hkv][chunks][n_rep][hd + 2] partial results
-  unsigned* ticket;            // workspace: [Hkv] arrival counters (zero between launches)
+  unsigned* ticket;            // workspace: [Hkv] arrival counters (zero between launches); SPLIT: [64 + 4 Hkv + slot]
+  float* split_o;              // SPLIT: [Hq * hd][4] un-normalised outputs per slot
+  float* split_ml;             // SPLIT: [Hq][8]: the slots' maxima [0..3] and sums [4..7]; a slot nobody filled holds (-3e38, 0)
   float eps, scale;
   int Hq, Hkv, hd, T_max, chunks;
   int dbg;                     // PARO_ATTN_DBG: stop after phase N (timing ablation; wrong results)
@@ -83,7 +94,7 @@ __device__ __forceinline__ float wave_sum(float v) {   // the same value in ever
 // scores on the matrix cores (the new key patched into the K fragments) -> soft-max of each wave's 64 positions in
 // registers (DPP row reductions, no LDS, no barrier) -> P V of the wave's own rows -> ONE barrier -> the four waves'
 // (max, sum, partial output) triples merged like chunks are.
-template <typename AT, int HD, int NREP, int CH, bool PARTS>
+template <typename AT, int HD, int NREP, int CH, bool PARTS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   constexpr int kChunk = CH;                   // positions of a workgroup
   constexpr int WP = CH / 4;                   // positions of a wave (64 / 32)
@@ -361,6 +372,97 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
     return num;
   };
+  if constexpr (SPLIT) {
+    const int per = (n_act + 3) >> 2;                   // chunks per slot
+    const int slot = s / per;
+    const int n_slots = (n_act + per - 1) / per;        // slots in use
+    // chunk 0 (always active) marks the slots nobody fills: (max, sum) = (-3e38, 0) -- the consumer skips their outputs
+    if (s == 0 && tid < n_rep * 4) {
+      const int j = tid >> 2, q = tid & 3;
+      if (q >= n_slots) {
+        a.split_ml[((int64_t)h * n_rep + j) * 8 + q] = -3.0e38f;
+        a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + q] = 0.f;
+      }
+    }
+    if (per == 1) {
+      // one chunk per slot (up to 4 x 128 positions): store the triple, done -- no ticket, no fence
+      for (int e = tid; e < n_rep * hd; e += 256) {
+        const int j = e / hd, d = e % hd;
+        float M, den;
+        const float num = chunk_value(j, d, M, den);
+        a.split_o[(((int64_t)h * n_rep + j) * hd + d) * 4 + slot] = num;
+        if (d == 0) {
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + slot] = M;
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + slot] = den;
+        }
+      }
+      return;
+    }
+    // several chunks per slot: publish, the slot's last arriver merges its chunks into the slot's triple
+    const int c_first = slot * per, c_count = min(per, n_act - c_first);
+    float* mine = a.part + (((int64_t)h * a.chunks + s) * n_rep) * (hd + 2);
+    for (int e = tid; e < n_rep * hd; e += 256) {
+      const int j = e / hd, d = e % hd;
+      float M, den;
+      mine[j * (hd + 2) + d] = chunk_value(j, d, M, den);
+      if (d == 0) {
+        mine[j * (hd + 2) + hd] = M;
+        mine[j * (hd + 2) + hd + 1] = den;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned* tk = a.ticket + 64 + h * 4 + slot;
+      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = (t == (unsigned)(c_count - 1)) ? 1u : 0u;
+      if (last_flag) {
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    const float* base = a.part + ((int64_t)h * a.chunks + c_first) * n_rep * (hd + 2);
+    for (int e = tid; e < n_rep * hd; e += 256) {
+      const int j = e / hd, d = e % hd;
+      const float* pj = base + (int64_t)j * (hd + 2);
+      const int64_t cstride = (int64_t)n_rep * (hd + 2);
+      float M = -3.0e38f;
+      for (int c0 = 0; c0 < c_count; c0 += 8) {
+        float mv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, c_count - 1) * cstride + hd];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) M = fmaxf(M, mv[q]);
+      }
+      float num = 0.f, den = 0.f;
+      for (int c0 = 0; c0 < c_count; c0 += 8) {
+        float mv[8], lv[8], ov[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float* pc = pj + (int64_t)min(c0 + q, c_count - 1) * cstride;
+          mv[q] = pc[hd];
+          lv[q] = pc[hd + 1];
+          ov[q] = pc[d];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float w = (c0 + q < c_count) ? __builtin_amdgcn_exp2f((mv[q] - M) * kLog2e) : 0.f;
+          num = __builtin_fmaf(w, ov[q], num);
+          den = __builtin_fmaf(w, lv[q], den);
+        }
+      }
+      a.split_o[(((int64_t)h * n_rep + j) * hd + d) * 4 + slot] = num;
+      if (d == 0) {
+        a.split_ml[((int64_t)h * n_rep + j) * 8 + slot] = M;
+        a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + slot] = den;
+      }
+    }
+    return;
+  }
   if (n_act == 1) {
     // the only chunk: normalise and write the output
     for (int e = tid; e < n_rep * hd; e += 256) {
@@ -432,21 +534,53 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   }
 }
 
+// The consumer's completion of a SPLIT launch, as its own launch (tests; callers whose next launch is not a fused GEMV): the same
+// expression, operation for operation, as the attn_in prologue of gemv_kernel (attn_merge, common.hpp).
+template <typename AT>
+__global__ __launch_bounds__(256) void attn_finish_kernel(const f32x4* o, const f32x4* ml, unsigned short* out, int n, int hd_shift) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int j = e >> hd_shift;
+  out[e] = Act<AT>::from_f32(attn_merge(o[e], ml[2 * j], ml[2 * j + 1]));
+}
+
 }  // namespace paro
+
+extern "C" int64_t paro_attn_parts_floats(int n_heads, int head_dim) {
+  if (n_heads < 1 || head_dim < 2) return -1;
+  return (int64_t)n_heads * head_dim * 4 + (int64_t)n_heads * 8;
+}
+
+extern "C" int paro_attn_finish(const float* attn_parts, int n_heads, int head_dim, void* out, int act_dtype, void* stream) {
+  using namespace paro;
+  if (!attn_parts || !out) return fail(PARO_ERR_INVALID, "null pointer");
+  if (n_heads < 1 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return fail(PARO_ERR_INVALID, "head_dim must be 64, 128 or 256");
+  if (act_dtype != PARO_DTYPE_F16 && act_dtype != PARO_DTYPE_BF16) return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  const int n = n_heads * head_dim, shift = head_dim == 64 ? 6 : (head_dim == 128 ? 7 : 8);
+  const f32x4* o = (const f32x4*)attn_parts;
+  const f32x4* ml = (const f32x4*)(attn_parts + (int64_t)n * 4);
+  if (act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL(attn_finish_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, ml, (unsigned short*)out, n, shift);
+  else hipLaunchKernelGGL(attn_finish_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, ml, (unsigned short*)out, n, shift);
+  return check_launch("paro_attn_finish");
+}
 
 extern "C" int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads, int head_dim, int max_positions) {
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 2 || max_positions < 1) return -1;
   const int64_t n_rep = n_heads / n_kv_heads, chunks = (max_positions + paro::attn_chunk(max_positions) - 1) / paro::attn_chunk(max_positions);
-  return 256 + (int64_t)n_kv_heads * chunks * n_rep * (head_dim + 2) * 4;   // tickets (zero-filled by the caller once) + partials
+  // tickets (zero-filled by the caller once: [0, 64) per KV head, [64, 320) per (KV head, slot) of the split launch) + partials, sized for
+  // 128-position chunks (the split launch always uses them)
+  const int64_t chunks128 = (max_positions + 127) / 128;
+  return paro::kAttnWsHeader + (int64_t)n_kv_heads * (chunks > chunks128 ? chunks : chunks128) * n_rep * (head_dim + 2) * 4;
 }
 
 namespace paro {
-static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache, void* out,
+static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache, void* out, float* split_out,
                             const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w, float eps, float scale,
                             int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
                             int64_t workspace_bytes, void* stream) {
   const bool parts = qkv_parts != nullptr;
-  if ((!qkv && !parts) || !kcache || !vcache || !out || !pos || !rope) return fail(PARO_ERR_INVALID, "null pointer");
+  const bool split = split_out != nullptr;
+  if ((!qkv && !parts) || !kcache || !vcache || (!out && !split) || !pos || !rope) return fail(PARO_ERR_INVALID, "null pointer");
   if (parts && norm_dim < 0) return fail(PARO_ERR_INVALID, "norm_dim must be >= 0");
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0) return fail(PARO_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
   if (n_kv_heads > 64) return fail(PARO_ERR_UNSUPPORTED, "at most 64 KV heads");
@@ -456,7 +590,7 @@ static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t nor
   const int64_t need = paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions);
   if (max_positions < 8 || max_positions % 8 != 0 || max_positions > 65535 * 128)
     return fail(PARO_ERR_INVALID, "max_positions must be a multiple of 8 in 8..%d (got %d)", 65535 * 128, max_positions);
-  const int kChunk = attn_chunk(max_positions);
+  const int kChunk = split ? 128 : attn_chunk(max_positions);
   if (!workspace || workspace_bytes < need)
     return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;
@@ -472,7 +606,9 @@ static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t nor
   a.qnw = (const unsigned short*)q_norm_w;
   a.knw = (const unsigned short*)k_norm_w;
   a.ticket = (unsigned*)workspace;
-  a.part = (float*)((char*)workspace + 256);
+  a.split_o = split_out;
+  a.split_ml = split ? split_out + (int64_t)n_heads * head_dim * 4 : nullptr;
+  a.part = (float*)((char*)workspace + kAttnWsHeader);
   a.eps = eps;
   a.scale = scale;
   a.Hq = n_heads;
@@ -490,7 +626,10 @@ static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t nor
   const int nr = n_rep <= 1 ? 1 : (n_rep <= 2 ? 2 : (n_rep <= 4 ? 4 : 8));
 #define PARO_ATTN_LAUNCH(T, HD, NR) \
   do { \
-    if (parts) { \
+    if (split) { \
+      if (parts) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, true, true>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, false, true>), grid, dim3(256), 0, st, a); \
+    } else if (parts) { \
       if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256, true>), grid, dim3(256), 0, st, a); \
       else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, true>), grid, dim3(256), 0, st, a); \
     } else if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256, false>), grid, dim3(256), 0, st, a); \
@@ -518,7 +657,7 @@ extern "C" int paro_attn_decode(const void* qkv, void* kcache, void* vcache, voi
                                 const void* q_norm_w, const void* k_norm_w, float eps, float scale, int n_heads,
                                 int n_kv_heads, int head_dim, int max_positions, int act_dtype, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-  return paro::attn_decode_impl(qkv, nullptr, 0, 0.f, kcache, vcache, out, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads, n_kv_heads, head_dim,
+  return paro::attn_decode_impl(qkv, nullptr, 0, 0.f, kcache, vcache, out, nullptr, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads, n_kv_heads, head_dim,
                                 max_positions, act_dtype, workspace, workspace_bytes, stream);
 }
 
@@ -527,6 +666,16 @@ extern "C" int paro_attn_decode_parts(const float* qkv_parts, int64_t norm_dim, 
                                       float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
                                       void* workspace, int64_t workspace_bytes, void* stream) {
   if (!qkv_parts) return paro::fail(PARO_ERR_INVALID, "null pointer");
-  return paro::attn_decode_impl(nullptr, qkv_parts, norm_dim, norm_eps, kcache, vcache, out, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads,
+  return paro::attn_decode_impl(nullptr, qkv_parts, norm_dim, norm_eps, kcache, vcache, out, nullptr, pos, rope, q_norm_w, k_norm_w, eps, scale, n_heads,
                                 n_kv_heads, head_dim, max_positions, act_dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int paro_attn_decode_split(const void* qkv, const float* qkv_parts, int64_t norm_dim, float norm_eps, void* kcache, void* vcache,
+                                      float* attn_parts, const int32_t* pos, const float* rope, const void* q_norm_w, const void* k_norm_w,
+                                      float eps, float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!attn_parts) return paro::fail(PARO_ERR_INVALID, "null pointer");
+  if ((qkv == nullptr) == (qkv_parts == nullptr)) return paro::fail(PARO_ERR_INVALID, "exactly one of qkv / qkv_parts");
+  return paro::attn_decode_impl(qkv, qkv_parts, norm_dim, norm_eps, kcache, vcache, nullptr, attn_parts, pos, rope, q_norm_w, k_norm_w, eps, scale,
+                                n_heads, n_kv_heads, head_dim, max_positions, act_dtype, workspace, workspace_bytes, stream);
 }

@@ -279,4 +279,19 @@ __device__ __forceinline__ void rotate_span_regs(float* xr, const unsigned (&ij)
   for (int r = 0; r < KROT; ++r) rotate_stage<VW, NCH>(xr, ij[r], th[r], sub);
 }
 
+// The merge of a split attention launch's four slots (attn.hip: paro_attn_decode_split): un-normalised outputs o, maxima m, sums l.
+// ONE definition for the fused GEMV's attn_in prologue (gemv_impl.hpp) and paro_attn_finish (attn.hip): both give the same bits.
+__device__ __forceinline__ float attn_merge(const f32x4& o, const f32x4& m, const f32x4& l) {
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float M = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+  float num = 0.f, den = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float w = __builtin_amdgcn_exp2f((m[c] - M) * kLog2e);
+    den = __builtin_fmaf(w, l[c], den);
+    num = __builtin_fmaf(w, l[c] > 0.f ? o[c] : 0.f, num);     // a slot nobody filled may hold anything
+  }
+  return num * __builtin_amdgcn_rcpf(den);
+}
+
 }  // namespace paro

@@ -210,10 +210,21 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (rows < 0 || rows > 64) return fail(PARO_ERR_INVALID, "paro_w4a16_gemv handles 1..64 rows (got %lld)", (long long)rows);
   const bool pout = F && F->parts_out;   // deferred K-split reduction (v12): this launch leaves / receives fp32 partial sums
   const bool pin = F && F->parts_in;
-  if (!x || (!y && !pout)) return fail(PARO_ERR_INVALID, "null pointer");
+  const bool ain = F && F->attn_in;      // x = the slots of a split attention launch (v14)
+  if ((!x && !ain) || (!y && !pout)) return fail(PARO_ERR_INVALID, "null pointer");
   const bool ar = F && F->ar_peers && F->ar_world >= 1;
-  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar || pin;
-  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+  const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar || pin || ain;
+  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr};
+  int attn_shift = 0;
+  if (ain) {
+    if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "attn_in is a batch-1 decode path (got %lld rows)", (long long)rows);
+    if (E || ar || pin) return fail(PARO_ERR_UNSUPPORTED, "attn_in cannot be combined with expert slots, the all-reduce epilogue or parts_in");
+    if (F->prologue != PARO_PROLOGUE_NONE || F->residual) return fail(PARO_ERR_UNSUPPORTED, "attn_in feeds the plain linear (no prologue, no residual: leave partial sums or add it downstream)");
+    if (L->krot > 8 || mode == 1 || mode == 2) return fail(PARO_ERR_UNSUPPORTED, "attn_in needs the in-kernel rotation (krot <= 8, mode 0)");
+    attn_shift = F->attn_head_dim == 64 ? 6 : (F->attn_head_dim == 128 ? 7 : (F->attn_head_dim == 256 ? 8 : 0));
+    if (!attn_shift || L->K % F->attn_head_dim != 0) return fail(PARO_ERR_INVALID, "attn_head_dim must be 64, 128 or 256 and divide K (got %d, K = %lld)", F->attn_head_dim, (long long)L->K);
+    if (((uintptr_t)F->attn_in & 15) != 0) return fail(PARO_ERR_INVALID, "attn_in must be 16-byte aligned");
+  }
   if (pout || pin) {
     if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "partial sums (parts_out / parts_in) are a batch-1 decode path (got %lld rows)", (long long)rows);
     if (E || ar) return fail(PARO_ERR_UNSUPPORTED, "partial sums are not defined for expert slots or the all-reduce epilogue");
@@ -315,6 +326,11 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.parts_out = pout ? 1 : 0;
   a.parts_in = pin ? F->parts_in : nullptr;
   a.x_out = pin ? (unsigned short*)F->x_out : nullptr;
+  a.attn_in = ain ? 1 : 0;
+  if (ain) {   // the same 16-byte argument pair: the slots' outputs [K][4], the slots' (max, sum) [K / head_dim][8] | log2(head_dim)
+    a.parts_in = F->attn_in;
+    a.x_out = (unsigned short*)((uintptr_t)(F->attn_in + (int64_t)L->K * 4) | (uintptr_t)attn_shift);
+  }
   const long long xstride = (fused && F->x_stride != 0) ? F->x_stride : (int64_t)L->K * ((fused && F->prologue >= PARO_PROLOGUE_SILU_MUL) ? 2 : 1);
   a.expert_idx = E ? E->expert_idx : nullptr;
   a.wq_estride = E ? E->wq_stride_bytes : 0;

@@ -93,6 +93,7 @@ struct GemvArgs {
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
   int parts_out;                 // deferred K-split reduction (paro_fusion_t, v12): this launch leaves partial sums
+  int attn_in;                   // x is a split attention launch's slots (paro_fusion_t.attn_in, v14): parts_in / x_out carry its two pointers
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
@@ -137,6 +138,9 @@ constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 
 //   `n` <= 4 fp32 partial sums [K][4] instead of reducing them in its launch, and this kernel finishes the sum while it seeds the
 //   rotation: x_k = round(base_k + ((p[n-1][k] + p[0][k]) + ... + p[n-2][k])) -- the order and the one rounding of the reducer
 //   below, so both routes give the same bits (the producer stores its splits in that order, four slots per channel, unused ones zero).  Column block 0 also stores the completed x (the decoder's residual stream).
+// FUSED | 16 (FUSED & 15 == 0, one row): x is the attention output, handed over UN-MERGED by a split attention launch
+//   (attn.hip, paro_attn_decode_split): per element four slots' un-normalised outputs [K][4] and per head the slots' maxima and sums
+//   [K / head_dim][8]; x_k = sum_c 2^(m_c - M) o_c[k] / sum_c 2^(m_c - M) l_c, one rounding, computed while seeding (attn_merge below).
 // QS: quantisation groups per 128-channel rotation span (1: group_size 128, 2: group_size 64 -- two (scale, zero)
 // words per tile and column, the tile's first two / last two MFMA k-steps accumulated separately).
 template <typename AT, int TPW, int MB, int WAVES, bool PREROT, int PD, int FUSED = 0, int QS = 1>
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int FMODE = FUSED & 3;          // 0 plain, 1 RMSNorm prologue and / or residual, 2 SiLU*mul prologue (+ residual)
   constexpr bool AREP = (FUSED & 4) != 0;   // + all-reduce epilogue (its own instantiations: the code costs the others ~5 % otherwise)
   constexpr bool PARTS_IN = (FUSED & 8) != 0;   // x = base + the producer's partial sums, completed while seeding (see above)
+  constexpr bool ATTN_IN = (FUSED & 16) != 0;    // x = the merge of a split attention launch's slots, completed while seeding
   static_assert(!PARTS_IN || ((FMODE == 0 || FMODE == 1) && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
+  static_assert(!ATTN_IN || (FMODE == 0 && MB == 1 && !AREP && !PREROT && !PARTS_IN), "attention slots feed the plain one-row kernel");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -183,13 +189,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   unsigned p_cb0_u, ent0, ent1;
   unsigned long long cnt_ptr;   // GemvArgs::counters (K-split epoch words), fetched with the same batch
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  u64x2 pin_ptrs = {0ull, 0ull};   // PARTS_IN: GemvArgs::parts_in, x_out
+  u64x2 pin_ptrs = {0ull, 0ull};   // PARTS_IN: GemvArgs::parts_in, x_out; ATTN_IN: the slots' outputs, the slots' (max, sum) | log2(head_dim)
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned m0_save;
     // (PARTS_IN: one more request in front of the batch below, whose wait covers it; its own statement so that the other
     // instantiations' prologue is byte for byte what it was)
-    if constexpr (PARTS_IN) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(pin_ptrs) : "s"(kp), "i"(offsetof(GemvArgs, parts_in)) : "memory");
+    if constexpr (PARTS_IN || ATTN_IN) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(pin_ptrs) : "s"(kp), "i"(offsetof(GemvArgs, parts_in)) : "memory");
     asm volatile(
         "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
         "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
@@ -322,7 +328,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   struct PBuf {
     unsigned xv[PREROT ? 1 : MB];
     unsigned xu[FMODE == 2 ? MB : 1];   // SiLU*mul prologue: the `up` pair of the same two channels
-    f32x4 xp[PARTS_IN ? 2 : 1];         // PARTS_IN: the producer's partial sums of the same two channels: [channel][slot], slots in summation order
+    f32x4 xp[(PARTS_IN || ATTN_IN) ? 2 : 1];   // PARTS_IN: the producer's partial sums of the same two channels: [channel][slot], slots in summation order; ATTN_IN: the slots' outputs
+    f32x4 am[ATTN_IN ? 2 : 1];          // ATTN_IN: the head's slot maxima, slot sums
     int g;                              // PARTS_IN: the group (where the completed x is stored)
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
@@ -359,6 +366,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         b.xp[0] = pp[0];
         b.xp[1] = pp[1];
       }
+      if constexpr (ATTN_IN) {
+        const unsigned e = (unsigned)(g * 128 + 2 * lane);
+        GP<f32x4> pp = (GP<f32x4>)pin_ptrs[0] + e;
+        b.xp[0] = pp[0];
+        b.xp[1] = pp[1];
+        GP<f32x4> ml = (GP<f32x4>)(pin_ptrs[1] & ~15ull) + 2u * (e >> (unsigned)(pin_ptrs[1] & 15ull));
+        b.am[0] = ml[0];
+        b.am[1] = ml[1];
+      }
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
       GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
 #pragma unroll
@@ -371,6 +387,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           GP<unsigned short> xr = x_p + ((unsigned)rr * (unsigned)h.xstride + (unsigned)(g * 128 + 2 * lane));
           b.xv[r] = *(GP<unsigned>)xr;
           if constexpr (FMODE == 2) b.xu[r] = *(GP<unsigned>)(xr + h.K);
+        } else if constexpr (ATTN_IN) {
+          b.xv[r] = 0u;
         } else {
           b.xv[r] = *(GP<unsigned>)(x_p + (unsigned)(rr * h.K + g * 128 + 2 * lane));
         }
@@ -504,6 +522,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int r = 0; r < MB; ++r) {
       const unsigned xv = r < h.rows ? b.xv[r] : 0u;
       float x0 = A::to_f32(xv & 0xffffu), x1 = A::to_f32(xv >> 16);
+      if constexpr (ATTN_IN) {
+        x0 = A::to_f32(A::from_f32(attn_merge(b.xp[0], b.am[0], b.am[1])));
+        x1 = A::to_f32(A::from_f32(attn_merge(b.xp[1], b.am[0], b.am[1])));
+      }
       if constexpr (PARTS_IN) {
         // no branch in here (a branch makes the compiler's vmcnt bookkeeping give up: the wait for these coefficients became a wait
         // for the unit's HBM tiles, +1.0 .. 1.6 us per launch): unused slots hold zeros, and only column block 0's buffer
@@ -1057,6 +1079,10 @@ int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) 
     }
     return fail(PARO_ERR_UNSUPPORTED, "the all-reduce epilogue is built for one row");
   }
+  if (a.attn_in) {   // x = the merge of a split attention launch's slots (FUSED | 16): one row, no prologue
+    if constexpr (MB == 1 && !PREROT) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 16>(a, waves, grid, st);
+    return fail(PARO_ERR_UNSUPPORTED, "attention slots as input are built for one row, in-kernel rotation");
+  }
   if (a.parts_in) {   // x = base + the producer's partial sums (FUSED | 8): one row, RMSNorm or no prologue
     if constexpr (MB == 1 && !PREROT) {
       if (a.prologue == PARO_PROLOGUE_NONE && !(a.hot.residual_lo | a.hot.residual_hi)) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 8>(a, waves, grid, st);
@@ -1100,7 +1126,7 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine || a.parts_in) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
+  if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine || a.parts_in || a.attn_in) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
 

@@ -333,6 +333,11 @@ class ParoDecoderLM:
             and os.environ.get("PARO_DEFERRED_QKV", "1") != "0"
         if self.deferred_qkv:
             self.parts_q = torch.zeros(qkv_w + 1, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
+        # ... and the attention's merge over position chunks (ABI v14): the chunks of a head run on different CUs and leave their slots'
+        # (max, sum, un-normalised output); o_proj completes the merge while it seeds its rotation.  PARO_SPLIT_ATTN=0: off
+        self.split_attn = self.deferred and c.head_dim in (64, 128) and os.environ.get("PARO_SPLIT_ATTN", "1") != "0"
+        if self.split_attn:
+            self.attn_parts = torch.zeros(ops.attn_parts_floats(self.nh, c.head_dim), dtype=torch.float32, device=dev)
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
@@ -402,8 +407,11 @@ class ParoDecoderLM:
                 cur, other = other, cur
             ops.attn_decode(self.parts_q if self.deferred_qkv else self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv,
                             c.head_dim, L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws, norm_dim=c.hidden,
-                            norm_eps=c.rms_eps)
-            ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, parts_out=self.parts_o)
+                            norm_eps=c.rms_eps, split_out=self.attn_parts if self.split_attn else None)
+            if self.split_attn:
+                ops.w4a16_gemv_fused(None, L.o, 0, parts_out=self.parts_o, attn_in=self.attn_parts, attn_head_dim=c.head_dim, dtype=self.dtype)
+            else:
+                ops.w4a16_gemv_fused(self.attn_buf, L.o, 0, parts_out=self.parts_o)
             ops.w4a16_gemv_fused(cur, L.gate_up, R, c.rms_eps, out=self.gu_buf, parts_in=self.parts_o, x_out=other.view(-1))
             cur, other = other, cur
             ops.w4a16_gemv_fused(self.gu_buf, L.down, S, parts_out=self.parts_d)

@@ -318,7 +318,8 @@ def dequant_packed(wq, sz, K: int, partition_sizes: Sequence[int], dtype=torch.f
 def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, residual: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, allreduce=None,
                      parts_out: Optional[torch.Tensor] = None, parts_in: Optional[torch.Tensor] = None,
-                     x_out: Optional[torch.Tensor] = None, parts_n: int = 0) -> torch.Tensor:
+                     x_out: Optional[torch.Tensor] = None, parts_n: int = 0, attn_in: Optional[torch.Tensor] = None,
+                     attn_head_dim: int = 0, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Decode-layer fusions around one fused linear (``paro_w4a16_gemv_fused``; rows <= 4):
     ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
     ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
@@ -334,9 +335,20 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     K-slices' sums of squares -- the consumer applies ``rsqrt(sum / K + eps)`` (:func:`attn_decode` does for the qkv projection).
     ``parts_in`` (float32 ``[K, 4]``, a producer's ``parts_out``): ``x`` is the residual stream BEFORE the producer's output
     and the kernel completes ``x' = round(x + sum(parts_in, 1))`` while it seeds its rotation (prologue NONE or RMSNORM; a plain
-    launch may K-split and may itself leave ``parts_out``); ``x_out [K]`` (not aliasing ``x``) receives ``x'``."""
+    launch may K-split and may itself leave ``parts_out``); ``x_out [K]`` (not aliasing ``x``) receives ``x'``.
+
+    ``attn_in`` (float32 ``[attn_parts_floats(K // attn_head_dim, attn_head_dim)]``, v14): the linear's input is the attention output
+    handed over un-merged by :func:`attn_decode` ``(..., split_out=)``; ``x`` is ignored (pass ``None``), the activation type comes from
+    ``dtype`` (or ``out``).  The launch completes the merge over the slots while it seeds its rotation -- the same bits as
+    :func:`attn_finish` followed by the plain launch.  One row, no prologue, no residual; ``parts_out`` allowed."""
     lib = nat.load()
     K, N = pk.K, pk.N
+    if attn_in is not None:
+        dt = dtype or (out.dtype if out is not None else torch.float16)
+        if attn_in.dtype != torch.float32 or not attn_in.is_contiguous() or attn_head_dim <= 0 or K % attn_head_dim \
+                or attn_in.numel() != attn_parts_floats(K // attn_head_dim, attn_head_dim):
+            raise ValueError(f"attn_in must be the contiguous float32 slot buffer of {K // max(attn_head_dim, 1)} heads x {attn_head_dim}")
+        x = torch.empty((1, K), dtype=dt, device=attn_in.device) if x is None else x     # never read: shape / dtype / device carrier
     width = 2 * K if prologue in (nat.PROLOGUE_SILU_MUL, nat.PROLOGUE_GELU_TANH_MUL) else K
     if x.size(-1) != width:
         raise ValueError(f"x must have {width} columns for this prologue, got {x.size(-1)}")
@@ -377,6 +389,8 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     if parts_in is not None:
         f.parts_in = parts_in.data_ptr()
         f.x_out = x_out.data_ptr() if x_out is not None else None
+    if attn_in is not None:
+        f.attn_in, f.attn_head_dim = attn_in.data_ptr(), int(attn_head_dim)
     ws = pk.workspace
     with torch.cuda.device(x.device):
         nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr() if y is not None else None, rows, ws.data_ptr(),
@@ -518,17 +532,45 @@ def attn_workspace(device, n_heads: int, n_kv_heads: int, head_dim: int, max_pos
     return ws
 
 
+def attn_parts_floats(n_heads: int, head_dim: int) -> int:
+    """Elements of the float32 slot buffer of a split attention launch (``paro_attn_parts_floats``)."""
+    n = nat.load().paro_attn_parts_floats(int(n_heads), int(head_dim))
+    if n < 0:
+        raise ValueError("bad n_heads / head_dim")
+    return int(n)
+
+
+def attn_finish(attn_parts: torch.Tensor, n_heads: int, head_dim: int, dtype: torch.dtype = torch.float16,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Complete a split attention launch's slots into the attention output ``[n_heads * head_dim]`` (``paro_attn_finish``): what the
+    ``attn_in`` prologue of :func:`w4a16_gemv_fused` computes, as its own launch."""
+    if attn_parts.dtype != torch.float32 or not attn_parts.is_contiguous() or attn_parts.numel() != attn_parts_floats(n_heads, head_dim):
+        raise ValueError("attn_parts must be the contiguous float32 slot buffer of a split attention launch")
+    y = out if out is not None else torch.empty(n_heads * head_dim, dtype=dtype, device=attn_parts.device)
+    if y.numel() != n_heads * head_dim or y.dtype != dtype or not y.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{n_heads * head_dim}] tensor of {dtype}")
+    with torch.cuda.device(attn_parts.device):
+        nat.check(nat.load().paro_attn_finish(attn_parts.data_ptr(), int(n_heads), int(head_dim), y.data_ptr(), nat.dtype_code(dtype),
+                                              nat.current_stream_ptr(attn_parts.device)))
+    return y
+
+
 def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, rope: torch.Tensor,
                 n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
                 out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, norm_dim: int = 0,
-                norm_eps: float = 1e-6) -> torch.Tensor:
+                norm_eps: float = 1e-6, split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decoder layer's batch-1 attention in one launch (``paro_attn_decode``): q/k norm + RoPE + KV-cache append at
     ``pos`` (int32 device tensor) + GQA over positions 0..pos.  ``kcache``: [n_kv_heads, T_max, head_dim];
     ``vcache``: [n_kv_heads, head_dim, T_max] (position-contiguous); T_max a multiple of 8; both must hold finite values
     (allocate them zero-filled).  ``qkv`` is the merged projection's output in the cache dtype, or -- float32
     ``[(n_heads + 2 n_kv_heads) * head_dim + 1, 4]`` -- the partial sums a K-split qkv projection left
     (``w4a16_gemv_fused(..., parts_out=)``; ``paro_attn_decode_parts``): the kernel completes each element as it reads it, scaled by
-    ``rsqrt(sum(last row) / norm_dim + norm_eps)`` when ``norm_dim > 0`` (the projection ran with the RMSNorm prologue)."""
+    ``rsqrt(sum(last row) / norm_dim + norm_eps)`` when ``norm_dim > 0`` (the projection ran with the RMSNorm prologue).
+
+    ``split_out`` (float32 ``[attn_parts_floats(n_heads, head_dim)]``, zero-filled once; ``paro_attn_decode_split``, v14): the merge over
+    position chunks is left to the consumer -- the launch stores per slot (at most four) the un-normalised outputs, maxima and sums;
+    ``w4a16_gemv_fused(None, o_proj, attn_in=split_out, attn_head_dim=head_dim)`` or :func:`attn_finish` completes them.  Returns
+    ``split_out``."""
     lib = nat.load()
     T_max = kcache.size(1)
     parts = qkv.dtype == torch.float32
@@ -539,7 +581,11 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
                          f"(got K {tuple(kcache.shape)}, V {tuple(vcache.shape)})")
     if tuple(rope.shape) != (T_max, head_dim) or rope.dtype != torch.float32 or pos.dtype != torch.int32:
         raise ValueError("rope must be fp32 [T, head_dim] (cos then sin per position) and pos an int32 device scalar")
-    y = out if out is not None else torch.empty(n_heads * head_dim, dtype=act_dtype, device=qkv.device)
+    split = split_out is not None
+    if split and (split_out.dtype != torch.float32 or not split_out.is_contiguous() or split_out.device != qkv.device
+                  or split_out.numel() != attn_parts_floats(n_heads, head_dim)):
+        raise ValueError(f"split_out must be a contiguous float32 tensor of attn_parts_floats({n_heads}, {head_dim}) elements on {qkv.device}")
+    y = out if (out is not None or split) else torch.empty(n_heads * head_dim, dtype=act_dtype, device=qkv.device)
     if out is not None and (out.numel() != n_heads * head_dim or out.dtype != act_dtype or not out.is_contiguous() or out.device != qkv.device):
         raise ValueError(f"out must be a contiguous tensor of {n_heads * head_dim} {act_dtype} elements on {qkv.device}")
     n_qkv = (n_heads + 2 * n_kv_heads) * head_dim
@@ -549,10 +595,13 @@ def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, p
     elif qkv.numel() != n_qkv or not qkv.is_contiguous():
         raise ValueError(f"qkv must be a contiguous vector of (n_heads + 2 n_kv_heads) * head_dim = {n_qkv} elements")
     ws = workspace if workspace is not None else attn_workspace(qkv.device, n_heads, n_kv_heads, head_dim, T_max)
-    tail = (kcache.data_ptr(), vcache.data_ptr(), y.data_ptr(), pos.data_ptr(), rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
+    tail = (kcache.data_ptr(), vcache.data_ptr(), split_out.data_ptr() if split else y.data_ptr(), pos.data_ptr(), rope.data_ptr(), None if q_norm_w is None else q_norm_w.data_ptr(),
             None if k_norm_w is None else k_norm_w.data_ptr(), float(eps), float(head_dim) ** -0.5, n_heads, n_kv_heads, head_dim, T_max,
             nat.dtype_code(act_dtype), ws.data_ptr(), ws.numel(), nat.current_stream_ptr(qkv.device))
     with torch.cuda.device(qkv.device):
+        if split:
+            nat.check(lib.paro_attn_decode_split(None if parts else qkv.data_ptr(), qkv.data_ptr() if parts else None, int(norm_dim), float(norm_eps), *tail))
+            return split_out
         if parts:
             nat.check(lib.paro_attn_decode_parts(qkv.data_ptr(), int(norm_dim), float(norm_eps), *tail))
         else:

@@ -1346,8 +1346,9 @@ def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
     cfg = lambda: DecoderConfig(512, 2048, 16, 2, 128, 3, 640, 1e-6, 10000.0, True, 64)     # o: 2048 -> 512, down: 2048 -> 512: both K-split
     ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
     monkeypatch.setenv("PARO_DEFERRED_QKV", "0")           # (the 2-way qkv changes qkv's own summation order: its own test below)
+    monkeypatch.setenv("PARO_SPLIT_ATTN", "0")             # (the split attention merges 128-position slots: another rounding, its own test below)
     lm_d = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
-    assert lm_d.deferred and not lm_d.deferred_qkv
+    assert lm_d.deferred and not lm_d.deferred_qkv and not lm_d.split_attn
     monkeypatch.setenv("PARO_DEFERRED_KSPLIT", "0")
     lm_r = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
     assert not lm_r.deferred
@@ -1358,6 +1359,36 @@ def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
         assert torch.equal(lm_d.logits, lm_r.logits)
     from paroquant_amd import ops
     ops.check_workspace(lm_d.layers[0].o.workspace)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decoder_harness_split_attention(dev, dtype, monkeypatch):
+    """The attention's merge over position chunks completed by o_proj (ABI v14, decoder.split_attn) against the in-launch merge: the
+    logits of every teacher-forced step agree to rounding (another partition of the positions, one more fp32 rescale), eager and graph;
+    positions cross the 128-position slot boundary."""
+    from paroquant_amd.decoder import ParoDecoderLM, DecoderConfig
+    cfg = lambda: DecoderConfig(512, 2048, 16, 2, 128, 3, 640, 1e-6, 10000.0, True, 320)
+    ids = torch.randint(0, 640, (150,), device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    lm_s = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
+    assert lm_s.deferred and lm_s.split_attn
+    monkeypatch.setenv("PARO_SPLIT_ATTN", "0")
+    lm_m = ParoDecoderLM.random(cfg(), dev, seed=9, dtype=dtype)
+    assert lm_m.deferred and not lm_m.split_attn
+    tol = 2e-2 if dtype == torch.float16 else 8e-2
+    for use_graph in (False, True):
+        for lm in (lm_s, lm_m):
+            lm.prefill(ids[:120])
+            if use_graph:
+                lm.capture()
+        for i in range(120, 150):                    # teacher-forced: both models see the same tokens at positions 120..149
+            for lm in (lm_s, lm_m):
+                lm.tok.copy_(ids[i:i + 1])
+                lm._graph.replay() if use_graph else lm.decode_step()
+            a, b = lm_s.logits.float(), lm_m.logits.float()
+            assert (a - b).abs().max().item() < tol * b.abs().max().item(), (use_graph, i)
+    from paroquant_amd import ops
+    ops.check_workspace(lm_s.layers[0].o.workspace)
 
 
 @pytest.mark.gpu

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--heads", type=int, default=32); ap.add_argument("--kv", type=int, default=8); ap.add_argument("--hd", type=int, default=128)
 ap.add_argument("--tmax", type=int, default=2048); ap.add_argument("--positions", default="0,100,255,256,700,2047")
 ap.add_argument("--layers", type=int, default=36)
+ap.add_argument("--split", action="store_true", help="paro_attn_decode_split: slots out, no in-launch merge")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 H, KV, hd, T = a.heads, a.kv, a.hd, a.tmax
@@ -23,9 +24,10 @@ rope = torch.cat([ang.cos(), ang.sin()], -1).contiguous()
 w = torch.ones(hd, device=dev).half()
 out = torch.empty(H * hd, device=dev).half()
 pos = torch.zeros(1, dtype=torch.int32, device=dev)
+sp = torch.zeros(ops.attn_parts_floats(H, hd), dtype=torch.float32, device=dev) if a.split else None
 def run():
     for k, v in caches:
-        ops.attn_decode(qkv, k, v, pos, rope, H, KV, hd, w, w, 1e-6, out=out)
+        ops.attn_decode(qkv, k, v, pos, rope, H, KV, hd, w, w, 1e-6, out=out, split_out=sp)
 run(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
@@ -38,5 +40,5 @@ for p in [int(v) for v in a.positions.split(",")]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / a.layers)
-    print(json.dumps({"max_positions": T, "chunk": 256 if T <= 512 else 128, "pos": p, "us_per_launch": round(float(np.median(ts)), 2),
+    print(json.dumps({"max_positions": T, "chunk": 128 if a.split else (256 if T <= 512 else 128), "split": bool(a.split), "pos": p, "us_per_launch": round(float(np.median(ts)), 2),
                       "dbg": os.environ.get("PARO_ATTN_DBG", "0")}), flush=True)

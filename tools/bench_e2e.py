@@ -48,7 +48,7 @@ def main():
         "ttft_ms": round(float(np.median([s["ttft_s"] for s in stats])) * 1e3, 2),
         "packed_weight_bytes_per_token": lm.bytes_per_token, "lm_head_bytes_per_token": lm_head_bytes,
         "effective_GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),
-        "hip_graph": not args.no_graph, "deferred_ksplit_reduction": bool(lm.deferred), "data": "synthetic"}), flush=True)
+        "hip_graph": not args.no_graph, "deferred_ksplit_reduction": bool(lm.deferred), "split_attention": bool(getattr(lm, "split_attn", False)), "data": "synthetic"}), flush=True)
 
 
 if __name__ == "__main__":
