@@ -96,17 +96,22 @@ __device__ __forceinline__ float wave_sum(float v) {   // the same value in ever
 // (max, sum, partial output) triples merged like chunks are.
 template <typename AT, int HD, int NREP, int CH, bool PARTS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
-  constexpr int kChunk = CH;                   // positions of a workgroup
-  constexpr int WP = CH / 4;                   // positions of a wave (64 / 32)
-  constexpr int KT = WP / 16;                  // K tiles (16 positions) of a wave
-  constexpr int VS = WP / 32;                  // V k-steps (32 positions) of a wave
+  // CH = 0 (SPLIT only): the chunk size follows the POSITION -- 64 positions per workgroup while the context fits four such slots
+  // (no ticket up to 256 positions, twice the CUs per head), 128 beyond; the grid is sized for 64
+  constexpr int CHM = CH ? CH : 128;           // largest chunk this instantiation can run (LDS sizing)
+  static_assert(CH != 0 || SPLIT, "position-dependent chunks are a split-launch feature");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int hd = HD, half = HD / 2;
   constexpr int DT = HD / 16;                  // 16-column output tiles of the P V product
+  // SPLIT builds cut the two products differently: the scores by POSITIONS (wave w: positions WP w .. of the chunk), P V by
+  // DIMENSIONS (wave w: dims (HD / 4) w .. over all positions of the chunk, after one barrier) -- every output element is then complete in one
+  // wave's registers and goes straight to memory: no partial outputs through LDS, no merge of the waves
+  constexpr int VT = SPLIT ? HD / 64 : DT;     // V tiles (16 dims) a wave holds
+  static_assert(SPLIT ? (CH == 128 || CH == 64 || CH == 0) : CH >= 128, "split launches work on 64- or 128-position chunks, the others on 128 / 256");
   constexpr float kLog2e = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) float pw[4 * NREP * WP];        // [wave][head][WP] unnormalised probabilities of the wave's positions
-  __shared__ __attribute__((aligned(16))) float accs[4 * NREP * HD];      // [wave][head][hd] partial outputs
+  __shared__ __attribute__((aligned(16))) float pw[4 * NREP * (CHM / 4)];  // [wave][head][WP] unnormalised probabilities of the wave's positions
+  __shared__ __attribute__((aligned(16))) float accs[SPLIT ? 4 : 4 * NREP * HD];      // [wave][head][hd] partial outputs
   __shared__ float st[4 * NREP * 2];                                       // [wave][head] (max, sum) of the wave's positions
   __shared__ __attribute__((aligned(16))) unsigned short q16[16 * HD];     // [16 MFMA rows][hd] roped queries (activation dtype), rows >= n_rep zero
   __shared__ __attribute__((aligned(16))) unsigned short k16[HD];          // the new token's roped key (activation dtype)
@@ -115,7 +120,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, s = blockIdx.y;
   const int n_rep = a.Hq / a.Hkv;
-  const int p0 = s * kChunk;
   const int kb = lane >> 4, mm = lane & 15;
   // The position first, through the scalar cache (one ~300-cycle round trip, nothing queued in front of it): chunks
   // beyond it leave at once, and the rotary row -- the only load that depends on it -- goes out ahead of the K / V stream.
@@ -154,7 +158,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // the floor of this kernel).
   int pos;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
-  if (p0 > pos || pos >= a.T_max || pos < 0) return;  // chunk beyond the current position; a position outside the cache writes nothing
+  if (pos >= a.T_max || pos < 0) return;              // a position outside the cache writes nothing
+  // ---- everything below depends on the chunk size: a generic lambda, instantiated once (CH != 0) or for both sizes (CH == 0)
+  auto rest = [&](auto ch_tag) {
+  constexpr int kChunk = decltype(ch_tag)::value;    // positions of a workgroup
+  constexpr int WP = kChunk / 4;                     // positions of a wave (64 / 32 / 16)
+  constexpr int KT = WP / 16;                        // K tiles (16 positions) of a wave
+  constexpr int VS = WP >= 32 ? WP / 32 : 1;         // V k-steps (32 positions) of a wave
+  constexpr int VK = SPLIT ? kChunk / 32 : VS;       // V k-steps (32 positions) a wave holds
+  const int p0 = s * kChunk;
+  if (p0 > pos) return;                               // chunk beyond the current position
   const int n_act = pos / kChunk + 1;                 // chunks that take part
   const int cn = min(kChunk, pos + 1 - p0);           // positions of this chunk
   const bool own_new = (pos - p0) < kChunk;           // this chunk holds the new token's position
@@ -181,7 +194,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // row: a single cache line for the whole wave), so they cost no bandwidth.  Rows past the end and the new token's row
   // (not in the cache yet) are masked / patched where they are consumed.
   u32x4 kw[KT][KS];
-  u32x4 vf[DT][VS];
+  u32x4 vf[VT][VK];
+  const int vdim0 = SPLIT ? wave * (HD / 4) : 0;     // first dim / first chunk position of this wave's V fragments
+  const int vpos0 = SPLIT ? 0 : wave * WP;
   {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -192,12 +207,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       for (int i = 0; i < KS; ++i) kw[t][i] = kr[need ? 4 * i : 0];
     }
 #pragma unroll
-    for (int i = 0; i < VS; ++i) {
-      const bool need = wave * WP + 32 * i < cn;
+    for (int i = 0; i < VK; ++i) {
+      const bool need = vpos0 + 32 * i < cn;
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const unsigned short* vr = a.vcache + ((int64_t)h * hd + (need ? 16 * t + mm : 0)) * a.T_max;
-        vf[t][i] = *(const u32x4*)(vr + (need ? min(p0 + wave * WP + 32 * i + 8 * kb, a.T_max - 8) : p0));
+      for (int t = 0; t < VT; ++t) {
+        const unsigned short* vr = a.vcache + ((int64_t)h * hd + (need ? vdim0 + 16 * t + mm : 0)) * a.T_max;
+        vf[t][i] = *(const u32x4*)(vr + (need ? min(p0 + vpos0 + 32 * i + 8 * kb, a.T_max - 8) : p0));
       }
     }
   }
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       }
     }
   }
-  __builtin_amdgcn_wave_barrier();   // the wave reads back what its own lanes wrote (LDS is in order within a wave)
+  if constexpr (SPLIT) __syncthreads();   // every wave reads every wave's probabilities below
+  else __builtin_amdgcn_wave_barrier();   // the wave reads back what its own lanes wrote (LDS is in order within a wave)
   if (a.dbg == 3) return;
 
   // ---- step 4: O[j][d] = sum_p e_j[p] V[p][d] over the wave's 64 positions on the matrix cores: A = probabilities
@@ -305,17 +321,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // token's value patched into its position
   {
     const int lp = pos - p0;
-    const bool vpatch = own_new && wave == lp / WP && kb == ((lp >> 3) & 3);
+    const bool own_blk = own_new && lp >= vpos0 && lp < vpos0 + 32 * VK;   // the new token's position is among this wave's fragments
+    const bool vpatch = own_blk && kb == ((lp >> 3) & 3);
 #pragma unroll
-    for (int i = 0; i < VS; ++i) {
+    for (int i = 0; i < VK; ++i) {
       // only the 32 positions that hold the chunk's end or the new token need any of this (wave-uniform test)
-      const bool pi32 = own_new && wave == lp / WP && i == ((lp % WP) >> 5);
-      if (wave * WP + 32 * i + 32 <= cn && !pi32) continue;
-      const int nv = cn - (wave * WP + 32 * i + 8 * kb);          // valid positions among this lane's eight
+      const bool pi32 = own_blk && i == ((lp - vpos0) >> 5);
+      if (vpos0 + 32 * i + 32 <= cn && !pi32) continue;
+      const int nv = cn - (vpos0 + 32 * i + 8 * kb);          // valid positions among this lane's eight
       unsigned mk[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) mk[c] = nv >= 2 * c + 2 ? 0xffffffffu : (nv == 2 * c + 1 ? 0x0000ffffu : 0u);
-      const bool pi = vpatch && i == ((lp % WP) >> 5);
+      const bool pi = vpatch && i == ((lp - vpos0) >> 5);
       // the new token's value replaces one 16-bit slot of one word: keep-mask / insert-shift per word, computed once
       unsigned keep[4], sh[4];
 #pragma unroll
@@ -325,12 +342,142 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         sh[c] = hit ? ((lp & 1) ? 16u : 0u) : 32u;            // 32: nothing inserted
       }
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const unsigned nv16 = v16[16 * t + mm];
+      for (int t = 0; t < VT; ++t) {
+        const unsigned nv16 = v16[vdim0 + 16 * t + mm];
 #pragma unroll
         for (int c = 0; c < 4; ++c) vf[t][i][c] = (vf[t][i][c] & mk[c] & keep[c]) | (sh[c] < 32u ? nv16 << sh[c] : 0u);
       }
     }
+    if constexpr (SPLIT) {
+      // the chunk's maximum and sum of head mm from the four waves' (max, sum); a wave's probabilities are rescaled by 2^(m_w - M) as
+      // they become the A operand (WP = 32: wave i's positions ARE k-step i; WP = 16: k-step i = waves 2 i, 2 i + 1)
+      // (four scalars, not an array: a select between two array elements became a dynamically indexed private array, which the
+      // compiler moved to LDS -- and addressing it by work-item id made every wave read the workgroup size from the AQL dispatch
+      // packet: one scalar load from the queue's memory, measured at 4 .. 7 us per launch)
+      float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, M = 0.f, den = 0.f;
+      if (mm < NREP) {
+        const float m0 = st[(0 * NREP + mm) * 2], m1 = st[(1 * NREP + mm) * 2], m2 = st[(2 * NREP + mm) * 2], m3 = st[(3 * NREP + mm) * 2];
+        M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        f0 = __builtin_amdgcn_exp2f((m0 - M) * kLog2e);
+        f1 = __builtin_amdgcn_exp2f((m1 - M) * kLog2e);
+        f2 = __builtin_amdgcn_exp2f((m2 - M) * kLog2e);
+        f3 = __builtin_amdgcn_exp2f((m3 - M) * kLog2e);
+        den = __builtin_fmaf(f0, st[(0 * NREP + mm) * 2 + 1], den);
+        den = __builtin_fmaf(f1, st[(1 * NREP + mm) * 2 + 1], den);
+        den = __builtin_fmaf(f2, st[(2 * NREP + mm) * 2 + 1], den);
+        den = __builtin_fmaf(f3, st[(3 * NREP + mm) * 2 + 1], den);
+      }
+      const float fk[4] = {f0, f1, f2, f3};                                         // WP = 32: k-step i's factor (compile-time index)
+      const float fh[2] = {(kb >> 1) ? f1 : f0, (kb >> 1) ? f3 : f2};               // WP = 16: this lane's half of k-step i
+      vec8 pa[VK];
+#pragma unroll
+      for (int i = 0; i < VK; ++i) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (mm < NREP) {
+          const int sw = WP == 32 ? i : 2 * i + (kb >> 1);                      // the wave whose positions these eight are
+          const int so = WP == 32 ? 8 * kb : 8 * (kb & 1);
+          const float fi = WP == 32 ? fk[i] : fh[i & 1];
+          const f32x4 e0 = *(const f32x4*)(pw + (sw * NREP + mm) * WP + so);
+          const f32x4 e1 = *(const f32x4*)(pw + (sw * NREP + mm) * WP + so + 4);
+          w[0] = (unsigned)A::from_f32(e0[0] * fi) | ((unsigned)A::from_f32(e0[1] * fi) << 16);
+          w[1] = (unsigned)A::from_f32(e0[2] * fi) | ((unsigned)A::from_f32(e0[3] * fi) << 16);
+          w[2] = (unsigned)A::from_f32(e1[0] * fi) | ((unsigned)A::from_f32(e1[1] * fi) << 16);
+          w[3] = (unsigned)A::from_f32(e1[2] * fi) | ((unsigned)A::from_f32(e1[3] * fi) << 16);
+        }
+        pa[i] = __builtin_bit_cast(vec8, w);
+      }
+      // where this chunk's triple goes: its slot of the caller's buffer (one chunk per slot), or the workspace (several chunks per
+      // slot: merged by the slot's last arriver below)
+      const int per = (n_act + 3) >> 2, slot = s / per, n_slots = (n_act + per - 1) / per;
+      float* ob;             // element (j, d) at ob[j * ohs + d * oes]
+      float* mb;             // (M, den) of head j at mb[j * mhs], mb[j * mhs + mds]
+      int ohs, oes, mhs, mds;
+      if (per == 1) {
+        ob = a.split_o + (int64_t)h * n_rep * hd * 4 + slot; ohs = hd * 4; oes = 4;
+        mb = a.split_ml + (int64_t)h * n_rep * 8 + slot; mhs = 8; mds = 4;
+      } else {
+        ob = a.part + (((int64_t)h * a.chunks + s) * n_rep) * (hd + 2); ohs = hd + 2; oes = 1;
+        mb = ob + hd; mhs = hd + 2; mds = 1;
+      }
+#pragma unroll
+      for (int t = 0; t < VT; ++t) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < VK; ++i) o = A::mfma(pa[i], __builtin_bit_cast(vec8, vf[t][i]), o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 4 * kb + r;
+          if (j < n_rep && (a.dbg != 5 || o[r] == 123.456f)) ob[j * ohs + (vdim0 + 16 * t + mm) * oes] = o[r];
+        }
+      }
+      if (wave == 0 && kb == 0 && mm < n_rep) {
+        mb[mm * mhs] = M;
+        mb[mm * mhs + mds] = den;
+      }
+      // chunk 0 (always active) marks the slots nobody fills: (max, sum) = (-3e38, 0) -- the consumer skips their outputs
+      if (s == 0 && tid < n_rep * 4) {
+        const int j = tid >> 2, q = tid & 3;
+        if (q >= n_slots) {
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + q] = -3.0e38f;
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + q] = 0.f;
+        }
+      }
+      if (per == 1) return;
+      // several chunks per slot: the slot's last arriver merges its chunks into the slot's triple
+      const int c_first = slot * per, c_count = min(per, n_act - c_first);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* tk = a.ticket + 64 + h * 4 + slot;
+        const unsigned tkt = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (tkt == (unsigned)(c_count - 1)) ? 1u : 0u;
+        if (last_flag) {
+          __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
+      __syncthreads();
+      if (!last_flag) return;
+      const float* base = a.part + ((int64_t)h * a.chunks + c_first) * n_rep * (hd + 2);
+      for (int e = tid; e < n_rep * hd; e += 256) {
+        const int j = e / hd, d = e % hd;
+        const float* pj = base + (int64_t)j * (hd + 2);
+        const int64_t cstride = (int64_t)n_rep * (hd + 2);
+        float Ms = -3.0e38f;
+        for (int c0 = 0; c0 < c_count; c0 += 8) {
+          float mv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, c_count - 1) * cstride + hd];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) Ms = fmaxf(Ms, mv[q]);
+        }
+        float num = 0.f, dn = 0.f;
+        for (int c0 = 0; c0 < c_count; c0 += 8) {
+          float mv[8], lv[8], ov[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float* pc = pj + (int64_t)min(c0 + q, c_count - 1) * cstride;
+            mv[q] = pc[hd];
+            lv[q] = pc[hd + 1];
+            ov[q] = pc[d];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float wq = (c0 + q < c_count) ? __builtin_amdgcn_exp2f((mv[q] - Ms) * kLog2e) : 0.f;
+            num = __builtin_fmaf(wq, ov[q], num);
+            dn = __builtin_fmaf(wq, lv[q], dn);
+          }
+        }
+        a.split_o[(((int64_t)h * n_rep + j) * hd + d) * 4 + slot] = num;
+        if (d == 0) {
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + slot] = Ms;
+          a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + slot] = dn;
+        }
+      }
+      return;
+    } else {
     vec8 pa[VS];
 #pragma unroll
     for (int i = 0; i < VS; ++i) {
@@ -356,7 +503,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         if (j < NREP) accs[(wave * NREP + j) * hd + 16 * t + mm] = o[r];
       }
     }
+    }
   }
+  if constexpr (!SPLIT) {
   if (a.dbg == 4) return;
   __syncthreads();
   // ---- the four waves' (max, sum, partial output) -> the chunk's: M = max m_w, num = sum 2^(m_w - M) o_w, den likewise
@@ -372,97 +521,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
     return num;
   };
-  if constexpr (SPLIT) {
-    const int per = (n_act + 3) >> 2;                   // chunks per slot
-    const int slot = s / per;
-    const int n_slots = (n_act + per - 1) / per;        // slots in use
-    // chunk 0 (always active) marks the slots nobody fills: (max, sum) = (-3e38, 0) -- the consumer skips their outputs
-    if (s == 0 && tid < n_rep * 4) {
-      const int j = tid >> 2, q = tid & 3;
-      if (q >= n_slots) {
-        a.split_ml[((int64_t)h * n_rep + j) * 8 + q] = -3.0e38f;
-        a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + q] = 0.f;
-      }
-    }
-    if (per == 1) {
-      // one chunk per slot (up to 4 x 128 positions): store the triple, done -- no ticket, no fence
-      for (int e = tid; e < n_rep * hd; e += 256) {
-        const int j = e / hd, d = e % hd;
-        float M, den;
-        const float num = chunk_value(j, d, M, den);
-        a.split_o[(((int64_t)h * n_rep + j) * hd + d) * 4 + slot] = num;
-        if (d == 0) {
-          a.split_ml[((int64_t)h * n_rep + j) * 8 + slot] = M;
-          a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + slot] = den;
-        }
-      }
-      return;
-    }
-    // several chunks per slot: publish, the slot's last arriver merges its chunks into the slot's triple
-    const int c_first = slot * per, c_count = min(per, n_act - c_first);
-    float* mine = a.part + (((int64_t)h * a.chunks + s) * n_rep) * (hd + 2);
-    for (int e = tid; e < n_rep * hd; e += 256) {
-      const int j = e / hd, d = e % hd;
-      float M, den;
-      mine[j * (hd + 2) + d] = chunk_value(j, d, M, den);
-      if (d == 0) {
-        mine[j * (hd + 2) + hd] = M;
-        mine[j * (hd + 2) + hd + 1] = den;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned* tk = a.ticket + 64 + h * 4 + slot;
-      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = (t == (unsigned)(c_count - 1)) ? 1u : 0u;
-      if (last_flag) {
-        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    const float* base = a.part + ((int64_t)h * a.chunks + c_first) * n_rep * (hd + 2);
-    for (int e = tid; e < n_rep * hd; e += 256) {
-      const int j = e / hd, d = e % hd;
-      const float* pj = base + (int64_t)j * (hd + 2);
-      const int64_t cstride = (int64_t)n_rep * (hd + 2);
-      float M = -3.0e38f;
-      for (int c0 = 0; c0 < c_count; c0 += 8) {
-        float mv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, c_count - 1) * cstride + hd];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) M = fmaxf(M, mv[q]);
-      }
-      float num = 0.f, den = 0.f;
-      for (int c0 = 0; c0 < c_count; c0 += 8) {
-        float mv[8], lv[8], ov[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float* pc = pj + (int64_t)min(c0 + q, c_count - 1) * cstride;
-          mv[q] = pc[hd];
-          lv[q] = pc[hd + 1];
-          ov[q] = pc[d];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float w = (c0 + q < c_count) ? __builtin_amdgcn_exp2f((mv[q] - M) * kLog2e) : 0.f;
-          num = __builtin_fmaf(w, ov[q], num);
-          den = __builtin_fmaf(w, lv[q], den);
-        }
-      }
-      a.split_o[(((int64_t)h * n_rep + j) * hd + d) * 4 + slot] = num;
-      if (d == 0) {
-        a.split_ml[((int64_t)h * n_rep + j) * 8 + slot] = M;
-        a.split_ml[((int64_t)h * n_rep + j) * 8 + 4 + slot] = den;
-      }
-    }
-    return;
-  }
   if (n_act == 1) {
     // the only chunk: normalise and write the output
     for (int e = tid; e < n_rep * hd; e += 256) {
@@ -532,6 +590,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
     a.out[((int64_t)h * n_rep + j) * hd + d] = A::from_f32(num / den);
   }
+  }
+  };   // rest
+  if constexpr (CH == 0) {
+    if (pos < 256) rest(std::integral_constant<int, 64>{});
+    else rest(std::integral_constant<int, 128>{});
+  } else {
+    rest(std::integral_constant<int, CH>{});
+  }
 }
 
 // The consumer's completion of a SPLIT launch, as its own launch (tests; callers whose next launch is not a fused GEMV): the same
@@ -568,8 +634,8 @@ extern "C" int64_t paro_attn_decode_workspace_bytes(int n_heads, int n_kv_heads,
   if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 2 || max_positions < 1) return -1;
   const int64_t n_rep = n_heads / n_kv_heads, chunks = (max_positions + paro::attn_chunk(max_positions) - 1) / paro::attn_chunk(max_positions);
   // tickets (zero-filled by the caller once: [0, 64) per KV head, [64, 320) per (KV head, slot) of the split launch) + partials, sized for
-  // 128-position chunks (the split launch always uses them)
-  const int64_t chunks128 = (max_positions + 127) / 128;
+  // 64-position chunks (the split launch's)
+  const int64_t chunks128 = (max_positions + 63) / 64;
   return paro::kAttnWsHeader + (int64_t)n_kv_heads * (chunks > chunks128 ? chunks : chunks128) * n_rep * (head_dim + 2) * 4;
 }
 
@@ -590,7 +656,10 @@ static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t nor
   const int64_t need = paro_attn_decode_workspace_bytes(n_heads, n_kv_heads, head_dim, max_positions);
   if (max_positions < 8 || max_positions % 8 != 0 || max_positions > 65535 * 128)
     return fail(PARO_ERR_INVALID, "max_positions must be a multiple of 8 in 8..%d (got %d)", 65535 * 128, max_positions);
-  const int kChunk = split ? 128 : attn_chunk(max_positions);
+  static const int env_sc = getenv("PARO_ATTN_SPLIT_CHUNK") ? atoi(getenv("PARO_ATTN_SPLIT_CHUNK")) : 0;   // A/B knob
+  const int kChunk = split ? (env_sc == 128 ? 128 : 64) : attn_chunk(max_positions);   // split: the grid is sized for 64-position chunks; the
+                                                                                       // kernel itself moves to 128 from 256 positions on
+  const bool split_dual = split && env_sc == 0;
   if (!workspace || workspace_bytes < need)
     return fail(PARO_ERR_INVALID, "attention workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   AttnArgs a;
@@ -627,7 +696,13 @@ static int attn_decode_impl(const void* qkv, const float* qkv_parts, int64_t nor
 #define PARO_ATTN_LAUNCH(T, HD, NR) \
   do { \
     if (split) { \
-      if (parts) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, true, true>), grid, dim3(256), 0, st, a); \
+      if (split_dual) { \
+        if (parts) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 0, true, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 0, false, true>), grid, dim3(256), 0, st, a); \
+      } else if (kChunk == 64) { \
+        if (parts) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 64, true, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 64, false, true>), grid, dim3(256), 0, st, a); \
+      } else if (parts) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, true, true>), grid, dim3(256), 0, st, a); \
       else hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 128, false, true>), grid, dim3(256), 0, st, a); \
     } else if (parts) { \
       if (kChunk == 256) hipLaunchKernelGGL((attn_decode_kernel<T, HD, NR, 256, true>), grid, dim3(256), 0, st, a); \

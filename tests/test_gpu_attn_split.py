@@ -1,6 +1,8 @@
 """Split decode attention (paro_attn_decode_split, ABI v14): the merge over position chunks is left to the consumer -- paro_attn_finish,
 or the attn_in prologue of the fused GEMV (o_proj).  Against the float64 oracle (oracle/paro_oracle.py: attention_decode, paro_linear_merged)
 and, bit for bit, against the route that finishes in its own launch."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -58,7 +60,9 @@ def test_split_attention_and_finish_match_oracle(dev, hd, Hq, Hkv, qk_norm, T, p
     assert torch.equal(kct, k2) and torch.equal(vct, v2)
     # slots nobody filled carry the sentinel
     ml = sp[Hq * hd * 4:].view(Hq, 8)
-    n_act = pos // 128 + 1
+    env = os.environ.get("PARO_ATTN_SPLIT_CHUNK")                                   # (A/B knob of attn.hip; default: by position)
+    chunk = int(env) if env in ("64", "128") else (64 if pos < 256 else 128)      # positions per workgroup of the split launch
+    n_act = pos // chunk + 1
     per = (n_act + 3) // 4
     used = (n_act + per - 1) // per
     assert bool((ml[:, 4:4 + used] > 0).all()) and bool((ml[:, 4 + used:] == 0).all()) and bool((ml[:, used:4] < -1e37).all())

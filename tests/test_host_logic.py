@@ -575,3 +575,26 @@ def test_hf_moe_expert_blocks_take_the_reference_export_names():
     # the per-linear surgery does not touch what lives under an experts block
     targets = {n[:-8] for n in names if n.endswith(".qweight") and not any(n.startswith(b + ".") for b in blocks)}
     assert targets == {"model.layers.0.self_attn.q_proj", "model.layers.1.self_attn.q_proj"}
+
+
+def test_no_kernel_reads_the_dispatch_packet():
+    """Every kernel descriptor in the built library: no dispatch-packet / queue pointer (a kernel that needs the workgroup size at run
+    time -- e.g. after a private array was moved to LDS -- reads it from the AQL packet in the queue's memory: 4 .. 7 us per launch,
+    profiles/NOTES.md 4.5).  tools/check_kernel_descriptors.py walks the embedded gfx950 code objects."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "paroquant_amd", "_lib", "libparo_mi355x.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    spec = importlib.util.spec_from_file_location("check_kd", os.path.join(root, "tools", "check_kernel_descriptors.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    blob = open(lib, "rb").read()
+    n, bad = 0, []
+    for triple, co in m.code_objects(blob):
+        if "gfx950" in triple and co[:4] == b"\x7fELF":
+            for name, props, priv in m.kernels(co):
+                n += 1
+                if props & 0b110:
+                    bad.append(name)
+    assert n > 100 and not bad, bad[:5]
