@@ -10,14 +10,15 @@
 // P V run on the matrix cores, the soft-max of a wave's 64 / 32 positions in registers.  A CU ingests ~13 B / clock, so
 // longer contexts are spread over many CUs rather than one workgroup per head.  The V cache is kept position-contiguous
 // ([head][dim][position]) so that its fragments are 16-byte loads too.  With more than one active chunk the partial
-// (max, sum, unnormalised output) triples go to a workspace and the LAST workgroup of a KV head to arrive (agent-scope
-// release -> ticket -> acquire; no spinning, so no dependence on dispatch order) merges them, reading eight chunks'
+// (max, sum, unnormalised output) triples go to a workspace and the LAST workgroup of a KV head to arrive (write-through
+// stores -> ticket -> agent-scope loads, see st_agent below; no spinning, so no dependence on dispatch order) merges them, reading eight chunks'
 // triples at a time.  The position comes from DEVICE memory, so one captured graph replays for every token: the grid
 // always covers max_positions, chunks beyond `pos` exit at once.
 //
-// SPLIT builds (paro_attn_decode_split): the merge is NOT done here.  Chunks are 128 positions; the active chunks are grouped into at
-// most FOUR slots (one chunk per slot up to 512 positions -- no ticket, no fence, the workgroup stores its (max, sum, un-normalised
-// output) triple and is done; beyond that the chunks of a slot meet at a per-slot ticket and the last one stores the slot's triple)
+// SPLIT builds (paro_attn_decode_split): the merge is NOT done here.  Chunks are 64 positions below 256 positions and 128 from there on
+// (one kernel, both paths; the grid is sized for 64); the active chunks are grouped into at most FOUR slots (one chunk per slot up to
+// 256 / 512 positions -- no ticket, the workgroup stores its (max, sum, un-normalised output) triple and is done; beyond that the
+// chunks of a slot meet at a per-slot ticket and the last one stores the slot's triple)
 // and the launch that consumes the attention output -- o_proj, `paro_fusion_t.attn_in` -- completes
 //     out[j][d] = sum_c 2^(m_c - M) o_c[d] / sum_c 2^(m_c - M) l_c
 // while it seeds its rotation: each element is read by the few workgroups whose K-slice holds it.  At short contexts that
@@ -85,6 +86,13 @@ __device__ __forceinline__ float wave_sum(float v) {   // the same value in ever
   v += dpp_f<0x143, 0xc>(v);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// Hand-over of partial results between workgroups of ONE launch without cache-wide fences: the producer's stores are agent-scope
+// relaxed atomics (write-through), it waits for their completion (s_waitcnt vmcnt(0)) and takes a ticket; the last arriver reads with
+// agent-scope relaxed atomic loads.  An agent-scope release / acquire pair instead writes back and invalidates the whole L2 of the
+// XCD: ~2 us per launch here (and 7.8 -> 5.3 us in gdn_step_kernel, which uses the same scheme).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // NREP = query heads per KV head rounded up to a power of two: a COMPILE-TIME bound, so that every loop over heads
 // unrolls without a branch per iteration.  Padding heads have zero queries and are never stored.
@@ -407,12 +415,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 4 * kb + r;
-          if (j < n_rep && (a.dbg != 5 || o[r] == 123.456f)) ob[j * ohs + (vdim0 + 16 * t + mm) * oes] = o[r];
+          if (j < n_rep) st_agent(ob + j * ohs + (vdim0 + 16 * t + mm) * oes, o[r]);
         }
       }
       if (wave == 0 && kb == 0 && mm < n_rep) {
-        mb[mm * mhs] = M;
-        mb[mm * mhs + mds] = den;
+        st_agent(mb + mm * mhs, M);
+        st_agent(mb + mm * mhs + mds, den);
       }
       // chunk 0 (always active) marks the slots nobody fills: (max, sum) = (-3e38, 0) -- the consumer skips their outputs
       if (s == 0 && tid < n_rep * 4) {
@@ -428,15 +436,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned* tk = a.ticket + 64 + h * 4 + slot;
         const unsigned tkt = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (tkt == (unsigned)(c_count - 1)) ? 1u : 0u;
-        if (last_flag) {
-          __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        if (last_flag) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       if (!last_flag) return;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         for (int c0 = 0; c0 < c_count; c0 += 8) {
           float mv[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, c_count - 1) * cstride + hd];
+          for (int q = 0; q < 8; ++q) mv[q] = ld_agent(pj + (int64_t)min(c0 + q, c_count - 1) * cstride + hd);
 #pragma unroll
           for (int q = 0; q < 8; ++q) Ms = fmaxf(Ms, mv[q]);
         }
@@ -459,9 +462,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const float* pc = pj + (int64_t)min(c0 + q, c_count - 1) * cstride;
-            mv[q] = pc[hd];
-            lv[q] = pc[hd + 1];
-            ov[q] = pc[d];
+            mv[q] = ld_agent(pc + hd);
+            lv[q] = ld_agent(pc + hd + 1);
+            ov[q] = ld_agent(pc + d);
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -536,23 +539,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   for (int e = tid; e < n_rep * hd; e += 256) {
     const int j = e / hd, d = e % hd;
     float M, den;
-    mine[j * (hd + 2) + d] = chunk_value(j, d, M, den);
+    st_agent(mine + j * (hd + 2) + d, chunk_value(j, d, M, den));
     if (d == 0) {
-      mine[j * (hd + 2) + hd] = M;
-      mine[j * (hd + 2) + hd + 1] = den;
+      st_agent(mine + j * (hd + 2) + hd, M);
+      st_agent(mine + j * (hd + 2) + hd + 1, den);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's write-through stores have completed ...
+  __syncthreads();                                     // ... every thread's have
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the release's write-back has drained before the ticket is taken
     const unsigned t = __hip_atomic_fetch_add(a.ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = (t == (unsigned)(n_act - 1)) ? 1u : 0u;
-    if (last_flag) {
-      __hip_atomic_store(a.ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (last_flag) __hip_atomic_store(a.ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
   }
   __syncthreads();
   if (!last_flag) return;
@@ -567,7 +565,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int c0 = 0; c0 < n_act; c0 += 8) {
       float mv[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) mv[q] = pj[(int64_t)min(c0 + q, n_act - 1) * cstride + hd];
+      for (int q = 0; q < 8; ++q) mv[q] = ld_agent(pj + (int64_t)min(c0 + q, n_act - 1) * cstride + hd);
 #pragma unroll
       for (int q = 0; q < 8; ++q) M = fmaxf(M, mv[q]);
     }
@@ -577,9 +575,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float* pc = pj + (int64_t)min(c0 + q, n_act - 1) * cstride;
-        mv[q] = pc[hd];
-        lv[q] = pc[hd + 1];
-        ov[q] = pc[d];
+        mv[q] = ld_agent(pc + hd);
+        lv[q] = ld_agent(pc + hd + 1);
+        ov[q] = ld_agent(pc + d);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {

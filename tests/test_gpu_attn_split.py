@@ -177,3 +177,40 @@ def test_split_attention_graph_replay(dev):
         ref, k_new, v_new = po.attention_decode(qkv, kc, vc, pos, Hq, Hkv, hd, cos, sin, qw, kw, 1e-6)
         assert po.rel_err(ops.attn_finish(sp, Hq, hd).float().cpu().numpy(), ref) < 4e-3, pos
         kc[:, pos], vc[:, pos] = k_new.astype(np.float16), v_new.astype(np.float16)     # the launch appended this position to the caches
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_attention_ticket_merge_is_deterministic(dev, split):
+    """The in-launch merge of several chunks (write-through stores -> ticket -> agent-scope loads, no cache-wide fence): 3000 graph
+    replays at a long position, every result compared on the device with the first one -- a lost or stale partial result would show
+    as a mismatch (or a NaN)."""
+    from paroquant_amd import ops
+    hd, Hq, Hkv, T, pos = 128, 32, 8, 2048, 2047
+    qkv, kc, vc, qw, kw, cos, sin, rope = _case(77, hd, Hq, Hkv, T, True, dev)
+    kct, vct = _t(kc, dev), _t(vc.transpose(0, 2, 1), dev)
+    q, nw = _t(qkv, dev), (_t(qw, dev), _t(kw, dev))
+    pt = torch.tensor([pos], dtype=torch.int32, device=dev)
+    ws = ops.attn_workspace(dev, Hq, Hkv, hd, T)
+    sp = torch.zeros(ops.attn_parts_floats(Hq, hd), dtype=torch.float32, device=dev) if split else None
+    out = torch.empty(Hq * hd, dtype=torch.float16, device=dev)
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ops.attn_decode(q, kct, vct, pt, rope, Hq, Hkv, hd, *nw, 1e-6, out=out, workspace=ws, split_out=sp)
+        if split:
+            ops.attn_finish(sp, Hq, hd, out=out)
+    step()
+    first = out.clone()
+    ref, _, _ = po.attention_decode(qkv, kc, vc, pos, Hq, Hkv, hd, cos, sin, qw, kw, 1e-6)
+    assert po.rel_err(first.float().cpu().numpy(), ref) < 4e-3
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            step()
+            bad.add_((out != first).sum())
+    for _ in range(300):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    assert int(ws.view(torch.int32)[:512].abs().sum()) == 0
