@@ -147,7 +147,10 @@ class ParoQuantConfig(QuantizationConfig):
 
     @classmethod
     def get_min_capability(cls) -> int:
-        return 75   # same value as the reference; on ROCm vLLM maps gfx9xx well above it
+        # the reference returns 75 (a CUDA compute capability, plugin.py:99-101); vLLM's ROCm platform reports gfx9xx as (9, x), so
+        # the gate that matters here is 'a CDNA GPU': 90 admits gfx90a / gfx942 / gfx950 and nothing older (the kernels are gfx950
+        # only -- the library refuses to load elsewhere, _native.load)
+        return 90
 
     @classmethod
     def get_config_filenames(cls) -> list[str]:
@@ -234,8 +237,9 @@ class ParoQuantLinearMethod(LinearMethodBase):
         n_groups = input_size_per_partition // gs
         qweight = torch.zeros(input_size_per_partition, out // cfg.pack_factor, dtype=torch.int32)
         qzeros = torch.zeros(n_groups, out // cfg.pack_factor, dtype=torch.int32)
-        # scales stay float16 (checkpoint dtype): no bf16 down-cast of the group scales
-        scales = torch.zeros(n_groups, out, dtype=torch.float16)
+        # the group scales take params_dtype, as vLLM's AWQ create_weights (which the reference inherits, plugin.py:183-192) allocates
+        # them: a bf16 model loads the checkpoint's fp16 scales through a bf16 parameter; the repack below converts back to fp16
+        scales = torch.zeros(n_groups, out, dtype=params_dtype if params_dtype in (torch.float16, torch.bfloat16) else torch.float16)
         if HAVE_VLLM:  # pragma: no cover
             layer.register_parameter("qweight", PackedvLLMParameter(
                 data=qweight, input_dim=0, output_dim=1, packed_dim=1, packed_factor=cfg.pack_factor,
@@ -273,7 +277,7 @@ class ParoQuantLinearMethod(LinearMethodBase):
         (as the reference releases them after the Marlin repack, plugin.py:267,276-279)."""
         sizes = list(layer.output_partition_sizes)
         pack = self.quant_config.pack_factor
-        qw, qz, sc = layer.qweight.data, layer.qzeros.data, layer.scales.data
+        qw, qz, sc = layer.qweight.data, layer.qzeros.data, layer.scales.data.to(torch.float16)
         qw, qz, sc, padded = pad_partitions(qw, qz, sc, sizes, pack)   # reference pads to the Marlin tile (plugin.py:210-217)
         layer.paro_packed = PackedParoWeights(qw.contiguous(), qz.contiguous(), sc.contiguous(), layer.theta.data,
                                               layer.pairs.data, layer.channel_scales.data, padded, None,

@@ -32,7 +32,7 @@ run(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     run()
-for p in [int(v) for v in a.positions.split(",")]:
+for p in [int(v) for v in a.positions.split(",") if int(v) < T]:
     pos.fill_(p)
     g.replay(); torch.cuda.synchronize()
     ts = []

@@ -57,6 +57,15 @@ for m in qwen3-4b llama3-8b qwen3-0.6b qwen3.5-9b; do timeout 400 python tools/b
 # ... and with the in-launch K-split reducer instead of the deferred reduction (paroquant_amd/decoder.py), same session
 rm -f $P/${R}_e2e_reducer.jsonl
 for m in qwen3-4b llama3-8b; do PARO_DEFERRED_KSPLIT=0 timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e_reducer.jsonl 2>> $OUT/e2e.err; done
+# ---- decode attention alone: the split launch (merge left to o_proj) and the in-launch merge, short and long caches
+rm -f $P/${R}_attn_split.jsonl
+for t in 264 2048 8192; do
+  timeout 120 python tools/bench_attn.py --tmax $t --positions 0,63,128,255,256,511,700,2047,8191 --split >> $P/${R}_attn_split.jsonl 2>> $OUT/attn.err
+  timeout 120 python tools/bench_attn.py --tmax $t --positions 0,63,128,255,256,511,700,2047,8191 >> $P/${R}_attn_split.jsonl 2>> $OUT/attn.err
+done
+# ... and end to end without it (PARO_SPLIT_ATTN=0), same session
+rm -f $P/${R}_e2e_nosplit.jsonl
+for m in qwen3-4b llama3-8b; do PARO_SPLIT_ATTN=0 timeout 300 python tools/bench_e2e.py --model $m >> $P/${R}_e2e_nosplit.jsonl 2>> $OUT/e2e.err; done
 # ---- deferred K-split reduction per launch and per producer -> consumer pair
 rm -f $P/${R}_parts_micro.jsonl
 for m in qwen3-4b llama3-8b; do timeout 300 python tools/bench_parts.py --model $m >> $P/${R}_parts_micro.jsonl 2>> $OUT/parts.err; done
