@@ -218,6 +218,15 @@ class ParoQwen35DecoderLM:
         self.gdn_ws = torch.zeros(int(nat.load().paro_gdn_workspace_bytes(c.lin_v_heads)), dtype=torch.uint8, device=dev)   # zero-filled once
         self.fused_tail = c.hidden % 512 == 0 and c.hidden <= 4096
         self.bytes_per_token = sum(pk.nbytes() for L in self.layers for pk in (L.mix_in, L.mix_out, L.gate_up, L.down))
+        # deferred K-split reduction (include/paro_abi.h v12; decoder.ParoDecoderLM._layers_deferred): out_proj / o_proj and down_proj leave
+        # their fp32 partial sums, the RMSNorm-prologue launch behind them (gate_up, the next block's in_proj) completes the residual stream
+        from .decoder import deferred_route_pays
+        n_o = min((ops.gemv_parts_count(L.mix_out, dt) for L in self.layers), default=0)
+        n_d = min((ops.gemv_parts_count(L.down, dt) for L in self.layers), default=0)
+        self.deferred = n_o >= 2 and n_d >= 2 and deferred_route_pays(c.hidden)
+        if self.deferred:
+            self.parts_o = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
+            self.parts_d = torch.zeros(c.hidden, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ one decode token (capturable)
     def decode_step(self) -> None:
@@ -227,16 +236,21 @@ class ParoQwen35DecoderLM:
         torch.index_select(self.embed, 0, self.tok, out=self.h)
         h, h2 = self.h, self.h2
         vd = c.lin_v_heads * 128
+        pend = None                      # deferred route: the previous block's down_proj partial sums, not yet in the stream
         with torch.cuda.device(self.device):
             for L in self.layers:
+                # (deferred: the mixer's input projection completes h = h_prev + sum(pend) while it seeds its rotation and stores it)
+                dk = dict(parts_in=pend, x_out=h2.view(-1)) if pend is not None else {}
+                if pend is not None:
+                    h, h2 = h2, h
                 if L.full:
-                    ops.w4a16_gemv_fused(h, L.mix_in, R, c.rms_eps, out=self.qkv)
+                    ops.w4a16_gemv_fused(h2 if pend is not None else h, L.mix_in, R, c.rms_eps, out=self.qkv, **dk)
                     mix = self.mix[:, : c.n_heads * c.head_dim]
                     nat.check(lib.paro_attn_decode_gated(self.qkv.data_ptr(), L.kcache.data_ptr(), L.vcache.data_ptr(), mix.data_ptr(), self.pos.data_ptr(),
                                                          self.rope.data_ptr(), L.q_norm.data_ptr(), L.k_norm.data_ptr(), 1, c.rms_eps, c.head_dim ** -0.5,
                                                          c.n_heads, c.n_kv_heads, c.head_dim, self.rd, c.max_positions, dtc, st))
                 else:
-                    ops.w4a16_gemv_fused(h, L.mix_in, R, c.rms_eps, out=self.qkvz)
+                    ops.w4a16_gemv_fused(h2 if pend is not None else h, L.mix_in, R, c.rms_eps, out=self.qkvz, **dk)
                     mix = self.mix[:, :vd]
                     nat.check(lib.paro_gdn_prep(self.qkvz.data_ptr(), h.data_ptr(), L.w_ab.data_ptr(), c.rms_eps, L.conv_state.data_ptr(), L.conv_w.data_ptr(),
                                                 L.A_log.data_ptr(), L.dt_bias.data_ptr(), self.conv_out.data_ptr(), self.g_beta.data_ptr(), c.hidden,
@@ -244,9 +258,19 @@ class ParoQwen35DecoderLM:
                     nat.check(lib.paro_gdn_step(self.conv_out.data_ptr(), self.qkvz.data_ptr() + 2 * self.conv_dim, self.g_beta.data_ptr(), L.state.data_ptr(),
                                                 L.gdn_norm.data_ptr(), c.rms_eps, mix.data_ptr(), c.lin_k_heads, c.lin_v_heads, dtc,
                                                 self.gdn_ws.data_ptr(), st))
-                ops.w4a16_gemv_fused(mix, L.mix_out, 0, residual=h, out=h2)                     # h2 = h + mixer(x)
-                ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu)
-                ops.w4a16_gemv_fused(self.gu, L.down, S, residual=h2, out=h)                    # h = h2 + mlp(...)
+                if self.deferred:
+                    ops.w4a16_gemv_fused(mix, L.mix_out, 0, parts_out=self.parts_o)
+                    ops.w4a16_gemv_fused(h, L.gate_up, R, c.rms_eps, out=self.gu, parts_in=self.parts_o, x_out=h2.view(-1))   # h2 = h + mixer(x)
+                    h, h2 = h2, h
+                    ops.w4a16_gemv_fused(self.gu, L.down, S, parts_out=self.parts_d)
+                    pend = self.parts_d
+                else:
+                    ops.w4a16_gemv_fused(mix, L.mix_out, 0, residual=h, out=h2)                     # h2 = h + mixer(x)
+                    ops.w4a16_gemv_fused(h2, L.gate_up, R, c.rms_eps, out=self.gu)
+                    ops.w4a16_gemv_fused(self.gu, L.down, S, residual=h2, out=h)                    # h = h2 + mlp(...)
+            if pend is not None:
+                ops.parts_finish(pend, h.view(-1), out=h2.view(-1))
+                h = h2
         if self.fused_tail:
             ops.lm_head(h, self.final_norm, self.lm_head, self.logits, c.rms_eps, self.lm_ws)
             ops.argmax_advance(self.lm_ws, c.vocab, self.tok, self.pos, self.out_tokens)

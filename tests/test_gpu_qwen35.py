@@ -171,3 +171,29 @@ def test_decoder_harness_matches_hf_qwen3_5(dev, tmp_path):
     with torch.no_grad():
         ref_gen = ref_model.generate(ids[None], max_new_tokens=6, do_sample=False)[0]
     assert (toks == ref_gen).float().mean().item() >= 0.9                       # greedy continuations agree (ties aside)
+
+
+@pytest.mark.gpu
+def test_qwen35_harness_deferred_matches_reducer(monkeypatch):
+    """The Qwen3.5 decode harness with the deferred K-split reduction (out_proj / o_proj / down_proj leave partial sums, gate_up and the next
+    block's in_proj complete the residual stream -- also the stream gdn_prep's dense rows read) against the in-launch reducer
+    (PARO_DEFERRED_KSPLIT=0): logits bit for bit and tokens one for one, eager and graph, over both layer kinds."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM, Qwen35Config
+    dev = torch.device("cuda:0")
+    cfg = lambda: Qwen35Config(512, 2048, 8, 2, 256, 4, 16, 4, 640, ["linear_attention", "linear_attention", "linear_attention", "full_attention"],
+                               max_positions=64)            # out_proj 2048 -> 512, o_proj 2048 -> 512, down 2048 -> 512: all K-split
+    ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
+    lm_d = ParoQwen35DecoderLM.random(cfg(), dev, seed=5)
+    assert lm_d.deferred
+    monkeypatch.setenv("PARO_DEFERRED_KSPLIT", "0")
+    lm_r = ParoQwen35DecoderLM.random(cfg(), dev, seed=5)
+    assert not lm_r.deferred
+    for use_graph in (False, True):
+        for lm in (lm_d, lm_r):
+            lm.reset()
+        td, _ = lm_d.generate(ids, 10, use_graph=use_graph)
+        tr, _ = lm_r.generate(ids, 10, use_graph=use_graph)
+        assert torch.equal(td, tr)
+        assert torch.equal(lm_d.logits, lm_r.logits)

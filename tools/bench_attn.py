@@ -40,5 +40,5 @@ for p in [int(v) for v in a.positions.split(",") if int(v) < T]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / a.layers)
-    print(json.dumps({"max_positions": T, "chunk": 128 if a.split else (256 if T <= 512 else 128), "split": bool(a.split), "pos": p, "us_per_launch": round(float(np.median(ts)), 2),
+    print(json.dumps({"max_positions": T, "chunk": (64 if p < 256 else 128) if a.split else (256 if T <= 512 else 128), "split": bool(a.split), "pos": p, "us_per_launch": round(float(np.median(ts)), 2),
                       "dbg": os.environ.get("PARO_ATTN_DBG", "0")}), flush=True)

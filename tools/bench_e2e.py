@@ -28,7 +28,6 @@ def main():
     if args.model in bench.HYBRID:       # Qwen3.5 family: gated delta net + gated head_dim-256 attention (paroquant_amd/decoder_qwen35.py)
         from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM
         lm = ParoQwen35DecoderLM.random(args.model, dev, n_layers=args.layers or None, max_positions=args.prompt + args.new + 8)
-        lm.deferred = False
     else:
         lm = ParoDecoderLM.random(args.model, dev, n_layers=args.layers or None, max_positions=args.prompt + args.new + 8)
     c = lm.cfg
