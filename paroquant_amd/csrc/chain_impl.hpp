@@ -162,6 +162,12 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
   constexpr int NH = PAIR ? 2 : 1;                      // column blocks per workgroup
   constexpr int HW = WAVES / NH;                        // waves per column block
   constexpr int EIT = (MB * 128 + THREADS - 1) / THREADS;   // outputs per thread and block
+  // Output `it` of a thread: the MR accumulator rows of one MFMA lane are MR consecutive `it` -- thread t owns (row quad q, column c) =
+  // (qd >> 7, qd & 127), qd = t + (it / MR) THREADS, and the batch rows q MR + (it % MR) -- so that the waves' partial sums of all MR rows
+  // are ONE LDS access per wave in the reduction (16 rows: 8 writes + 8 reads of 16 bytes per lane instead of 32 + 32 dwords; the
+  // reduction was 1.4 .. 2.0 us of an 8 .. 13 us launch at 16 rows, profiles/r04_chain_timeline_rows16.txt)
+  static_assert(EIT % MR == 0, "a thread's outputs come in groups of MR rows");
+  typedef float vecMR __attribute__((ext_vector_type(MR == 1 ? 1 : MR)));
   constexpr int RR = MB < 2 ? MB : 2;                   // rows per rotation task: two chains interleave well, more rows per task only lengthen its stage chain (tasks are dealt to the waves)
   constexpr int RED_FLOATS = WAVES * 8 * MR * 64;
   constexpr int Z_FLOATS = MB * 128;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < MR; ++r) red[((wave * 8 + j) * MR + r) * 64 + lane] = acc[j][r];
+    for (int r = 0; r < MR; ++r) red[((wave * 8 + j) * 64 + lane) * MR + r] = acc[j][r];   // (MR consecutive floats: merged into one b64 / b128 store)
   // the input's RMSNorm scalar per row
 #pragma unroll
   for (int i = 0; i < SQR; ++i) {
@@ -397,20 +403,34 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
   ts[4] = __builtin_amdgcn_s_memtime();
 #endif
 
+  // (b, c) of output `it`; false when the thread has no such output
+  auto out_bc = [&](int it, int& b, int& c) -> bool {
+    const int qd = tid + (it / MR) * THREADS;
+    c = qd & 127;
+    b = (qd >> 7) * MR + (it % MR);
+    const bool live = b < rows && qd < (MB / MR) * 128;
+    if (!live) b = 0;
+    return live;
+  };
   float v[EIT][NH];
 #pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int e = tid + it * THREADS;
-    const int b = e >> 7, c = e & 127;
-    const int src = ((c >> 4) * MR + (b % MR)) * 64 + (b / MR) * 16 + (c & 15);
+  for (int qi = 0; qi < EIT / MR; ++qi) {
+    const int qd = tid + qi * THREADS;
+    const int c = qd & 127, bq = min(qd >> 7, MB / MR - 1);
+    const int src = (((c >> 4) * 64) + bq * 16 + (c & 15)) * MR;       // tile c >> 4, MFMA lane (row quad, column in the tile)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      float s = 0.f;
-      if (e < rows * 128) {
+      float s[MR];
 #pragma unroll
-        for (int w = 0; w < HW; ++w) s += red[(h * HW + w) * 8 * MR * 64 + src];
+      for (int r = 0; r < MR; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int w = 0; w < HW; ++w) {
+        const vecMR q = *(const vecMR*)(red + (h * HW + w) * 8 * MR * 64 + src);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) s[r] += q[r];
       }
-      v[it][h] = s;
+#pragma unroll
+      for (int r = 0; r < MR; ++r) v[qi * MR + r][h] = s[r];
     }
   }
 
@@ -419,9 +439,8 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
       // producer: ONE write-through 8-byte {tag, fp32 partial} granule per output; no drain, no flag, no fence
 #pragma unroll
       for (int it = 0; it < EIT; ++it) {
-        const int e = tid + it * THREADS;
-        if (e >= rows * 128) continue;
-        const int b = e >> 7, c = e & 127;
+        int b, c;
+        if (!out_bc(it, b, c)) continue;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           const int col = ((PAIR ? a.blk0 + bx + h * a.up_off : bx) << 7) + c;
@@ -448,8 +467,8 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
       for (int spin = 0; !done; ++spin) {
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
-          const int e = min(tid + it * THREADS, rows * 128 - 1);
-          const int b = e >> 7, c = e & 127;
+          int b, c;
+          out_bc(it, b, c);                      // (a thread without this output polls row 0 of its column: in range, never consumed)
 #pragma unroll
           for (int h = 0; h < NH; ++h) {
             const int col = ((PAIR ? a.blk0 + bx + h * a.up_off : bx) << 7) + c;
@@ -493,9 +512,8 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
   // ---- the finished outputs of the block(s): norm scalar, bias, residual, one rounding, store; stage for the rotation
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
-    const int e = tid + it * THREADS;
-    const bool live = e < rows * 128;
-    const int b = live ? (e >> 7) : 0, c = e & 127;
+    int b, c;
+    const bool live = out_bc(it, b, c);
     float yf[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -518,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_kernel(const ChainArgs a_in)
         z = g * yf[1] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * arg));
       }
     }
-    if (live) zs[e] = z;
+    if (live) zs[b * 128 + c] = z;
     if (a.ssq_out) {
       // the block's sum of squares per row: a wave covers 64 consecutive columns of one row (THREADS is a multiple of 128)
       const float s = wave_sum_dpp(live ? yf[0] * yf[0] : 0.f);
