@@ -115,6 +115,11 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
       waves = 16;
     else if (rows > 4 || tpw > 2 || G < 16)
       waves = G >= 8 ? 8 : 4;
+    else if (rows == 1 && tpw == 2 && ksplit == 1 && G <= 24)
+      // 17..24 groups on 2-tile blocks (Qwen3-4B qkv, 2560 -> 6144): sixteen waves leave most of them ONE unit -- no tile request in flight
+      // behind the rotation -- eight waves run two or three (5.41 -> 5.16 us on the build without packed-FP32 ops,
+      // profiles/r04_sweep_qwen3-4b.jsonl; with them the two were level)
+      waves = 8;
     else
       waves = 16;
   }
