@@ -35,7 +35,8 @@ def _case(seed, hd, Hq, Hkv, T, qk_norm, dev, dtype=np.float16):
     return qkv, kc, vc, qw, kw, cos, sin, rope
 
 
-@pytest.mark.parametrize("hd,Hq,Hkv,qk_norm", [(128, 8, 2, True), (64, 4, 2, False), (128, 32, 8, True), (128, 4, 4, False)])
+@pytest.mark.parametrize("hd,Hq,Hkv,qk_norm", [(128, 8, 2, True), (64, 4, 2, False), (128, 32, 8, True), (128, 4, 4, False), (128, 16, 2, True),
+                                             (64, 16, 2, True)])      # (the last two: eight query heads per KV head, Llama-3-70B's ratio)
 @pytest.mark.parametrize("T,pos", [(264, 0), (264, 5), (264, 127), (264, 128), (264, 255), (264, 263), (1024, 300), (1024, 511), (1024, 512),
                                     (1024, 1023), (4096, 2500), (4096, 4095)])
 def test_split_attention_and_finish_match_oracle(dev, hd, Hq, Hkv, qk_norm, T, pos):
@@ -214,3 +215,27 @@ def test_attention_ticket_merge_is_deterministic(dev, split):
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
     assert int(ws.view(torch.int32)[:512].abs().sum()) == 0
+
+
+def test_split_attention_bf16(dev):
+    """bf16 caches and activations through the split launch and its completion (probabilities rounded to bf16 for P V as HF does)."""
+    from paroquant_amd import ops
+    bf = torch.bfloat16
+    hd, Hq, Hkv, T = 128, 16, 4, 1024
+    rng = np.random.default_rng(9)
+    f = lambda t: t.float().cpu().numpy()
+    for pos in (37, 200, 255, 256, 800):
+        qkv = torch.from_numpy(rng.standard_normal((Hq + 2 * Hkv) * hd).astype(np.float32)).to(dev).to(bf)
+        kc = torch.from_numpy(rng.standard_normal((Hkv, T, hd)).astype(np.float32)).to(dev).to(bf)
+        vc = torch.from_numpy(rng.standard_normal((Hkv, T, hd)).astype(np.float32)).to(dev).to(bf)
+        qw = torch.from_numpy((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32)).to(dev).to(bf)
+        kw = torch.from_numpy((1 + 0.2 * rng.standard_normal(hd)).astype(np.float32)).to(dev).to(bf)
+        cos, sin = po.rope_tables(hd, T, 1e4)
+        rope = torch.from_numpy(np.concatenate([cos, sin], axis=-1).astype(np.float32)).to(dev)
+        kct, vct = kc.clone(), vc.transpose(1, 2).contiguous()
+        sp = torch.zeros(ops.attn_parts_floats(Hq, hd), dtype=torch.float32, device=dev)
+        ops.attn_decode(qkv, kct, vct, torch.tensor([pos], dtype=torch.int32, device=dev), rope, Hq, Hkv, hd, qw, kw, 1e-6, split_out=sp)
+        out = ops.attn_finish(sp, Hq, hd, dtype=bf)
+        ref, k_new, v_new = po.attention_decode(f(qkv), f(kc), f(vc), pos, Hq, Hkv, hd, cos, sin, f(qw), f(kw), 1e-6)
+        assert out.dtype == bf and po.rel_err(f(out), ref) < 3e-2, pos          # the bound of test_fused_prologues_and_attention_bf16
+        assert po.rel_err(f(kct[:, pos]), k_new) < 2e-2 and po.rel_err(f(vct[:, :, pos]), v_new) < 1e-6
