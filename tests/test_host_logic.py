@@ -242,7 +242,8 @@ def test_round3_launch_shape_heuristics():
         assert parts(*m["o_proj"]) == 4 and parts(*m["down_proj"]) == 4 and parts(*m["qkv_proj"]) == 2 and parts(*m["gate_up_proj"]) == 0
     assert parts(*q06["o_proj"]) == 2 and parts(*q06["down_proj"]) == 2
     assert parts(*q4["o_proj"], bias=True) == 0
-    assert shape(*q4["qkv_proj"], 1) == (2, 1, 16, 0)          # ... while the ordinary one-row launch of Qwen3-4B's qkv stays unsplit
+    assert shape(*q4["qkv_proj"], 1) == (2, 1, 8, 0)           # ... while the ordinary one-row launch of Qwen3-4B's qkv stays unsplit (8 waves since
+                                                                # the round-4 re-sweep: 17..24 groups on 2-tile blocks, profiles/r04_sweep_qwen3-4b.jsonl)
     # fused family, more than one row (profiles/r03_sweep_rows.jsonl): o_proj 2-tile blocks x 4 splits x 8 waves up to 4 rows, 4 tiles at
     # 5..8; mid-width qkv 4 tiles x 2 splits x 8 waves at 5..8 rows from K = 2048 on
     for m in (l8, q4):
