@@ -285,7 +285,7 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*l8["o_proj"], 1) == (4, 4, 4, 0)
     assert shape(*l8["gate_up_proj"], 1) == (8, 1, 8, 0)
     assert shape(*l8["down_proj"], 1) == (4, 4, 8, 0)
-    assert shape(*q4["qkv_proj"], 1) == (2, 1, 16, 0)
+    assert shape(*q4["qkv_proj"], 1) == (2, 1, 8, 0)       # (20 groups on 2-tile blocks: 8 waves, round-4 re-sweep)
     assert shape(*q4["gate_up_proj"], 1) == (8, 1, 8, 0)
     # 160 column blocks x 4 splits would not be resident at once (2 eight-wave workgroups per CU): clamped to 3
     assert shape(*l70["qkv_proj"], 1) == (4, 3, 8, 0)
