@@ -82,9 +82,11 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj class
     tpw = 4; ksplit = 4;
     waves = G / 4 <= 8 ? 4 : 8;   // 8 groups per split: 4 waves x 2 units beat 8 x 1 (o_proj 7.0 -> 6.6 us on the same box)
-    // more than one row (tools/sweep_gemv.py --rows 2 / 4 / 8, profiles/r03_sweep_rows.jsonl): 8 waves, and 2-tile blocks up to 4 rows
-    // (o_proj Qwen3-4B 6.85 -> 6.17 us at 2 rows, 9.27 -> 7.88 at 8; Llama-3-8B 7.27 -> 6.46, 9.55 -> 8.28)
-    if (rows > 1) { waves = 8; if (rows <= 4) tpw = 2; }
+    // more than four rows (tools/sweep_gemv.py --rows 8, profiles/r03_sweep_rows.jsonl): 8 waves (o_proj Qwen3-4B 9.27 -> 7.88 us at 8 rows,
+    // Llama-3-8B 9.55 -> 8.28).  At 2..4 rows the one-row shape stays ahead on the build without packed-FP32 ops (re-swept in round 4,
+    // profiles/r04_sweep_rows*.jsonl: Qwen3-4B o_proj 6.73 -> 6.22 us at 2 rows, 6.83 -> 6.38 at 4; Llama-3-8B 7.02 -> 6.26, 7.18 -> 6.49;
+    // round 3's 2-tile x 8-wave choice for them dated from the build with packed ops)
+    if (rows > 4) waves = 8;
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
     // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us)
     tpw = 1; ksplit = 2; waves = 8;
@@ -157,7 +159,10 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // (re-measured with the round-2 prologue, Llama-3-8B, us fused / pre-pass: M=6 qkv 11.3 / 13.2, gate_up 19.9 / 20.0;
   // M=8 qkv 11.4 / 13.4, o 10.1 / 13.4, gate_up 21.5 / 20.8, down 17.5 / 16.8; M=12 qkv 16.7 / 14.9, gate_up 47 / 22:
   // below 9 rows only the wide merged projections still prefer the pre-pass)
-  if (mode_auto && (rows > 8 || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
+  // (round 4, profiles/r04_sweep_rows16_*.jsonl: a NARROW single-partition output with K < 8192 -- o_proj: 40 column blocks x 4 K-slices --
+  // replicates so little rotation that the fused form stays ahead up to 16 rows: 11.4 us against 13.5 / 13.7 with the pre-pass)
+  const bool narrow_single = L->n_parts == 1 && L->N / 16 <= 320 && L->K / 128 < 64;
+  if (mode_auto && ((rows > 8 && !narrow_single) || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv, deferred);
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   (void)waves_in;

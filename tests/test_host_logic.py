@@ -244,11 +244,13 @@ def test_round3_launch_shape_heuristics():
     assert parts(*q4["o_proj"], bias=True) == 0
     assert shape(*q4["qkv_proj"], 1) == (2, 1, 8, 0)           # ... while the ordinary one-row launch of Qwen3-4B's qkv stays unsplit (8 waves since
                                                                 # the round-4 re-sweep: 17..24 groups on 2-tile blocks, profiles/r04_sweep_qwen3-4b.jsonl)
-    # fused family, more than one row (profiles/r03_sweep_rows.jsonl): o_proj 2-tile blocks x 4 splits x 8 waves up to 4 rows, 4 tiles at
-    # 5..8; mid-width qkv 4 tiles x 2 splits x 8 waves at 5..8 rows from K = 2048 on
+    # fused family, more than one row: o_proj keeps its one-row shape (4 tiles x 4 splits x 4 waves) up to 4 rows (round-4 re-sweep on the
+    # build without packed-FP32 ops, profiles/r04_sweep_rows*.jsonl), 8 waves at 5..16 rows -- and stays FUSED up to 16 rows (a narrow
+    # single-partition output replicates little rotation); mid-width qkv 4 tiles x 2 splits x 8 waves at 5..8 rows from K = 2048 on
     for m in (l8, q4):
-        assert shape(*m["o_proj"], 2) == (2, 4, 8, 0) and shape(*m["o_proj"], 4) == (2, 4, 8, 0) and shape(*m["o_proj"], 8) == (4, 4, 8, 0)
+        assert shape(*m["o_proj"], 2) == (4, 4, 4, 0) and shape(*m["o_proj"], 4) == (4, 4, 4, 0) and shape(*m["o_proj"], 8) == (4, 4, 8, 0)
         assert shape(*m["o_proj"], 1)[:3] == (4, 4, 4)
+        assert shape(*m["o_proj"], 16)[3] == 0 and shape(*m["down_proj"], 16)[3] == 1 and shape(*m["qkv_proj"], 16)[3] == 1
     assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 0) and shape(*q4["qkv_proj"], 4) == (2, 1, 16, 0)
     # chain family (profiles/r03_chain_shape_sweep_rows.jsonl): deep K 8 slices at <= 8 rows, 5 at <= 16; the others 5 / 4; four groups per
     # slice instead of three (Qwen3-4B o_proj: 8 slices x 4 waves, not 11)
@@ -292,7 +294,7 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*l70["o_proj"], 1) == (4, 4, 8, 0)
     assert shape(*l70["down_proj"], 1) == (8, 4, 8, 0)
     # small batches: fused up to 8 rows (4 for WIDE merged projections), rotate pre-pass above; 17..64 rows always pre-pass
-    assert shape(*l8["o_proj"], 8)[3] == 0 and shape(*l8["o_proj"], 9)[3] == 1
+    assert shape(*l8["o_proj"], 8)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 0 and shape(*l8["down_proj"], 9)[3] == 1     # (o_proj: narrow, one partition: fused to 16 rows)
     assert shape(*l8["qkv_proj"], 8)[3] == 0 and shape(*l8["qkv_proj"], 9)[3] == 1
     assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 5)[3] == 1
     assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
