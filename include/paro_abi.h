@@ -392,6 +392,12 @@ int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, float eps, 
 int64_t paro_gdn_workspace_bytes(int n_v_heads);   /* scratch of paro_gdn_step: zero-filled ONCE by the caller (the arrival tickets return to zero) */
 int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,
                   int n_k_heads, int n_v_heads, int act_dtype, void* workspace, void* stream);
+/* v14: the recurrence of paro_gdn_step over n_tokens tokens in ONE launch (the prompt pass of a gated-delta-net layer): the state is read
+ * once and written once, conv_out [n_tokens][2 key_dim + value_dim] and g_beta [n_tokens][2 n_v_heads] are per-token rows as paro_gdn_prep
+ * lays them out, out_raw fp32 [n_tokens][n_v_heads * 128] receives o = S^T q per token BEFORE the gated RMSNorm (which needs whole heads
+ * and is row-parallel over the tokens: left to the caller, like the causal convolution in front). */
+int paro_gdn_sequence(const void* conv_out, const float* g_beta, float* state, float* out_raw, int n_tokens, int n_k_heads,
+                      int n_v_heads, int act_dtype, void* stream);
 int paro_attn_decode_gated(const void* qkv, void* kcache, void* vcache, void* out, const int32_t* pos, const float* rope,
                            const void* q_norm_w, const void* k_norm_w, int norm_plus_one, float eps, float scale, int n_heads,
                            int n_kv_heads, int head_dim, int rotary_dim, int max_positions, int act_dtype, void* stream);

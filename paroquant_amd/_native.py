@@ -74,6 +74,7 @@ EXPORTS = (
     "paro_gdn_prep",
     "paro_gdn_step",
     "paro_gdn_workspace_bytes",
+    "paro_gdn_sequence",
     "paro_attn_decode_gated",
 )
 
@@ -271,6 +272,8 @@ def load() -> ctypes.CDLL:
     lib.paro_gdn_prep.argtypes = [c_void_p, c_void_p, c_void_p, f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.paro_gdn_step.restype = c_int
     lib.paro_gdn_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, f32, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.paro_gdn_sequence.restype = c_int
+    lib.paro_gdn_sequence.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.paro_gdn_workspace_bytes.restype = c_int64
     lib.paro_gdn_workspace_bytes.argtypes = [c_int]
     lib.paro_attn_decode_gated.restype = c_int

@@ -355,6 +355,106 @@ extern "C" int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, 
   return check_launch("paro_gdn_prep");
 }
 
+namespace paro {
+// Prefill of the gated delta net: the recurrence of gdn_step_kernel over T tokens in ONE launch -- the 128 x 128 state of a value head
+// stays in registers from the first token to the last (read once, written once), which is what a recurrent layer's prompt pass should cost;
+// the token-by-token route moved it through HBM per token (and was 2 launches per token and layer).  Same work split (value heads x 4
+// workgroups of 32 columns), same arithmetic per token, token t + 1's inputs requested while token t is computed.  The gated RMSNorm
+// needs a head's 128 outputs, i.e. all four workgroups: it is left to the caller (raw fp32 outputs [T][nv * 128]), as is the causal
+// convolution in front (both are row-parallel over T: library GEMM / elementwise work, not a recurrence).
+struct GdnSeqArgs {
+  const unsigned short* conv_out;  // [T][2 key_dim + value_dim] after conv + SiLU
+  const float* g_beta;             // [T][2 nv]: decay, beta
+  float* state;                    // [nv][128][128], updated in place
+  float* out_raw;                  // [T][nv * 128] fp32: o = S^T q per token (before the gated norm)
+  int nk, nv, T;
+};
+template <typename AT>
+__global__ __launch_bounds__(256) void gdn_seq_kernel(const GdnSeqArgs a) {
+  typedef Act<AT> A;
+  const int tid = threadIdx.x, vl = tid & 31, ksl = tid >> 5;
+  const int h = blockIdx.x >> 2, c4 = blockIdx.x & 3, v = c4 * 32 + vl;
+  const int kh = h / (a.nv / a.nk);
+  const int key_dim = a.nk * 128, row = 2 * key_dim + a.nv * 128;
+  __shared__ float qs[128], ks[128], part[8][32], nrm[4];
+  float* S = a.state + ((int64_t)h * 128 + ksl * 16) * 128 + v;
+  float s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = S[i * 128];
+  const int d = tid & 127, isk = tid >> 7;
+  auto fetch = [&](int t, unsigned short& xr, unsigned short& vr, float& dec, float& bet) {
+    const unsigned short* r = a.conv_out + (int64_t)t * row;
+    xr = r[(isk ? key_dim : 0) + kh * 128 + d];
+    vr = r[2 * key_dim + h * 128 + v];
+    dec = a.g_beta[(int64_t)t * 2 * a.nv + h];
+    bet = a.g_beta[(int64_t)t * 2 * a.nv + a.nv + h];
+  };
+  unsigned short xr, vr;
+  float decay, beta;
+  fetch(0, xr, vr, decay, beta);
+  for (int t = 0; t < a.T; ++t) {
+    unsigned short xn = 0, vn = 0;
+    float dn = 0.f, bn = 0.f;
+    fetch(min(t + 1, a.T - 1), xn, vn, dn, bn);                      // the next token's inputs are in flight under this one's arithmetic
+    {
+      const float x = A::to_f32(xr);
+      const float ss = wave_total(x * x);
+      if ((tid & 63) == 0) nrm[tid >> 6] = ss;
+      __syncthreads();
+      const float inv = __builtin_amdgcn_rsqf(nrm[2 * isk] + nrm[2 * isk + 1] + 1e-6f);
+      if (isk) ks[d] = x * inv; else qs[d] = x * inv * 0.08838834764831845f;
+    }
+    __syncthreads();
+    float kv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] *= decay;
+      kv = __builtin_fmaf(s[i], ks[ksl * 16 + i], kv);
+    }
+    part[ksl][vl] = kv;
+    __syncthreads();
+    float kvm = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kvm += part[q][vl];
+    const float delta = (A::to_f32(vr) - kvm) * beta;
+    __syncthreads();
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __builtin_fmaf(ks[ksl * 16 + i], delta, s[i]);
+      o = __builtin_fmaf(s[i], qs[ksl * 16 + i], o);
+    }
+    part[ksl][vl] = o;
+    __syncthreads();
+    if (tid < 32) {
+      float of = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) of += part[q][tid];
+      a.out_raw[(int64_t)t * a.nv * 128 + h * 128 + c4 * 32 + tid] = of;
+    }
+    // (no barrier here: nrm / qs / ks / part are next written behind the next token's first, second and third barriers)
+    xr = xn; vr = vn; decay = dn; beta = bn;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) S[i * 128] = s[i];
+}
+}  // namespace paro
+
+extern "C" int paro_gdn_sequence(const void* conv_out, const float* g_beta, float* state, float* out_raw, int n_tokens, int n_k_heads,
+                                 int n_v_heads, int act_dtype, void* stream) {
+  using namespace paro;
+  if (!conv_out || !g_beta || !state || !out_raw) return fail(PARO_ERR_INVALID, "null pointer");
+  if (n_tokens < 1) return fail(PARO_ERR_INVALID, "n_tokens must be >= 1");
+  if (n_k_heads < 1 || n_v_heads < n_k_heads || n_v_heads % n_k_heads) return fail(PARO_ERR_INVALID, "value heads must be a multiple of key heads");
+  GdnSeqArgs a;
+  a.conv_out = (const unsigned short*)conv_out; a.g_beta = g_beta; a.state = state; a.out_raw = out_raw;
+  a.nk = n_k_heads; a.nv = n_v_heads; a.T = n_tokens;
+  if (act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL(gdn_seq_kernel<f16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
+  else if (act_dtype == PARO_DTYPE_BF16) hipLaunchKernelGGL(gdn_seq_kernel<bf16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
+  else return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  return check_launch("paro_gdn_sequence");
+}
+
 extern "C" int64_t paro_gdn_workspace_bytes(int n_v_heads) { return n_v_heads < 1 ? -1 : (int64_t)n_v_heads * (128 + 1) * 4; }
 
 extern "C" int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,

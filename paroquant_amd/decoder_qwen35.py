@@ -314,12 +314,17 @@ class ParoQwen35DecoderLM:
         self._graph = g
 
     @torch.no_grad()
-    def prefill(self, ids: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
-        """The prompt through the decode step, one teacher-forced token at a time; returns the logits of the last position and leaves
-        (tok, pos) at the first generated token."""
+    def prefill(self, ids: torch.Tensor, use_graph: bool = True, sequential: bool = False) -> torch.Tensor:
+        """The prompt pass; returns the logits of the last position and leaves (tok, pos) at the first generated token.  Default: every
+        linear over all T rows at once (the library's prefill GEMM path), the gated delta net's recurrence as ONE launch per layer with the
+        state in registers (``paro_gdn_sequence``), convolution / norms / full attention as row-parallel torch operations
+        (:meth:`_prefill_rows`).  ``sequential=True``: the decode step, one teacher-forced token at a time (what round 4 started with;
+        kept as the cross-check of the row form)."""
         T = int(ids.numel())
         if T > self.cfg.max_positions:
             raise ValueError("prompt longer than max_positions")
+        if not sequential and T >= 2 and os.environ.get("PARO_QWEN35_SEQUENTIAL_PREFILL", "0") != "1":
+            return self._prefill_rows(ids)
         self.reset()
         ids_d = ids.to(self.device)
         if use_graph and self._graph is None:
@@ -332,6 +337,81 @@ class ParoQwen35DecoderLM:
                 self.decode_step()
         self.out_tokens[:T] = ids_d
         return self.logits.clone()
+
+    @torch.no_grad()
+    def _prefill_rows(self, ids: torch.Tensor) -> torch.Tensor:
+        """All T prompt rows at once.  Rounding points follow the decode kernels (csrc/gdn.hip), which follow HF's modelling code
+        (models/qwen3_5: Qwen3_5GatedDeltaNet.forward, Qwen3_5Attention.forward, Qwen3_5RMSNormGated)."""
+        c, dt, dev, lib = self.cfg, self.dtype, self.device, nat.load()
+        T = int(ids.numel())
+        self.reset()
+        ids_d = ids.to(dev)
+        h = self.embed[ids_d]                                                          # [T, hidden]
+        rs = lambda x: torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + c.rms_eps)
+        kd, vd, nk, nv = c.lin_k_heads * 128, c.lin_v_heads * 128, c.lin_k_heads, c.lin_v_heads
+        HD, nh, nkv, rd = c.head_dim, c.n_heads, c.n_kv_heads, self.rd
+        half = rd // 2
+        cos, sin = self.rope[:T, :half][:, None, :], self.rope[:T, half:][:, None, :]   # fp32 [T, 1, half]
+        dtc, st = nat.dtype_code(dt), nat.current_stream_ptr(dev)
+
+        def rope_partial(x):                                                          # x fp32 [T, H, HD] (already normalised, rounded to dt)
+            x1, x2 = x[..., :half], x[..., half:rd]
+            r = torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(dt).float()
+            return torch.cat([r, x[..., rd:]], dim=-1)
+
+        with torch.cuda.device(dev):
+            for L in self.layers:
+                r0 = rs(h)
+                y = (L.mix_in.apply(h).float() * r0).to(dt)                            # the norm's weight is folded into the channel scales
+                if L.full:
+                    qg = y[:, : 2 * nh * HD].view(T, nh, 2, HD)
+                    q, gate = qg[:, :, 0].float(), qg[:, :, 1].float()
+                    k = y[:, 2 * nh * HD: 2 * nh * HD + nkv * HD].view(T, nkv, HD).float()
+                    v = y[:, 2 * nh * HD + nkv * HD:].view(T, nkv, HD)
+                    q = (q * rs(q) * (1.0 + L.q_norm.float())).to(dt).float()         # (1 + w) RMSNorm per head, one rounding
+                    k = (k * rs(k) * (1.0 + L.k_norm.float())).to(dt).float()
+                    q, k = rope_partial(q), rope_partial(k)
+                    L.kcache[:, :T] = k.to(dt).transpose(0, 1)
+                    L.vcache[:, :T] = v.transpose(0, 1)
+                    rep = nh // nkv
+                    kk = k.repeat_interleave(rep, dim=1).transpose(0, 1)               # [nh, T, HD]
+                    vv = v.float().repeat_interleave(rep, dim=1).transpose(0, 1)
+                    sc = torch.matmul(q.transpose(0, 1) * (HD ** -0.5), kk.transpose(1, 2))          # [nh, T, T] fp32
+                    sc = sc.masked_fill(torch.ones(T, T, dtype=torch.bool, device=dev).triu(1), float("-inf"))
+                    att = torch.matmul(torch.softmax(sc, dim=-1), vv).transpose(0, 1)                  # [T, nh, HD]
+                    mix = (att * torch.sigmoid(gate)).to(dt).reshape(T, nh * HD)
+                else:
+                    conv_dim = 2 * kd + vd
+                    xin = y[:, :conv_dim]                                              # [T, conv_dim] the convolution's inputs, z behind them
+                    z = y[:, conv_dim:].float().view(T, nv, 128)
+                    pad = torch.cat([torch.zeros(3, conv_dim, dtype=dt, device=dev), xin], dim=0).float()
+                    w = L.conv_w                                                       # [conv_dim, 4]: taps for inputs t-3 .. t
+                    cv = pad[0:T] * w[:, 0] + pad[1:T + 1] * w[:, 1] + pad[2:T + 2] * w[:, 2] + pad[3:T + 3] * w[:, 3]
+                    conv_out = (cv * torch.sigmoid(cv)).to(dt).contiguous()
+                    last3 = pad[T:T + 3].to(dt)                                        # the state the next token's update reads
+                    L.conv_state[:, 1:4] = last3.transpose(0, 1)
+                    ab = torch.matmul(h.float() * r0, L.w_ab.t())                      # [T, 2 nv]  ((1 + w) folded into w_ab)
+                    tt = ab[:, :nv] + L.dt_bias
+                    g = torch.exp(-torch.exp(L.A_log) * torch.nn.functional.softplus(tt, threshold=20.0))
+                    g_beta = torch.cat([g, torch.sigmoid(ab[:, nv:])], dim=-1).contiguous()
+                    raw = torch.empty(T, vd, dtype=torch.float32, device=dev)
+                    nat.check(lib.paro_gdn_sequence(conv_out.data_ptr(), g_beta.data_ptr(), L.state.data_ptr(), raw.data_ptr(), T, nk, nv, dtc, st))
+                    o = raw.view(T, nv, 128).to(dt).float()                            # Qwen3_5RMSNormGated with gdn_step_kernel's rounding points
+                    n = (o * rs(o)).to(dt).float()
+                    wn = (L.gdn_norm.float() * n).to(dt).float()
+                    mix = (wn * (z * torch.sigmoid(z))).to(dt).reshape(T, vd)
+                h = h + L.mix_out.apply(mix.contiguous())
+                gu = (L.gate_up.apply(h).float() * rs(h)).to(dt)
+                act = (torch.nn.functional.silu(gu[:, : c.inter].float()) * gu[:, c.inter:].float()).to(dt)
+                h = h + L.down.apply(act.contiguous())
+            x = h[-1:].float()
+            xn = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + c.rms_eps) * self.final_norm.float()).to(dt)
+            logits = torch.matmul(xn, self.lm_head.t())
+        self.logits.copy_(logits)
+        self.out_tokens[:T] = ids_d
+        self.tok.copy_(torch.argmax(logits, dim=-1))
+        self.pos.fill_(T)
+        return logits.clone()
 
     @torch.no_grad()
     def generate(self, ids: torch.Tensor, max_new_tokens: int, use_graph: bool = True):

@@ -164,8 +164,13 @@ def test_decoder_harness_matches_hf_qwen3_5(dev, tmp_path):
     assert agree >= 0.9, agree
     # the captured graph replays the same steps bit for bit (states restored around the capture's warm-up), and generate() continues
     eager_logits = got[-1].clone()
-    last = lm.prefill(ids)
+    last = lm.prefill(ids, sequential=True)
     assert torch.equal(last[0], eager_logits)
+    # the row form of the prompt pass (every linear over all T rows, the delta rule as one launch per layer): the same last-position logits
+    # to rounding, and -- against HF -- as close as the token-by-token route
+    last_rows = lm.prefill(ids)
+    assert po.rel_err(_np(last_rows[0]), _np(eager_logits)) < 2e-2
+    assert po.rel_err(_np(last_rows[0]), _np(ref_logits[-1])) < 3e-2
     toks, stats = lm.generate(ids, 6)
     assert toks.shape == (T + 6,) and torch.equal(toks[:T], ids) and stats["decode_tokens_per_s"] > 0
     with torch.no_grad():
@@ -197,3 +202,39 @@ def test_qwen35_harness_deferred_matches_reducer(monkeypatch):
         tr, _ = lm_r.generate(ids, 10, use_graph=use_graph)
         assert torch.equal(td, tr)
         assert torch.equal(lm_d.logits, lm_r.logits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_qwen35_row_prefill_matches_sequential(dtype):
+    """paro_gdn_sequence + the row-parallel prompt pass against the decode step run token by token (the route the HF comparison pins):
+    last-position logits, every layer's recurrent state, convolution state and KV cache, and ten greedy decode steps continued from each."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM, Qwen35Config
+    dev = torch.device("cuda:0")
+    cfg = Qwen35Config(512, 1024, 4, 2, 256, 2, 4, 4, 640, ["linear_attention", "linear_attention", "linear_attention", "full_attention"], max_positions=96)
+    lm = ParoQwen35DecoderLM.random(cfg, dev, seed=11, dtype=dtype)
+    ids = torch.randint(0, 640, (70,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    tol = 2e-2 if dtype == torch.float16 else 8e-2
+    f = lambda t: t.float().cpu().numpy().astype(np.float64)
+    ls = lm.prefill(ids, use_graph=False, sequential=True)
+    snap = [(L.state.clone(), L.conv_state.clone()) if not L.full else (L.kcache.clone(), L.vcache.clone()) for L in lm.layers]
+    seq_logits = [ls.clone()]
+    for _ in range(10):
+        lm.decode_step()
+        seq_logits.append(lm.logits.clone())
+    lr = lm.prefill(ids, use_graph=False)
+    assert int(lm.pos.item()) == 70
+    assert po.rel_err(f(lr), f(ls)) < tol
+    for L, (a, b) in zip(lm.layers, snap):
+        if L.full:
+            assert po.rel_err(f(L.kcache[:, :70]), f(a[:, :70])) < tol and po.rel_err(f(L.vcache[:, :70]), f(b[:, :70])) < tol
+        else:
+            assert po.rel_err(f(L.state), f(a)) < tol
+            assert po.rel_err(f(L.conv_state[:, 1:]), f(b[:, 1:])) < tol
+    lm.tok.copy_(torch.argmax(ls, dim=-1))                      # continue from the SAME token in both routes
+    for i in range(10):
+        lm.decode_step()
+        assert po.rel_err(f(lm.logits), f(seq_logits[i + 1])) < 2 * tol, i
+        lm.tok.copy_(torch.argmax(seq_logits[i + 1], dim=-1))

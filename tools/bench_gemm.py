@@ -48,7 +48,17 @@ def main():
     bad = [v for v in variants if v not in (0, 1, 2, 4)]       # (variant 3 was removed in ABI v11)
     if bad:
         raise SystemExit(f"--variants: unknown GEMM variant(s) {bad}; the library builds 0 (auto), 1, 2 and 4")
-    for name, K, sizes, _ in layer_shapes(args.model):
+    import bench
+    if args.model in bench.HYBRID:       # Qwen3.5 family: the distinct linears of both layer kinds (delta-net block first, then the full-attention block's)
+        shapes, seen = [], set()
+        for full in (False, True):
+            for name, K, sizes, kind in bench.hybrid_layer_shapes(args.model, full):
+                if (K, tuple(sizes)) not in seen:
+                    seen.add((K, tuple(sizes)))
+                    shapes.append((name, K, sizes, kind))
+    else:
+        shapes = layer_shapes(args.model)
+    for name, K, sizes, _ in shapes:
         if args.only and name not in args.only.split(","):
             continue
         pk = synth_packed(K, sizes, dev, gen)

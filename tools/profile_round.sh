@@ -77,6 +77,10 @@ timeout 900 python tools/stress_fused.py 10000 2>&1 | grep -v amdgpu.ids | tail 
 # ---- prefill
 timeout 400 python tools/bench_gemm.py --model llama3-8b --rows 65536 --variants 0 > $P/${R}_prefill_llama3-8b.jsonl 2> $OUT/gemm.err
 timeout 300 python tools/bench_moe.py > $P/${R}_moe_prefill.jsonl 2>> $OUT/gemm.err
+# ---- BASELINE config 3 (Qwen3.5-4B: batch-1 decode + batch 32 x 2048 prefill): the 4B-class hybrid linear set, decode line and prefill TFLOP/s
+timeout 400 python bench.py --workload qwen3.5-4b-class --per-shape --no-cpu-baseline --no-e2e --no-north-star > $OUT/bench_q35_4b.json 2> $OUT/bench_q35_4b.err
+tail -1 $OUT/bench_q35_4b.json > $P/${R}_bench_qwen3.5-4b-class.jsonl; grep us_per_launch $OUT/bench_q35_4b.err >> $P/${R}_bench_qwen3.5-4b-class.jsonl
+timeout 400 python tools/bench_gemm.py --model qwen3.5-4b-class --rows 65536 --variants 0 > $P/${R}_prefill_qwen3.5-4b-class.jsonl 2>> $OUT/gemm.err
 # ---- PMC passes LAST
 cd /tmp
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e --no-route-ab --no-north-star > $OUT/fetch.log 2>&1
