@@ -392,6 +392,15 @@ int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, float eps, 
 int64_t paro_gdn_workspace_bytes(int n_v_heads);   /* scratch of paro_gdn_step: zero-filled ONCE by the caller (the arrival tickets return to zero) */
 int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,
                   int n_k_heads, int n_v_heads, int act_dtype, void* workspace, void* stream);
+/* v14: paro_gdn_prep folded into paro_gdn_step -- one launch per gated-delta-net block and token.  qkvz = the in_proj output [conv_dim +
+ * value_dim] (the convolution's inputs, then z); conv_state is DOUBLE-BUFFERED by the token's parity, act_dtype [2][conv_dim][4]: the launch
+ * reads buffer (*pos & 1) and writes buffer ((*pos + 1) & 1) (workgroups that share a key head compute the same q / k channels: nobody reads
+ * what another workgroup of the launch has written, duplicate writers store identical values); every other argument as in the two calls.
+ * The same arithmetic, operation for operation. */
+int paro_gdn_fused_step(const void* qkvz, const void* x, const float* w_ab, float eps_in, void* conv_state, const float* conv_w,
+                        const float* A_log, const float* dt_bias, float* state, const void* norm_w, float eps, void* out,
+                        const int32_t* pos, int hidden, int conv_dim, int n_k_heads, int n_v_heads, int act_dtype, void* workspace,
+                        void* stream);
 /* v14: the recurrence of paro_gdn_step over n_tokens tokens in ONE launch (the prompt pass of a gated-delta-net layer): the state is read
  * once and written once, conv_out [n_tokens][2 key_dim + value_dim] and g_beta [n_tokens][2 n_v_heads] are per-token rows as paro_gdn_prep
  * lays them out, out_raw fp32 [n_tokens][n_v_heads * 128] receives o = S^T q per token BEFORE the gated RMSNorm (which needs whole heads

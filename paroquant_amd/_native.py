@@ -75,6 +75,7 @@ EXPORTS = (
     "paro_gdn_step",
     "paro_gdn_workspace_bytes",
     "paro_gdn_sequence",
+    "paro_gdn_fused_step",
     "paro_attn_decode_gated",
 )
 
@@ -272,6 +273,9 @@ def load() -> ctypes.CDLL:
     lib.paro_gdn_prep.argtypes = [c_void_p, c_void_p, c_void_p, f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.paro_gdn_step.restype = c_int
     lib.paro_gdn_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, f32, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.paro_gdn_fused_step.restype = c_int
+    lib.paro_gdn_fused_step.argtypes = [c_void_p, c_void_p, c_void_p, f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, f32, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.paro_gdn_sequence.restype = c_int
     lib.paro_gdn_sequence.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.paro_gdn_workspace_bytes.restype = c_int64

@@ -455,6 +455,180 @@ extern "C" int paro_gdn_sequence(const void* conv_out, const float* g_beta, floa
   return check_launch("paro_gdn_sequence");
 }
 
+namespace paro {
+// gdn_prep_kernel folded into gdn_step_kernel: ONE launch per gated-delta-net block and token instead of two (a dependent launch costs
+// ~2.4 us before it does anything; the block's two were 4.7 + 5.3 us).  Every workgroup (value head h, column quarter c4) computes what it
+// needs itself, with the arithmetic of the two kernels operation for operation (same bits):
+//   * the causal convolution of ITS channels -- q and k of the key head (one channel per thread), its 32 value columns -- and their next
+//     state.  The workgroups that share a key head compute the same q / k channels: the convolution state is double-buffered by the
+//     token's parity (read [pos & 1], write [(pos + 1) & 1]), so nobody reads what another workgroup of the launch has written, and the
+//     duplicate writers store identical values;
+//   * the head's two dense rows (in_proj_a, in_proj_b) with the input RMSNorm's scalar: 2 x hidden fp32 weights per workgroup, four times
+//     per head (4 MB instead of 1 MB per layer on Qwen3.5-9B: L2-served after the first reader).
+struct GdnFusedArgs {
+  const unsigned short* qkvz;      // [conv_dim + value_dim]: the convolution's inputs, then z
+  const unsigned short* x;         // [hidden] residual stream in front of the layer
+  const float* w_ab;               // [2 nv][hidden]
+  unsigned short* conv_state;      // [2][conv_dim][4]
+  const float* conv_w;             // [conv_dim][4]
+  const float* A_log;
+  const float* dt_bias;
+  float* state;                    // [nv][128][128]
+  const unsigned short* norm_w;
+  unsigned short* out;             // [value_dim]
+  float* scratch;                  // paro_gdn_workspace_bytes
+  const int* pos;
+  float eps_in, eps;
+  int hidden, conv_dim, nk, nv;
+};
+template <typename AT>
+__global__ __launch_bounds__(256) void gdn_fused_kernel(const GdnFusedArgs a) {
+  typedef Act<AT> A;
+  const int tid = threadIdx.x, vl = tid & 31, ksl = tid >> 5;
+  const int h = blockIdx.x >> 2, c4 = blockIdx.x & 3, v = c4 * 32 + vl;
+  const int kh = h / (a.nv / a.nk);
+  const int key_dim = a.nk * 128;
+  __shared__ float qs[128], ks[128], part[8][32], nrm[4], red[16], vsh[32], gb[2];
+  __shared__ unsigned last;
+  int pos;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.pos) : "memory");
+  const unsigned short* cs_rd = a.conv_state + (int64_t)(pos & 1) * a.conv_dim * 4;
+  unsigned short* cs_wr = a.conv_state + (int64_t)((pos + 1) & 1) * a.conv_dim * 4;
+  float* S = a.state + ((int64_t)h * 128 + ksl * 16) * 128 + v;
+  float s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = S[i * 128];                           // in flight under everything in front of the recurrence
+  // ---- the convolution of this workgroup's channels (gdn_prep_kernel's expression): thread -> one q or k channel; threads 0..31 also a v column
+  const int d = tid & 127, isk = tid >> 7;
+  auto conv = [&](int c) -> float {
+    const u32x2 st = *(const u32x2*)(cs_rd + 4 * c);
+    const f32x4 w = *(const f32x4*)(a.conv_w + 4 * c);
+    const unsigned short xn = a.qkvz[c];
+    const float s0 = A::to_f32(st[0] >> 16), s1 = A::to_f32(st[1] & 0xffffu), s2 = A::to_f32(st[1] >> 16);
+    const float cv = w[0] * s0 + w[1] * s1 + w[2] * s2 + w[3] * A::to_f32(xn);
+    *(u32x2*)(cs_wr + 4 * c) = (u32x2){(st[1] & 0xffffu) << 16, (st[1] >> 16) | ((unsigned)xn << 16)};
+    return A::to_f32(A::from_f32(cv * sigmoidf_(cv)));
+  };
+  const float xqk = conv((isk ? key_dim : 0) + kh * 128 + d);
+  if (tid < 32) vsh[tid] = conv(2 * key_dim + h * 128 + c4 * 32 + tid);
+  // ---- the head's dense rows a, b over the RMS-normalised hidden state (gdn_prep_kernel's row workgroups, two rows here)
+  float dota = 0.f, dotb = 0.f, ssq = 0.f;
+  {
+    const float* wa = a.w_ab + (int64_t)h * a.hidden;
+    const float* wb = a.w_ab + (int64_t)(a.nv + h) * a.hidden;
+    for (int i0 = 0; i0 < a.hidden; i0 += 256 * 16) {
+      const int i = i0 + tid * 16;
+      f32x4 wa4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 wb4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      u32x4 x8[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+      if (i + 16 <= a.hidden) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wa4[q] = *(const f32x4*)(wa + i + 4 * q); wb4[q] = *(const f32x4*)(wb + i + 4 * q); }
+        x8[0] = *(const u32x4*)(a.x + i);
+        x8[1] = *(const u32x4*)(a.x + i + 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned xw = x8[q >> 2][q & 3];
+        const float x0 = A::to_f32(xw & 0xffffu), x1 = A::to_f32(xw >> 16);
+        dota = __builtin_fmaf(wa4[q >> 1][(q & 1) * 2], x0, __builtin_fmaf(wa4[q >> 1][(q & 1) * 2 + 1], x1, dota));
+        dotb = __builtin_fmaf(wb4[q >> 1][(q & 1) * 2], x0, __builtin_fmaf(wb4[q >> 1][(q & 1) * 2 + 1], x1, dotb));
+        ssq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, ssq));
+      }
+    }
+  }
+  dota = wave_total(dota);
+  dotb = wave_total(dotb);
+  ssq = wave_total(ssq);
+  {
+    // q / k l2-norm statistics (gdn_step_kernel) ride on the same barrier
+    const float ss = wave_total(xqk * xqk);
+    if ((tid & 63) == 0) { red[tid >> 6] = dota; red[4 + (tid >> 6)] = dotb; red[8 + (tid >> 6)] = ssq; nrm[tid >> 6] = ss; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float sa = red[0] + red[1] + red[2] + red[3], sb = red[4] + red[5] + red[6] + red[7], sq = red[8] + red[9] + red[10] + red[11];
+    const float rstd = __builtin_amdgcn_rsqf(sq / (float)a.hidden + a.eps_in);
+    const float t = sa * rstd + a.dt_bias[h];
+    const float sp = t > 20.f ? t : log1pf(__expf(t));
+    gb[0] = __expf(-__expf(a.A_log[h]) * sp);
+    gb[1] = sigmoidf_(sb * rstd);
+  }
+  {
+    const float inv = __builtin_amdgcn_rsqf(nrm[2 * isk] + nrm[2 * isk + 1] + 1e-6f);
+    if (isk) ks[d] = xqk * inv; else qs[d] = xqk * inv * 0.08838834764831845f;
+  }
+  __syncthreads();
+  const float decay = gb[0], beta = gb[1];
+  float kv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s[i] *= decay;
+    kv = __builtin_fmaf(s[i], ks[ksl * 16 + i], kv);
+  }
+  part[ksl][vl] = kv;
+  __syncthreads();
+  float kvm = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) kvm += part[q][vl];
+  const float delta = (vsh[vl] - kvm) * beta;
+  __syncthreads();
+  float o = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s[i] = __builtin_fmaf(ks[ksl * 16 + i], delta, s[i]);
+    o = __builtin_fmaf(s[i], qs[ksl * 16 + i], o);
+    S[i * 128] = s[i];
+  }
+  part[ksl][vl] = o;
+  __syncthreads();
+  float* raw = a.scratch + (int64_t)h * 128;
+  unsigned* ticket = (unsigned*)(a.scratch + (int64_t)a.nv * 128) + h;
+  if (tid < 32) {
+    float of = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) of += part[q][tid];
+    __hip_atomic_store(raw + c4 * 32 + tid, of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last || tid >= 128) return;
+  const float of = A::to_f32(A::from_f32(__hip_atomic_load(raw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  const float ss = wave_total(of * of);
+  if ((tid & 63) == 0) nrm[tid >> 6] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const float n = A::to_f32(A::from_f32(of * __builtin_amdgcn_rsqf((nrm[0] + nrm[1]) / 128.f + a.eps)));
+  const float wn = A::to_f32(A::from_f32(A::to_f32(a.norm_w[tid]) * n));
+  const float zf = A::to_f32(a.qkvz[a.conv_dim + h * 128 + tid]);
+  a.out[h * 128 + tid] = A::from_f32(wn * (zf * sigmoidf_(zf)));
+}
+}  // namespace paro
+
+extern "C" int paro_gdn_fused_step(const void* qkvz, const void* x, const float* w_ab, float eps_in, void* conv_state, const float* conv_w,
+                                   const float* A_log, const float* dt_bias, float* state, const void* norm_w, float eps, void* out,
+                                   const int32_t* pos, int hidden, int conv_dim, int n_k_heads, int n_v_heads, int act_dtype, void* workspace,
+                                   void* stream) {
+  using namespace paro;
+  if (!qkvz || !x || !w_ab || !conv_state || !conv_w || !A_log || !dt_bias || !state || !norm_w || !out || !pos || !workspace)
+    return fail(PARO_ERR_INVALID, "null pointer");
+  if (hidden < 16 || hidden % 16 || conv_dim < 1) return fail(PARO_ERR_INVALID, "bad geometry (hidden must be a multiple of 16)");
+  if (n_k_heads < 1 || n_v_heads < n_k_heads || n_v_heads % n_k_heads) return fail(PARO_ERR_INVALID, "value heads must be a multiple of key heads");
+  if (conv_dim != 2 * n_k_heads * 128 + n_v_heads * 128) return fail(PARO_ERR_INVALID, "conv_dim must be (2 key heads + value heads) x 128");
+  GdnFusedArgs a;
+  a.qkvz = (const unsigned short*)qkvz; a.x = (const unsigned short*)x; a.w_ab = w_ab; a.conv_state = (unsigned short*)conv_state; a.conv_w = conv_w;
+  a.A_log = A_log; a.dt_bias = dt_bias; a.state = state; a.norm_w = (const unsigned short*)norm_w; a.out = (unsigned short*)out;
+  a.scratch = (float*)workspace; a.pos = pos; a.eps_in = eps_in; a.eps = eps; a.hidden = hidden; a.conv_dim = conv_dim; a.nk = n_k_heads; a.nv = n_v_heads;
+  if (act_dtype == PARO_DTYPE_F16) hipLaunchKernelGGL(gdn_fused_kernel<f16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
+  else if (act_dtype == PARO_DTYPE_BF16) hipLaunchKernelGGL(gdn_fused_kernel<bf16>, dim3((unsigned)n_v_heads * 4), dim3(256), 0, (hipStream_t)stream, a);
+  else return fail(PARO_ERR_INVALID, "act_dtype must be f16 or bf16");
+  return check_launch("paro_gdn_fused_step");
+}
+
 extern "C" int64_t paro_gdn_workspace_bytes(int n_v_heads) { return n_v_heads < 1 ? -1 : (int64_t)n_v_heads * (128 + 1) * 4; }
 
 extern "C" int paro_gdn_step(const void* conv_out, const void* z, const float* g_beta, float* state, const void* norm_w, float eps, void* out,

@@ -94,7 +94,7 @@ class ParoQwen35DecoderLM:
             L.vcache = torch.zeros(c.n_kv_heads, c.max_positions, c.head_dim, dtype=dt, device=dev)
         else:
             conv_dim = 2 * c.lin_k_heads * 128 + c.lin_v_heads * 128
-            L.conv_state = torch.zeros(conv_dim, 4, dtype=dt, device=dev)
+            L.conv_state = torch.zeros(2, conv_dim, 4, dtype=dt, device=dev)       # double-buffered by the token's parity (paro_gdn_fused_step)
             L.state = torch.zeros(c.lin_v_heads, 128, 128, dtype=torch.float32, device=dev)
         self.layers.append(L)
 
@@ -252,12 +252,11 @@ class ParoQwen35DecoderLM:
                 else:
                     ops.w4a16_gemv_fused(h2 if pend is not None else h, L.mix_in, R, c.rms_eps, out=self.qkvz, **dk)
                     mix = self.mix[:, :vd]
-                    nat.check(lib.paro_gdn_prep(self.qkvz.data_ptr(), h.data_ptr(), L.w_ab.data_ptr(), c.rms_eps, L.conv_state.data_ptr(), L.conv_w.data_ptr(),
-                                                L.A_log.data_ptr(), L.dt_bias.data_ptr(), self.conv_out.data_ptr(), self.g_beta.data_ptr(), c.hidden,
-                                                self.conv_dim, c.lin_v_heads, dtc, st))
-                    nat.check(lib.paro_gdn_step(self.conv_out.data_ptr(), self.qkvz.data_ptr() + 2 * self.conv_dim, self.g_beta.data_ptr(), L.state.data_ptr(),
-                                                L.gdn_norm.data_ptr(), c.rms_eps, mix.data_ptr(), c.lin_k_heads, c.lin_v_heads, dtc,
-                                                self.gdn_ws.data_ptr(), st))
+                    # conv1d update + the dense a / b rows + the recurrence + the gated norm: one launch (gdn.hip: gdn_fused_kernel)
+                    nat.check(lib.paro_gdn_fused_step(self.qkvz.data_ptr(), h.data_ptr(), L.w_ab.data_ptr(), c.rms_eps, L.conv_state.data_ptr(),
+                                                      L.conv_w.data_ptr(), L.A_log.data_ptr(), L.dt_bias.data_ptr(), L.state.data_ptr(),
+                                                      L.gdn_norm.data_ptr(), c.rms_eps, mix.data_ptr(), self.pos.data_ptr(), c.hidden, self.conv_dim,
+                                                      c.lin_k_heads, c.lin_v_heads, dtc, self.gdn_ws.data_ptr(), st))
                 if self.deferred:
                     ops.w4a16_gemv_fused(mix, L.mix_out, 0, parts_out=self.parts_o)
                     ops.w4a16_gemv_fused(h, L.gate_up, R, c.rms_eps, out=self.gu, parts_in=self.parts_o, x_out=h2.view(-1))   # h2 = h + mixer(x)
@@ -389,7 +388,7 @@ class ParoQwen35DecoderLM:
                     cv = pad[0:T] * w[:, 0] + pad[1:T + 1] * w[:, 1] + pad[2:T + 2] * w[:, 2] + pad[3:T + 3] * w[:, 3]
                     conv_out = (cv * torch.sigmoid(cv)).to(dt).contiguous()
                     last3 = pad[T:T + 3].to(dt)                                        # the state the next token's update reads
-                    L.conv_state[:, 1:4] = last3.transpose(0, 1)
+                    L.conv_state[T & 1][:, 1:4] = last3.transpose(0, 1)             # (the buffer the token at position T reads)
                     ab = torch.matmul(h.float() * r0, L.w_ab.t())                      # [T, 2 nv]  ((1 + w) folded into w_ab)
                     tt = ab[:, :nv] + L.dt_bias
                     g = torch.exp(-torch.exp(L.A_log) * torch.nn.functional.softplus(tt, threshold=20.0))

@@ -232,9 +232,92 @@ def test_qwen35_row_prefill_matches_sequential(dtype):
             assert po.rel_err(f(L.kcache[:, :70]), f(a[:, :70])) < tol and po.rel_err(f(L.vcache[:, :70]), f(b[:, :70])) < tol
         else:
             assert po.rel_err(f(L.state), f(a)) < tol
-            assert po.rel_err(f(L.conv_state[:, 1:]), f(b[:, 1:])) < tol
+            assert po.rel_err(f(L.conv_state[70 & 1][:, 1:]), f(b[70 & 1][:, 1:])) < tol      # (the buffer the token at position 70 reads)
     lm.tok.copy_(torch.argmax(ls, dim=-1))                      # continue from the SAME token in both routes
     for i in range(10):
         lm.decode_step()
         assert po.rel_err(f(lm.logits), f(seq_logits[i + 1])) < 2 * tol, i
         lm.tok.copy_(torch.argmax(seq_logits[i + 1], dim=-1))
+
+
+def _gdn_reference(qkv, x, w_ab, eps_in, st3, conv_w, A_log, dt_bias, S, norm_w, eps, z, nk, nv):
+    """float64 restatement of one token of the gated delta net (transformers models/qwen3_5: causal_conv1d_update + SiLU,
+    torch_recurrent_gated_delta_rule for one step, Qwen3_5RMSNormGated); st3 = the last three convolution inputs, oldest first."""
+    kd = nk * 128
+    cv = conv_w[:, 0] * st3[:, 0] + conv_w[:, 1] * st3[:, 1] + conv_w[:, 2] * st3[:, 2] + conv_w[:, 3] * qkv
+    co = cv / (1.0 + np.exp(-cv))
+    xn = x / np.sqrt((x * x).mean() + eps_in)
+    ab = w_ab @ xn
+    tt = ab[:nv] + dt_bias
+    g = np.exp(-np.exp(A_log) * np.where(tt > 20.0, tt, np.log1p(np.exp(np.minimum(tt, 20.0)))))
+    beta = 1.0 / (1.0 + np.exp(-ab[nv:]))
+    out = np.zeros((nv, 128))
+    S2 = S.copy()
+    for h in range(nv):
+        kh = h // (nv // nk)
+        q, k, v = co[kh * 128:(kh + 1) * 128], co[kd + kh * 128: kd + (kh + 1) * 128], co[2 * kd + h * 128: 2 * kd + (h + 1) * 128]
+        q = q / np.sqrt((q * q).sum() + 1e-6) * 128 ** -0.5
+        k = k / np.sqrt((k * k).sum() + 1e-6)
+        Sh = S2[h] * g[h]
+        delta = (v - Sh.T @ k) * beta[h]
+        Sh = Sh + np.outer(k, delta)
+        S2[h] = Sh
+        o = Sh.T @ q
+        n = o / np.sqrt((o * o).mean() + eps) * norm_w
+        zz = z[h * 128:(h + 1) * 128]
+        out[h] = n * (zz / (1.0 + np.exp(-zz)))
+    return out.reshape(-1), S2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nk,nv,hidden", [(2, 4, 512), (16, 32, 4096), (4, 4, 1024)])
+def test_gdn_fused_step_matches_the_two_launches_and_the_reference(nk, nv, hidden):
+    """paro_gdn_fused_step (one launch per delta-net block) against paro_gdn_prep -> paro_gdn_step (two) on the same inputs, over four
+    consecutive tokens (both parities of the double-buffered convolution state), and against a float64 restatement of HF's single-token path."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(nk + nv)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    kd, vd = nk * 128, nv * 128
+    cd = 2 * kd + vd
+    w_ab = (rnd(2 * nv, hidden) * 0.05).contiguous()
+    conv_w = (rnd(cd, 4) * 0.3).contiguous()
+    A_log = torch.log(torch.rand(nv, device=dev, generator=g) * 7.0 + 1.0)
+    dt_bias = rnd(nv) * 0.1
+    norm_w = (1.0 + 0.05 * rnd(128)).half()
+    S0 = (rnd(nv, 128, 128) * 0.1).contiguous()
+    cs0 = (rnd(cd, 4) * 0.5).half()
+    st = nat.current_stream_ptr(dev)
+    ws = lambda: torch.zeros(int(lib.paro_gdn_workspace_bytes(nv)), dtype=torch.uint8, device=dev)
+    # route A: two launches, single-buffered state; route B: fused, double-buffered (token 0 reads buffer 0)
+    csA, SA, wsA = cs0.clone(), S0.clone(), ws()
+    csB = torch.zeros(2, cd, 4, dtype=torch.float16, device=dev); csB[0] = cs0
+    SB, wsB = S0.clone(), ws()
+    conv_out, g_beta = torch.empty(cd, dtype=torch.float16, device=dev), torch.empty(2 * nv, dtype=torch.float32, device=dev)
+    outA, outB = torch.empty(vd, dtype=torch.float16, device=dev), torch.empty(vd, dtype=torch.float16, device=dev)
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    f64 = lambda t: t.double().cpu().numpy()
+    S_ref, st3 = f64(S0), f64(cs0)[:, 1:4]
+    for t in range(4):
+        qkvz = (rnd(cd + vd) * 0.8).half().contiguous()
+        x = rnd(hidden).half().contiguous()
+        pos.fill_(t)
+        nat.check(lib.paro_gdn_prep(qkvz.data_ptr(), x.data_ptr(), w_ab.data_ptr(), 1e-6, csA.data_ptr(), conv_w.data_ptr(), A_log.data_ptr(),
+                                    dt_bias.data_ptr(), conv_out.data_ptr(), g_beta.data_ptr(), hidden, cd, nv, nat.DTYPE_F16, st))
+        nat.check(lib.paro_gdn_step(conv_out.data_ptr(), qkvz.data_ptr() + 2 * cd, g_beta.data_ptr(), SA.data_ptr(), norm_w.data_ptr(), 1e-6,
+                                    outA.data_ptr(), nk, nv, nat.DTYPE_F16, wsA.data_ptr(), st))
+        nat.check(lib.paro_gdn_fused_step(qkvz.data_ptr(), x.data_ptr(), w_ab.data_ptr(), 1e-6, csB.data_ptr(), conv_w.data_ptr(), A_log.data_ptr(),
+                                          dt_bias.data_ptr(), SB.data_ptr(), norm_w.data_ptr(), 1e-6, outB.data_ptr(), pos.data_ptr(), hidden, cd, nk, nv,
+                                          nat.DTYPE_F16, wsB.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(csB[(t + 1) & 1][:, 1:], csA[:, 1:]), t                 # the convolution state moves identically
+        assert po.rel_err(f64(outB), f64(outA)) < 2e-3 and po.rel_err(f64(SB), f64(SA)) < 1e-5, t      # same arithmetic (fp contraction may differ)
+        ref, S_ref = _gdn_reference(f64(qkvz[:cd]), f64(x), f64(w_ab), 1e-6, st3, f64(conv_w), f64(A_log), f64(dt_bias), S_ref, f64(norm_w), 1e-6,
+                                    f64(qkvz[cd:]), nk, nv)
+        st3 = np.concatenate([st3[:, 1:], f64(qkvz[:cd])[:, None]], axis=1)
+        assert po.rel_err(f64(outB), ref) < 1e-2 and po.rel_err(f64(SB), S_ref) < 5e-3, t
+    assert int(wsB.view(torch.int32)[nv * 128:].abs().sum()) == 0                  # tickets back at zero
