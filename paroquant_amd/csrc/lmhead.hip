@@ -5,9 +5,21 @@
 // One wave per 4 rows at a time, 16-byte non-temporal loads, fp32 accumulation; every workgroup also leaves its
 // (max logit, lowest index) pair, and a one-workgroup second kernel reduces those, appends the consumed token to the
 // output sequence and advances the position -- the three torch launches (index_copy, argmax, add) it replaces.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace paro {
+
+// acc + w.lo * x.lo + w.hi * x.hi on two packed activations (v_dot2c_f32_f16 / v_dot2c_f32_bf16: fp32 accumulation): the row products
+// were a convert + an FMA per element -- ~50 us of VALU issue per Qwen3.5 token beside 208 us of streaming at one or two waves per SIMD
+template <typename AT>
+__device__ __forceinline__ float dot2_acc(unsigned w, unsigned x, float acc) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  if constexpr (std::is_same<AT, f16>::value) return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), __builtin_bit_cast(h2, x), acc, false);
+  else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w), __builtin_bit_cast(b2, x), acc, false);
+}
 
 constexpr int kLmRowsPerWg = 64;   // 4 waves x 4 passes x 4 rows
 
@@ -45,6 +57,7 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const LmHeadArgs a) {
   load_rows(row0 + wave * 16);
   // x, its RMS statistic, the normalised vector of this lane's chunks (kept in registers as fp32)
   float xn[CH][8];
+  unsigned xh[CH][4];            // the normalised vector as packed activations (what HF's RMSNorm returns: already rounded)
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
@@ -66,6 +79,7 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const LmHeadArgs a) {
     for (int e = 0; e < 4; ++e) {
       xn[c][2 * e] = A::to_f32(A::from_f32(A::to_f32(A::from_f32(xn[c][2 * e] * r)) * A::to_f32(wv[e] & 0xffffu)));
       xn[c][2 * e + 1] = A::to_f32(A::from_f32(A::to_f32(A::from_f32(xn[c][2 * e + 1] * r)) * A::to_f32(wv[e] >> 16)));
+      xh[c][e] = (unsigned)A::from_f32(xn[c][2 * e]) | ((unsigned)A::from_f32(xn[c][2 * e + 1]) << 16);
     }
   }
   float best = -3.0e38f;
@@ -78,10 +92,7 @@ __global__ __launch_bounds__(256) void lm_head_kernel(const LmHeadArgs a) {
 #pragma unroll
       for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[q] = __builtin_fmaf(A::to_f32(w[q][c][e] & 0xffffu), xn[c][2 * e], acc[q]);
-          acc[q] = __builtin_fmaf(A::to_f32(w[q][c][e] >> 16), xn[c][2 * e + 1], acc[q]);
-        }
+        for (int e = 0; e < 4; ++e) acc[q] = dot2_acc<AT>(w[q][c][e], xh[c][e], acc[q]);
     if (pass < 3) load_rows(r0 + 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
