@@ -88,8 +88,10 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // round 3's 2-tile x 8-wave choice for them dated from the build with packed ops)
     if (rows > 4) waves = 8;
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
-    // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us)
-    tpw = 1; ksplit = 2; waves = 8;
+    // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us).
+    // Re-swept in round 4 on the build without packed-FP32 ops (profiles/r04_sweep_qwen3-0.6b.jsonl): below 24 groups the in-launch
+    // hand-off no longer pays -- o_proj (16 groups) unsplit 3.89 us against 4.20 -- unless the splits leave partial sums (`deferred`)
+    tpw = 1; ksplit = (G >= 24 || deferred) ? 2 : 1; waves = 8;
   } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= ((deferred && rows == 1) || rows > 4 ? 16 : 32)) {
     // mid-width outputs with K >= 4096 (Llama-3-8B qkv: 384 tiles x 32 groups): 96 fat column blocks x 2 splits halve
     // the replicated rotation; pays since the reducer polls all splits at once (7.10 -> 6.71 us; at G = 20, Qwen3-4B
@@ -116,7 +118,9 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     if (tpw == 4 && tiles >= 768 && tiles < 1024 && G >= 64 && rows <= 4)
       waves = 16;
     else if (rows > 4 || tpw > 2 || G < 16)
-      waves = G >= 8 ? 8 : 4;
+      // (eight groups or fewer per workgroup at up to four rows: four waves run two units each instead of eight running one -- Qwen3-0.6B
+      // qkv 3.42 -> 3.29 us, gate_up 3.84 -> 3.43, profiles/r04_sweep_qwen3-0.6b.jsonl)
+      waves = (G >= 16 || (G >= 8 && (rows > 4 || tpw > 2))) ? 8 : 4;
     else if (rows == 1 && tpw == 2 && ksplit == 1 && G <= 24)
       // 17..24 groups on 2-tile blocks (Qwen3-4B qkv, 2560 -> 6144): sixteen waves leave most of them ONE unit -- no tile request in flight
       // behind the rotation -- eight waves run two or three (5.41 -> 5.16 us on the build without packed-FP32 ops,

@@ -1343,7 +1343,10 @@ def test_decoder_harness_deferred_matches_reducer(dev, dtype, monkeypatch):
     """One GPU: o / down leave their K-split partial sums to the RMSNorm-prologue launch behind them (decoder._layers_deferred) --
     logits bit for bit and tokens one for one what the in-launch reducer route (PARO_DEFERRED_KSPLIT=0) gives, eager and graph."""
     from paroquant_amd.decoder import ParoDecoderLM, DecoderConfig
-    cfg = lambda: DecoderConfig(512, 2048, 16, 2, 128, 3, 640, 1e-6, 10000.0, True, 64)     # o: 2048 -> 512, down: 2048 -> 512: both K-split
+    # o: 3072 -> 512, down: 3072 -> 512 -- 24 groups each: the automatic per-call shape K-splits them 2-way like the deferred route does
+    # (below 24 groups the per-call route no longer splits at all -- round-4 re-sweep, gemv.hip -- and the two routes then differ by the
+    # summation order, i.e. at rounding level)
+    cfg = lambda: DecoderConfig(512, 3072, 24, 4, 128, 3, 640, 1e-6, 10000.0, True, 64)
     ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
     monkeypatch.setenv("PARO_DEFERRED_QKV", "0")           # (the 2-way qkv changes qkv's own summation order: its own test below)
     monkeypatch.setenv("PARO_SPLIT_ATTN", "0")             # (the split attention merges 128-position slots: another rounding, its own test below)

@@ -187,8 +187,9 @@ def test_qwen35_harness_deferred_matches_reducer(monkeypatch):
         pytest.skip("needs a GPU")
     from paroquant_amd.decoder_qwen35 import ParoQwen35DecoderLM, Qwen35Config
     dev = torch.device("cuda:0")
-    cfg = lambda: Qwen35Config(512, 2048, 8, 2, 256, 4, 16, 4, 640, ["linear_attention", "linear_attention", "linear_attention", "full_attention"],
-                               max_positions=64)            # out_proj 2048 -> 512, o_proj 2048 -> 512, down 2048 -> 512: all K-split
+    cfg = lambda: Qwen35Config(512, 3072, 12, 2, 256, 4, 24, 4, 640, ["linear_attention", "linear_attention", "linear_attention", "full_attention"],
+                               max_positions=64)            # out_proj, o_proj, down: 3072 -> 512, 24 groups: K-split 2-way by both routes
+                                                            # (below 24 groups the per-call route does not split: rounding-level differences)
     ids = torch.tensor([3, 17, 101, 7, 250, 9, 33], device=dev)
     lm_d = ParoQwen35DecoderLM.random(cfg(), dev, seed=5)
     assert lm_d.deferred
