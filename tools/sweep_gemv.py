@@ -45,7 +45,17 @@ def main():
     ksps = [int(k) for k in args.ksplit.split(",")]
     wvs = [int(k) for k in args.waves.split(",")]
     modes = [int(k) for k in args.mode.split(",")]
-    for name, K, sizes, _ in layer_shapes(args.model, args.tp):
+    import bench
+    if args.model in bench.HYBRID:       # Qwen3.5 family: the distinct linears of both layer kinds
+        shapes, seen = [], set()
+        for full in (False, True):
+            for nm, K_, sz_, kind in bench.hybrid_layer_shapes(args.model, full, args.tp):
+                if (K_, tuple(sz_)) not in seen:
+                    seen.add((K_, tuple(sz_)))
+                    shapes.append((nm, K_, sz_, kind))
+    else:
+        shapes = layer_shapes(args.model, args.tp)
+    for name, K, sizes, _ in shapes:
         nb = alg_bytes(K, sum(sizes), len(sizes))
         copies = max(2, min(48, int((1 << 30) // nb) + 1))
         if args.only and name not in args.only.split(","):
