@@ -92,10 +92,13 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // Re-swept in round 4 on the build without packed-FP32 ops (profiles/r04_sweep_qwen3-0.6b.jsonl): below 24 groups the in-launch
     // hand-off no longer pays -- o_proj (16 groups) unsplit 3.89 us against 4.20 -- unless the splits leave partial sums (`deferred`)
     tpw = 1; ksplit = (G >= 24 || deferred) ? 2 : 1; waves = 8;
-  } else if (auto_tpw && auto_ks && auto_wv && !deferred && rows == 1 && tiles >= 512 && tiles < 1024 && G >= 16 && G < 64) {
+  } else if (auto_tpw && auto_ks && auto_wv && !deferred && rows == 1 && tiles > 512 && tiles < 1024 && G >= 16 && G < 64) {
     // almost-wide merged projections (the Qwen3.5 family's in_proj_qkvz 768 tiles, gated qkv 640): 4-tile blocks -- 160..192 of them --
     // unsplit below 32 groups (4B-class, K = 2560: 7.39 -> 6.10 us and 7.28 -> 5.99 against 2-tile blocks), four K-slices of four waves
-    // from 32 groups on (9B, K = 4096: 8.91 -> 8.08 and 8.86 -> 7.93 against 2 slices of eight); profiles/r04_sweep_qwen3.5-*.jsonl
+    // from 32 groups on (9B, K = 4096: 8.91 -> 8.08 and 8.86 -> 7.93 against 2 slices of eight); profiles/r04_sweep_qwen3.5-*.jsonl.
+    // The pattern behind the unsplit choices: the fewest tiles per wave that still give at most 256 column blocks -- ONE round of
+    // workgroups over the 256 CUs (384 tiles: 2 -> 192 blocks; 512: 2 -> 256; 640 / 768: 4 -> 160 / 192; 1216 / 1792: 8 -> 152 / 224).
+    // Exactly 512 tiles stay on 2-tile blocks (Llama-3-70B TP = 4 o_proj 2048 -> 8192: 4.67 us against 5.32 on 4-tile blocks)
     tpw = 4;
     if (G >= 32) { ksplit = 4; waves = 4; } else { ksplit = 1; waves = 8; }
   } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= ((deferred && rows == 1) || rows > 4 ? 16 : 32)) {
@@ -114,7 +117,7 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
       // 8192 -> 14336: unsplit 4 x 16 waves 15.0 us, 2 x 16 waves 18.7 (profiles/r02_sweep_llama3-70b_tp4.jsonl;
       // the fused launch read 19.0 with the 2-tile shape, profiles/r02_fused_tp4.jsonl)
       tpw = 4;
-    else if (tiles >= 512 && rows == 1)
+    else if (tiles > 512 && rows == 1)
       tpw = 4;      // (a caller that fixes ksplit = 1 on an almost-wide output: the same 4-tile blocks as the automatic shape above)
     else if (tiles >= 320)
       tpw = 2;
