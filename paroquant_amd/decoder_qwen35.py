@@ -207,8 +207,6 @@ class ParoQwen35DecoderLM:
         kd, vd = c.lin_k_heads * 128, c.lin_v_heads * 128
         self.conv_dim = 2 * kd + vd
         self.qkvz = torch.zeros(1, self.conv_dim + vd, dtype=dt, device=dev)
-        self.conv_out = torch.zeros(self.conv_dim, dtype=dt, device=dev)
-        self.g_beta = torch.zeros(2 * c.lin_v_heads, dtype=torch.float32, device=dev)
         self.qkv = torch.zeros(1, (2 * c.n_heads + 2 * c.n_kv_heads) * c.head_dim, dtype=dt, device=dev)
         self.mix = torch.zeros(1, max(vd, c.n_heads * c.head_dim), dtype=dt, device=dev)
         self.gu = torch.zeros(1, 2 * c.inter, dtype=dt, device=dev)
