@@ -78,7 +78,14 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // blocks of 4 tiles -> no K-split (TP = 4 gate_up 8192 -> 14336: 16.9 -> 15.0 us); very narrow (TP = 8 qkv
     // 8192 -> 1280: 80 tiles) -> 2-tile blocks, 16 waves (6.7 -> 6.0 us)
     if (tiles >= 768 && G < 128 && rows <= 4) { tpw = 4; ksplit = 1; waves = 16; }
-    else if (tiles < 128 && rows <= 4) { tpw = 2; waves = 16; }
+    // (re-swept in round 4: 16 groups per K-slice on sixteen waves is one unit per wave -- eight waves run two: TP = 8 qkv 6.18 -> 5.75 us)
+    else if (tiles < 128 && rows <= 4) { tpw = 2; waves = (G + 3) / 4 > 16 ? 16 : 8; }
+    else if (rows == 1) {
+      // one split fewer when that brings (column blocks x K-slices) down to one round of 8-wave workgroups over the 256 CUs
+      // (Llama-3-70B TP = 2 qkv, 8192 -> 5120: 80 blocks x 4 = 320 -> x 3 = 240: 9.29 -> 8.40 us; profiles/r04_sweep_llama3-70b_tp2.jsonl)
+      const int64_t cbs = (tiles + tpw - 1) / tpw;
+      if (cbs * 4 > 256 && cbs * 3 <= 256) ksplit = 3;
+    }
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 32) {   // o_proj class
     tpw = 4; ksplit = 4;
     waves = G / 4 <= 8 ? 4 : 8;   // 8 groups per split: 4 waves x 2 units beat 8 x 1 (o_proj 7.0 -> 6.6 us on the same box)
