@@ -94,6 +94,9 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // profiles/r04_sweep_rows*.jsonl: Qwen3-4B o_proj 6.73 -> 6.22 us at 2 rows, 6.83 -> 6.38 at 4; Llama-3-8B 7.02 -> 6.26, 7.18 -> 6.49;
     // round 3's 2-tile x 8-wave choice for them dated from the build with packed ops)
     if (rows > 4) waves = 8;
+    // (very narrow outputs -- the un-merged k_proj / v_proj of an HF module tree, 4096 -> 1024: 64 one-tile blocks x 4 K-slices are 256
+    // workgroups, one round; 4-tile blocks leave 64: 4.65 -> 4.43 us, profiles/r04_sweep_shape_4096x1024.jsonl)
+    else if (rows == 1 && tiles <= 64) tpw = 1;
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
     // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us).
     // Re-swept in round 4 on the build without packed-FP32 ops (profiles/r04_sweep_qwen3-0.6b.jsonl): below 24 groups the in-launch

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--mode", default="0")
     ap.add_argument("--order", type=int, default=-1, help="wq tile order: 0 [tile][group], 1 [group][tile], -1 auto")
     ap.add_argument("--only", default="", help="comma-separated linear names to run")
+    ap.add_argument("--shape", default="", help="K:N1+N2+... -- one custom linear instead of a model's (e.g. 4096:1024, the north star's k_proj / v_proj)")
     ap.add_argument("--tp", type=int, default=1, help="per-rank shapes of a tensor-parallel split")
     ap.add_argument("--share_rot", type=int, default=0, help="1: every weight copy uses copy 0's rotation schedule and "
                     "channel scales (they stay cache resident): measures what the cold first touch of those small streams costs")
@@ -46,7 +47,10 @@ def main():
     wvs = [int(k) for k in args.waves.split(",")]
     modes = [int(k) for k in args.mode.split(",")]
     import bench
-    if args.model in bench.HYBRID:       # Qwen3.5 family: the distinct linears of both layer kinds
+    if args.shape:
+        K_, cols = args.shape.split(":")
+        shapes = [("custom", int(K_), [int(c) for c in cols.split("+")], "col")]
+    elif args.model in bench.HYBRID:       # Qwen3.5 family: the distinct linears of both layer kinds
         shapes, seen = [], set()
         for full in (False, True):
             for nm, K_, sz_, kind in bench.hybrid_layer_shapes(args.model, full, args.tp):
