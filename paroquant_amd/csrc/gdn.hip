@@ -19,10 +19,20 @@ namespace paro {
 template <typename T>
 using GPc = const __attribute__((address_space(1))) T*;
 
-__device__ __forceinline__ float wave_total(float v) {   // the wave's sum in every lane
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// the wave's sum in every lane: four row steps and two row broadcasts on the VALU's DPP path, the total read back from lane 63 (a
+// __shfl_xor butterfly is six dependent ds_bpermute round trips of ~100 cycles each; these kernels are chains of such reductions)
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float gdn_dpp(float a) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, RMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_total(float v) {
+  v += gdn_dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += gdn_dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += gdn_dpp<0x141, 0xf>(v);   // row_half_mirror
+  v += gdn_dpp<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += gdn_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += gdn_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
