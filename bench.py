@@ -893,6 +893,21 @@ def run(args, rank: int, local_rank: int, world: int):
             traffic = json.load(f).get("traffic_bytes_per_launch")
     elif pmc_file:
         pmc_reason = "the PMC summary describes the default one-row workload at full depth"
+    # L2-side traffic: what the CUs pull through L2 per launch -- TCP -> TCC read requests x 128 B from the round's
+    # rocprofv3 --pmc TCP_TCC_READ_REQ_sum pass (tools/pmc_l2.py) -- next to the HBM-side figure; same freshness rule (kernel_sources_sha)
+    l2_traffic, l2_source = None, None
+    if traffic is not None:
+        import glob
+        l2_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_l2_{model}.json")))
+        try:
+            if l2_files:
+                with open(l2_files[-1]) as f:
+                    l2 = json.load(f)
+                if l2.get("kernel_sources_sha") == kernel_sources_sha():
+                    l2_traffic = int(round(l2["mean_MB_through_the_CUs_per_launch"]["at_128B"] * 1e6))
+                    l2_source = os.path.relpath(l2_files[-1], ROOT)
+        except Exception:
+            l2_traffic, l2_source = None, None
     roofline = {"bound": "hbm", "kernel": ("paro::chain_kernel (INT4 GEMV on rotated activations + the consumer's rotation in the epilogue"
                                            if stack.route == "chain" else ("paro::gemv_kernel (fused rotate+INT4 GEMV; K-split reductions deferred into the consuming launch"
                                                                            if stack.route == "parts" else "paro::gemv_kernel (fused rotate+INT4 GEMV")) + ", all launches of the step)",
@@ -900,6 +915,7 @@ def run(args, rank: int, local_rank: int, world: int):
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": os.path.relpath(pmc_file, ROOT) if (pmc_file and traffic is not None) else None,
                 "traffic_note": None if traffic is not None else pmc_reason,
+                "l2_traffic": l2_traffic, "l2_traffic_source": l2_source,      # bytes through the CUs' vector caches per launch (L2 -> CU), or null
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
                 "launches_per_step": launches,
                 "note": "per rank; launch duration = HIP-event time of the timed region / launches (includes inter-kernel gaps"
