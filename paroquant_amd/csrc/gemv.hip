@@ -97,6 +97,12 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // (very narrow outputs -- the un-merged k_proj / v_proj of an HF module tree, 4096 -> 1024: 64 one-tile blocks x 4 K-slices are 256
     // workgroups, one round; 4-tile blocks leave 64: 4.65 -> 4.43 us, profiles/r04_sweep_shape_4096x1024.jsonl)
     else if (rows == 1 && tiles <= 64) tpw = 1;
+    // (one K-slice fewer when that brings (column blocks x slices) down to one round of workgroups: Qwen3.5-27B-class out_proj 6144 -> 5120
+    // and the TP = 4 down shard 4352 -> 5120, 80 blocks x 4 = 320 -> x 3 = 240: 7.63 -> 6.73 us, 7.12 -> 6.11; profiles/r04_sweep_qwen3.5-27b-class_tp*.jsonl)
+    if (rows == 1 && tpw == 4) {
+      const int64_t cbs = (tiles + 3) / 4;
+      if (cbs * 4 > 256 && cbs * 3 <= 256) ksplit = 3;
+    }
   } else if (auto_tpw && auto_ks && auto_wv && narrow && G >= 16 && rows <= 4) {
     // small models' o / down (Qwen3-0.6B: 2048 -> 1024, 3072 -> 1024): 2 K-splits of 8-wave workgroups (down 4.81 -> 4.36 us).
     // Re-swept in round 4 on the build without packed-FP32 ops (profiles/r04_sweep_qwen3-0.6b.jsonl): below 24 groups the in-launch
@@ -110,7 +116,8 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // workgroups over the 256 CUs (384 tiles: 2 -> 192 blocks; 512: 2 -> 256; 640 / 768: 4 -> 160 / 192; 1216 / 1792: 8 -> 152 / 224).
     // Exactly 512 tiles stay on 2-tile blocks (Llama-3-70B TP = 4 o_proj 2048 -> 8192: 4.67 us against 5.32 on 4-tile blocks)
     tpw = 4;
-    if (G >= 32) { ksplit = 4; waves = 4; } else { ksplit = 1; waves = 8; }
+    if (G >= 32 && tiles >= 832) { tpw = 8; ksplit = 2; waves = 8; }     // 27B-class gated qkv (896 tiles, 40 groups): 112 blocks x 2 = 224, one round: 11.66 -> 9.93 us
+    else if (G >= 32) { ksplit = 4; waves = 4; } else { ksplit = 1; waves = 8; }
   } else if (auto_tpw && auto_ks && auto_wv && tiles < 1024 && G >= ((deferred && rows == 1) || rows > 4 ? 16 : 32)) {
     // mid-width outputs with K >= 4096 (Llama-3-8B qkv: 384 tiles x 32 groups): 96 fat column blocks x 2 splits halve
     // the replicated rotation; pays since the reducer polls all splits at once (7.10 -> 6.71 us; at G = 20, Qwen3-4B
@@ -134,6 +141,12 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     else
       tpw = 1;
   }
+  if (auto_tpw && auto_ks && auto_wv && !deferred && rows == 1 && tpw == 8 && ksplit <= 0) {
+    // wide outputs on 8-tile blocks (profiles/r04_sweep_qwen3.5-27b-class_tp1.jsonl), the one-round pattern again:
+    const int64_t cbs = (tiles + 7) / 8;
+    if (cbs * 2 <= 256 && G >= 32) ksplit = 2;                 // at most 128 blocks: two K-slices fill the round (in_proj_qkvz 5120 -> 16384: 12.82 -> 10.54 us)
+    else if (cbs > 256 && cbs <= 320) tpw = 4;                 // a thin second round of fat blocks (gate_up 5120 -> 34816, 272 blocks: 25.3 -> 22.3 us)
+  }
   if (ksplit <= 0) ksplit = 1;
   if (waves <= 0) {
     if (tpw == 4 && tiles >= 768 && tiles < 1024 && G >= 64 && rows <= 4)
@@ -141,7 +154,7 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     else if (rows > 4 || tpw > 2 || G < 16)
       // (eight groups or fewer per workgroup at up to four rows: four waves run two units each instead of eight running one -- Qwen3-0.6B
       // qkv 3.42 -> 3.29 us, gate_up 3.84 -> 3.43, profiles/r04_sweep_qwen3-0.6b.jsonl)
-      waves = (G >= 16 || (G >= 8 && (rows > 4 || tpw > 2))) ? 8 : 4;
+      waves = (G > 8 || (G == 8 && (rows > 4 || tpw > 2))) ? 8 : 4;     // (9..15 groups: eight waves -- 27B-class TP = 4 out_proj, 12 groups: 4.57 -> 4.04 us)
     else if (rows == 1 && tpw == 2 && ksplit == 1 && G <= 24)
       // 17..24 groups on 2-tile blocks (Qwen3-4B qkv, 2560 -> 6144): sixteen waves leave most of them ONE unit -- no tile request in flight
       // behind the rotation -- eight waves run two or three (5.41 -> 5.16 us on the build without packed-FP32 ops,
