@@ -601,3 +601,51 @@ def test_no_kernel_reads_the_dispatch_packet():
                 if props & 0b110:
                     bad.append(name)
     assert n > 100 and not bad, bad[:5]
+
+
+def test_round4_launch_shape_heuristics():
+    """What the round-4 re-sweeps (profiles/r04_sweep_*.jsonl, on the build without packed-FP32 ops) changed in gemv_autotune, pinned: the
+    pattern behind them is ONE round of workgroups over the 256 CUs -- the fewest tiles per wave with <= 256 column blocks for unsplit launches,
+    (column blocks x K-slices) <= 256 for split ones."""
+    import bench
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+
+    def shape(K, sizes, rows=1):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.wq_order = K, sum(sizes), len(sizes), 8, nat.DTYPE_F16, 0
+        for i, s_ in enumerate(sizes):
+            d.part_cols[i] = s_
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)
+        out = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
+        nat.check(lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(o) for o in out]))
+        return tuple(o.value for o in out)
+
+    def hybrid(model, tp=1):
+        r = {}
+        for full in (False, True):
+            for n, K, s, _ in bench.hybrid_layer_shapes(model, full, tp):
+                r.setdefault(n, (K, s))
+        return r
+
+    dense = lambda m, tp=1: {n: (K, s) for n, K, s, _ in bench.layer_shapes(m, tp)}
+    # Qwen3-0.6B (BASELINE config 1): <= 8 groups per workgroup -> 4 waves; narrow layers below 24 groups unsplit in the per-call route
+    q06 = dense("qwen3-0.6b")
+    assert shape(*q06["qkv_proj"]) == (1, 1, 4, 0) and shape(*q06["gate_up_proj"]) == (2, 1, 4, 0)
+    assert shape(*q06["o_proj"]) == (1, 1, 8, 0) and shape(*q06["down_proj"]) == (1, 2, 8, 0)
+    # the Qwen3.5 family's almost-wide merged projections: 4-tile blocks, unsplit below 32 groups, 4 x 4-wave K-slices from 32 on
+    q4b, q9b, q27, q27t = hybrid("qwen3.5-4b-class"), hybrid("qwen3.5-9b"), hybrid("qwen3.5-27b-class"), hybrid("qwen3.5-27b-class", 4)
+    assert shape(*q4b["in_proj_qkvz"]) == (4, 1, 8, 0) and shape(*q4b["qkv_proj(gated q)"]) == (4, 1, 8, 0)
+    assert shape(*q9b["in_proj_qkvz"]) == (4, 4, 4, 0) and shape(*q9b["qkv_proj(gated q)"]) == (4, 4, 4, 0)
+    # 27B-class (BASELINE config 5): 8-tile blocks x 2 slices fill the round, 80 blocks x 3 slices, a thin second round avoided
+    assert shape(*q27["in_proj_qkvz"]) == (8, 2, 8, 0) and shape(*q27["qkv_proj(gated q)"]) == (8, 2, 8, 0)
+    assert shape(*q27["out_proj"]) == (4, 3, 8, 0) and shape(*q27["gate_up_proj"]) == (4, 1, 8, 0)
+    assert shape(*q27t["out_proj"]) == (2, 1, 8, 0) and shape(*q27t["down_proj"])[:2] == (4, 3)
+    # Llama-3-70B tensor-parallel shards
+    assert shape(*dense("llama3-70b", 2)["qkv_proj"]) == (4, 3, 8, 0)
+    assert shape(*dense("llama3-70b", 4)["o_proj"]) == (2, 1, 8, 0) and shape(*dense("llama3-70b", 4)["down_proj"]) == (4, 2, 8, 0)
+    assert shape(*dense("llama3-70b", 8)["qkv_proj"]) == (2, 4, 8, 0)
+    # the un-merged k_proj / v_proj of an HF module tree; o_proj keeps its one-row shape at 2..4 rows and stays fused to 16 rows
+    assert shape(4096, [1024]) == (1, 4, 4, 0)
+    assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 4, 8, 0)
