@@ -191,7 +191,7 @@ def synth_pairs(rng: np.random.Generator, krot: int, K: int) -> np.ndarray:
     return out.reshape(krot, K)
 
 
-def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None, gain_k: int = 0):
+def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None, gain_k: int = 0, keep_ckpt: bool = False):
     """Random layer in checkpoint format (SURVEY section 8d synthetic inputs), unit gain, repacked by the
     product path (torch.ops.paro.repack_awq).  `gain_k`: the in_features the gain is normalised for -- the FULL K for a
     row-parallel shard, whose tp partial outputs are summed by the all-reduce (unit gain after the sum, as in a real shard)."""
@@ -209,14 +209,18 @@ def synth_packed(K: int, sizes, dev, gen: torch.Generator, wq_order=None, gain_k
     rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=dev).item()))
     pairs = torch.from_numpy(np.stack([synth_pairs(rng, 8, K) for _ in range(P)])).to(dev)
     cs = (torch.rand(P, 1, K, device=dev, generator=gen) * 1.5 + 0.5).half()
-    return PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes, wq_order=wq_order)
+    pk = PackedParoWeights(qweight, qzeros, scales, theta, pairs, cs, sizes, wq_order=wq_order)
+    if keep_ckpt:      # the checkpoint-format tensors on the host: what the float64 oracle chain of `route_oracle_check` reads
+        pk._ckpt = dict(qweight=qweight.cpu().numpy(), qzeros=qzeros.cpu().numpy(), scales=scales.cpu().numpy(), theta=theta.cpu().numpy(),
+                        pairs=pairs.cpu().numpy(), channel_scales=cs.cpu().numpy(), sizes=list(sizes), K=K)
+    return pk
 
 
 class DecodeStack:
     """All quantised linears of `n_layers` decoder layers, chained for one decode token (`rows` sequences)."""
 
     def __init__(self, model: str, dev, n_layers=None, tp: int = 1, rank: int = 0, seed: int = 0, allreduce=None, rows: int = 1,
-                 route: str = "auto"):
+                 route: str = "auto", keep_ckpt: bool = False):
         self.model, self.tp, self.rank, self.rows = model, tp, rank, rows
         from paroquant_amd import ops
         self.ops = ops
@@ -232,7 +236,8 @@ class DecodeStack:
         self.shapes = self.plan[0]
         self.layers = []
         for shapes in self.plan:
-            self.layers.append([synth_packed(K, sizes, dev, gen, gain_k=K * tp if kind == "row" else 0) for (_, K, sizes, kind) in shapes])
+            self.layers.append([synth_packed(K, sizes, dev, gen, gain_k=K * tp if kind == "row" else 0, keep_ckpt=keep_ckpt)
+                                for (_, K, sizes, kind) in shapes])
         self.x = torch.randn(rows, self.hidden, device=dev, dtype=torch.float16, generator=gen)
         self.launches_per_step = sum(len(sh) for sh in self.plan)
         self.bytes_per_step = sum(alg_bytes(K, sum(s), len(s)) for sh in self.plan for (_, K, s, _) in sh)
@@ -401,6 +406,121 @@ def time_steps(fn, steps: int, warmup: int, world: int, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = t[0].item(), t[1].item()
     return wall, ev_ms
+
+
+def route_oracle_check(model: str, dev, routes, n_layers: int = 2):
+    """every one-row route against the float64 ORACLE chain (oracle/paro_oracle.py used as the checker, never as the thing
+    measured), not against another route.  A small twin of the bench stack (`n_layers` decoder layers, own seed, checkpoint tensors kept on the
+    host) runs through each route on the GPU; the oracle runs the same chain -- linear i + 1 reads the first K columns of linear i's output,
+    rounded to fp16 as the kernels store it -- with the rotation, the dequantisation and the dot products in float64 (`ideal=True`).
+    Returns {route: {"max_rel_err_vs_oracle", "within_1e-2_of_oracle"}} + the description of the check."""
+    from oracle import paro_oracle as po       # checker use only (as tests/ and smoke() use it)
+    small = DecodeStack(model, dev, n_layers=n_layers, seed=4242, route="fused", keep_ckpt=True)
+    flat = small._flat
+    h = small.x.cpu().numpy().astype(np.float16)
+    for i, pk in enumerate(flat):
+        c = pk._ckpt
+        need = flat[i + 1].K if i + 1 < len(flat) else sum(c["sizes"])       # columns the next linear reads (whole partitions)
+        cols, outs = 0, []
+        for p, n in enumerate(c["sizes"]):
+            if cols >= need:
+                break
+            outs.append(po.paro_linear(h[:, : c["K"]], np.ascontiguousarray(c["qweight"][:, cols // 8:(cols + n) // 8]),
+                                       np.ascontiguousarray(c["qzeros"][:, cols // 8:(cols + n) // 8]), np.ascontiguousarray(c["scales"][:, cols:cols + n]),
+                                       c["theta"][p], c["pairs"][p], c["channel_scales"][p], None, 128, ideal=True))
+            cols += n
+        y64 = np.concatenate(outs, axis=-1)
+        h = y64.astype(np.float16)             # the kernels' one rounding per linear
+    ref, ncol = y64, y64.shape[-1]
+    out = {}
+    for route in routes:
+        try:
+            small.use_route(route)
+            y = small.step(small.x)
+            torch.cuda.synchronize(dev)
+            err = float(np.max(np.abs(y.float().cpu().numpy().astype(np.float64)[:, :ncol] - ref)) / max(np.max(np.abs(ref)), 1e-30))
+            out[route] = {"max_rel_err_vs_oracle": round(err, 6), "within_1e-2_of_oracle": bool(err < 1e-2)}
+        except Exception as e:
+            out[route] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            small.route = "fused"
+    del small
+    torch.cuda.empty_cache()
+    return out, (f"{n_layers} decoder layers ({len(flat)} chained linears) of the same architecture through each route vs the float64 oracle chain "
+                 "(oracle/paro_oracle.py paro_linear ideal=True, fp16 rounding between linears), max|y - ref| / max|ref| of the last linear's output")
+
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 matrix peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md; not the 2:1-sparsity figure)
+
+# the north star's second metric: "MFMA utilisation (prefill, compute-bound) against gfx950 peaks" at BASELINE config 3's batch-32 x seq-2048
+# prefill (M = 65536 rows): the reference reaches this through ParoQuantLinearMethod.apply at large M (vllm/plugin.py:281-311)
+PREFILL_SHAPES = [("llama3-8b gate_up_proj [P=2]", 4096, [14336, 14336]), ("llama3-8b qkv_proj [P=3]", 4096, [4096, 1024, 1024]),
+                  ("qwen3.5-4b-class gate_up_proj [P=2]", 2560, [9216, 9216])]
+
+
+def prefill_table(dev, rows: int = 65536, launches: int = 5):
+    """One bounded prefill leg: the fused linear at M = 32 x 2048 rows through the per-call operator (`PackedParoWeights.apply`
+    = rotation pre-pass on the matrix cores + W4A16 MFMA GEMM), `launches` timed calls after two warm-ups; the pre-pass alone
+    (`paro_rotate_parts` with the dense rotation matrices = the same launch the GEMM entry issues first) timed the same way."""
+    from paroquant_amd import ops
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    out = []
+    for name, K, sizes in PREFILL_SHAPES:
+        pk = synth_packed(K, sizes, dev, gen)
+        pk.prepare_prefill(torch.float16)
+        x = torch.randn(rows, K, device=dev, dtype=torch.float32, generator=gen).half()
+        xr = torch.empty(len(sizes), rows, K, device=dev, dtype=torch.float16)
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / launches
+        ms = timed(lambda: pk.apply(x))
+        ms_pre = timed(lambda: ops.rotate_parts(x, pk, out=xr))
+        flops = 2.0 * rows * K * sum(sizes)
+        out.append({"linear": name, "M": rows, "K": K, "N": sum(sizes), "P": len(sizes), "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1),
+                    "mfma_util": round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4), "prepass_ms": round(ms_pre, 4),
+                    "prepass_share": round(ms_pre / ms, 4), "launches": launches})
+        del pk, x, xr
+        torch.cuda.empty_cache()
+    return out
+
+
+def config_steps(dev, models=(("qwen3-0.6b", 0), ("qwen3.5-4b-class", 8)), steps: int = 20, warmup: int = 3):
+    """BASELINE configs 1 and 2's decode legs in the same line: the bench step (per-call route, one HIP graph) of the
+    other single-GPU configurations; `layers` = 0 builds the full depth, otherwise the first n layers (stated in the row; the per-layer time
+    does not depend on the depth: distinct weights per layer, far past the caches either way for the 4B-class)."""
+    out = []
+    for model, nl in models:
+        st = DecodeStack(model, dev, n_layers=nl or None, seed=31, route="fused")
+        st.step(st.x)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        ss = torch.cuda.Stream(dev)
+        ss.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(ss):
+            st.step(st.x)
+        torch.cuda.current_stream(dev).wait_stream(ss)
+        with torch.cuda.graph(g):
+            st.step(st.x)
+        _, ev = time_steps(g.replay, steps, warmup, 1, dev)
+        ms = ev / steps
+        full = n_layers_of(model)
+        out.append({"workload": f"{model}-PARO batch-1 decode", "layers_measured": st.n_layers, "layers_of_model": full,
+                    "ms_per_step_measured": round(ms, 4), "tokens_per_s_full_depth": round(1e3 / (ms * full / st.n_layers), 1),
+                    "bytes_per_step_measured": int(st.bytes_per_step), "launches": st.launches_per_step,
+                    "roofline_frac": round(st.bytes_per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+        del st, g
+        torch.cuda.empty_cache()
+    return out
 
 
 # BASELINE.json's target: ">= 70 % of MI355X HBM roofline on batch-1 INT4 GEMV at Llama-3-8B q/k/v/o/mlp shapes" -- the five rows of
@@ -670,6 +790,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end decode leg (fused harness: attention, norms, lm_head)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--per-shape", action="store_true", help="also print a per-linear GEMV table of the workload's model to stderr")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.prefill (MFMA utilisation at M = 65536) and extra.configs (BASELINE configs 1 / 2 decode steps)")
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip extra.llama3_8b_per_shape (the five Llama-3-8B GEMV shapes of BASELINE.md section 3, timed by the default run)")
     ap.add_argument("--pmc-file", default="", help="PMC summary json for roofline.traffic (default: newest profiles/rNN_pmc_bench_<model>.json)")
@@ -846,12 +967,21 @@ def run(args, rank: int, local_rank: int, world: int):
                 # (144 linears), gated at the north star's 1e-2
                 rel = float((y_mine.float() - y_other.float()).abs().max() / y_mine.float().abs().max())
                 route_ab[other] = {"ms_per_step": round(w2 * 1e3 / args.steps, 4), "roofline_frac": frac_of(w2),
-                                   "max_rel_diff_vs_headline": rel, "within_1e-2": bool(rel < 1e-2),
+                                   # context only: two routes cut K differently, so after the whole chain their fp32 summation orders have
+                                   # diverged by chain-amplified ROUNDING -- parity is gated against the oracle below, not here
+                                   "rounding_divergence_from_headline_after_%d_linears" % stack.launches_per_step: rel,
                                    "reachable_through": ROUTE_REACH[other]}
             except Exception as e:
                 route_ab[other] = {"error": f"{type(e).__name__}: {e}"}
             finally:
                 stack.route = mine
+        try:       # parity of every route: against the float64 oracle chain
+            chk, how = route_oracle_check(model, dev, [r for r in route_ab if "error" not in route_ab[r]])
+            for r, v in chk.items():
+                route_ab[r].update(v)
+            route_ab["oracle_check"] = how
+        except Exception as e:
+            route_ab["oracle_check"] = f"failed: {type(e).__name__}: {e}"
     # TP runs report BOTH collectives: the one-shot xGMI kernel (when it came up and passed its self-test)
     # and the backend's all-reduce (RCCL), timed on the same shards; the headline is the faster leg that is healthy.
     allreduce_ab = None
@@ -991,6 +1121,18 @@ def run(args, rank: int, local_rank: int, world: int):
                                    "note": "batch-1 fused rotate + INT4 GEMV per operator call, HIP graph of 300 launches over >= 768 MiB of distinct weights"}
             except Exception as e:
                 result["extra"] = {"llama3_8b_per_shape": {"error": f"{type(e).__name__}: {e}"}}
+        if world == 1 and not tp_mode and args.rows == 1 and not args.no_extra:
+            ex = result.setdefault("extra", {})
+            try:       # the north star's second metric, driver-visible: prefill MFMA utilisation at M = 32 x 2048
+                ex["prefill"] = {"rows": prefill_table(dev), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                                 "note": "fused linear per operator call at M = 65536 (BASELINE config 3's batch-32 x seq-2048 prefill): rotation pre-pass on the "
+                                         "matrix cores + W4A16 MFMA GEMM; mfma_util = 2 M K N / time / dense fp16 peak; prepass_share = the pre-pass launch alone / the call"}
+            except Exception as e:
+                ex["prefill"] = {"error": f"{type(e).__name__}: {e}"}
+            try:       # BASELINE configs 1 and 2 (decode legs) next to the headline configuration
+                ex["configs"] = config_steps(dev)
+            except Exception as e:
+                ex["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
             try:       # SURVEY 8d's per-shape table (B1 torch-CPU, B2 C port); context, never fatal for the contract line

@@ -386,7 +386,9 @@ int paro_attn_finish(const float* attn_parts, int n_heads, int head_dim, void* o
  *   paro_attn_decode_gated   Qwen3_5Attention at one row: qkv = [n_heads][2][head_dim] (query | gate per head) then k, v heads; q / k
  *                   RMSNorm with weights w (norm_plus_one: 1 + w), rotary embedding on the first rotary_dim dimensions (rope fp32
  *                   [max_positions][rotary_dim]: cos then sin), KV append at *pos (kcache / vcache act_dtype [n_kv_heads][max_positions]
- *                   [head_dim]), attention over 0..*pos, output * sigmoid(gate).  head_dim 256. */
+ *                   [head_dim]), attention over 0..*pos, output * sigmoid(gate).  head_dim 256.  *pos is read on the DEVICE: a value
+ *                   outside [0, max_positions) appends nothing and the output rows are NaN (no host check is possible under graph replay).
+ *                   paro_gdn_fused_step uses *pos only for the parity of its double-buffered convolution state (any value is in bounds). */
 int paro_gdn_prep(const void* qkv, const void* x, const float* w_ab, float eps, void* conv_state, const float* conv_w, const float* A_log,
                   const float* dt_bias, void* conv_out, float* g_beta, int hidden, int conv_dim, int n_v_heads, int act_dtype, void* stream);
 int64_t paro_gdn_workspace_bytes(int n_v_heads);   /* scratch of paro_gdn_step: zero-filled ONCE by the caller (the arrival tickets return to zero) */
@@ -474,7 +476,8 @@ int paro_chain_launch_shape(const paro_linear_t* L, const paro_chain_t* C, int64
 int paro_w4a16_gemv_chain(const paro_linear_t* L, const paro_chain_t* C, int64_t rows, void* workspace,
                           int64_t workspace_bytes, int ksplit, int waves, void* stream);
 /* Head of a chain: x [rows][K] rotated with every partition's parameters of L into x_rot [n_parts][rows][K] in ONE
- * launch (the stage kernel behind rotation::rotate, rotation.cu:10-43). */
+ * launch (the stage kernel behind rotation::rotate, rotation.cu:10-43; with L->rmat and >= 256 rows the dense per-group product on
+ * the matrix cores, i.e. exactly the pre-pass paro_w4a16_gemm runs in front of its GEMM kernel). */
 int paro_rotate_parts(const paro_linear_t* L, const void* x, void* x_rot, int64_t rows, void* stream);
 
 /* ---------------------------------------------------------------------------

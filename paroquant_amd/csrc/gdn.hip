@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256) void attn_gated_decode_kernel(const AttnGatedA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x, n_rep = a.Hq / a.Hkv, kvh = head / n_rep;
   const int pos = *a.pos;
+  // *pos lives in device memory (a captured graph replays for every token): no host check can see it.  A position outside the cache
+  // writes nothing to the KV cache or the score array and answers NaN (as paro_attn_decode's kernels leave the cache alone)
+  if (pos < 0 || pos >= a.T_max) {
+    a.out[head * HD + tid] = A::from_f32(__builtin_nanf(""));
+    return;
+  }
   const int half = a.rd / 2;
   auto block_sum = [&](float v, int slot) {
     v = wave_total(v);

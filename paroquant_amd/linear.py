@@ -36,6 +36,31 @@ def pad_partitions(qweight, qzeros, scales, sizes, pack: int = 8, multiple: int 
     return qweight.contiguous(), qzeros.contiguous(), scales.contiguous(), padded
 
 
+def coalesce_partitions(theta, pairs, channel_scales, sizes):
+    """Merge ADJACENT partitions whose rotation parameters are identical into one kernel partition.
+
+    vLLM loads one checkpoint rotation into several slots when a fused projection spans more than one output partition
+    (tuple shard ids, reference ``vllm/plugin.py:60-76``: Qwen3.5's ``in_proj_qkvz`` = ``in_proj_qkv`` -> slots (0, 1, 2) +
+    ``in_proj_z`` -> slot 3).  The reference then rotates x once per slot (``plugin.py:288-306``); the fused kernel's cost per
+    128-channel group grows with the number of rotations it runs, so slots that hold the SAME rotation over neighbouring columns
+    are one partition here (the outputs are identical: same rotated x, same columns).  Returns
+    ``(theta, pairs, channel_scales, merged_sizes, slot_of_partition)``."""
+    P = len(sizes)
+    cs = channel_scales.reshape(P, -1)
+    keep, merged = [0], [int(sizes[0])]
+    for p in range(1, P):
+        q = keep[-1]
+        if torch.equal(theta[p], theta[q]) and torch.equal(pairs[p], pairs[q]) and torch.equal(cs[p], cs[q]):
+            merged[-1] += int(sizes[p])
+        else:
+            keep.append(p)
+            merged.append(int(sizes[p]))
+    if len(keep) == P:
+        return theta, pairs, channel_scales, [int(s) for s in sizes], keep
+    idx = torch.tensor(keep, device=theta.device)
+    return theta.index_select(0, idx), pairs.index_select(0, idx), cs.index_select(0, idx).reshape(len(keep), 1, -1), merged, keep
+
+
 class PackedParoWeights:
     """Kernel-ready parameters of one (possibly merged) ParoQuant linear.
 

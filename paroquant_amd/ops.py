@@ -428,24 +428,26 @@ def parts_finish(parts: torch.Tensor, x: Optional[torch.Tensor] = None, out: Opt
     return out
 
 
-def pk_desc(pk, act_dtype: torch.dtype, bias=None) -> nat.ParoLinearDesc:
+def pk_desc(pk, act_dtype: torch.dtype, bias=None, rmat=None) -> nat.ParoLinearDesc:
     """``paro_linear_t`` of a :class:`paroquant_amd.linear.PackedParoWeights`."""
     return make_desc(pk.K, pk.partition_sizes, int(pk.pairs.size(1)), act_dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                     pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order)
+                     pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order, rmat)
 
 
 def rotate_parts(x: torch.Tensor, pk, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Head of a decode chain: ``x [rows, K]`` rotated with every merged partition's parameters of ``pk`` in one launch
-    -> ``[n_parts, rows, K]`` (``paro_rotate_parts``; the stage kernel behind ``rotation::rotate``)."""
+    -> ``[n_parts, rows, K]`` (``paro_rotate_parts``; the stage kernel behind ``rotation::rotate``, from 256 rows on the dense
+    per-group product on the matrix cores -- the prefill GEMM's pre-pass on its own)."""
     lib = nat.load()
     K, P = pk.K, len(pk.partition_sizes)
     x2 = x.reshape(-1, K).contiguous()
     rows = x2.size(0)
+    rmat = pk.rotation_matrices(x.dtype) if rows >= 256 else None
     if out is None:
         out = torch.empty((P, rows, K), dtype=x.dtype, device=x.device)
     elif out.numel() != P * rows * K or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError(f"out must be a contiguous [{P}, {rows}, {K}] tensor of {x.dtype}")
-    d = pk_desc(pk, x.dtype)
+    d = pk_desc(pk, x.dtype, rmat=rmat)
     with torch.cuda.device(x.device):
         nat.check(lib.paro_rotate_parts(ctypes.byref(d), x2.data_ptr(), out.data_ptr(), rows, nat.current_stream_ptr(x.device)))
     return out

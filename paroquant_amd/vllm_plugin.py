@@ -24,7 +24,7 @@ from typing import Any, Optional
 import torch
 from torch.nn import Parameter
 
-from .linear import PackedParoWeights, pad_partitions
+from .linear import PackedParoWeights, coalesce_partitions, pad_partitions
 
 try:  # pragma: no cover - exercised only where vLLM is installed
     from vllm.model_executor.layers.linear import LinearBase, LinearMethodBase, UnquantizedLinearMethod
@@ -279,13 +279,15 @@ class ParoQuantLinearMethod(LinearMethodBase):
         pack = self.quant_config.pack_factor
         qw, qz, sc = layer.qweight.data, layer.qzeros.data, layer.scales.data.to(torch.float16)
         qw, qz, sc, padded = pad_partitions(qw, qz, sc, sizes, pack)   # reference pads to the Marlin tile (plugin.py:210-217)
-        layer.paro_packed = PackedParoWeights(qw.contiguous(), qz.contiguous(), sc.contiguous(), layer.theta.data,
-                                              layer.pairs.data, layer.channel_scales.data, padded, None,
+        # slots that received the same checkpoint rotation (tuple shard ids, plugin.py:60-76) become ONE kernel partition
+        theta, pairs, cs, kernel_sizes, _ = coalesce_partitions(layer.theta.data, layer.pairs.data, layer.channel_scales.data, padded)
+        layer.paro_packed = PackedParoWeights(qw.contiguous(), qz.contiguous(), sc.contiguous(), theta, pairs, cs, kernel_sizes, None,
                                               self.quant_config.group_size, self.quant_config.bits)
+        layer.kernel_partition_sizes = kernel_sizes
         layer.padded_partition_sizes = padded
         layer.rot_theta = layer.paro_packed.theta
         layer.rot_pairs = layer.paro_packed.pairs
-        layer.rot_scales = layer.paro_packed.channel_scales.reshape(len(sizes), 1, -1)
+        layer.rot_scales = layer.paro_packed.channel_scales.reshape(len(kernel_sizes), 1, -1)
         del layer.qweight, layer.qzeros, layer.scales
         del layer.theta, layer.pairs, layer.channel_scales
 

@@ -1513,8 +1513,9 @@ def test_moe_experts_match_oracle(dev, E, H, I, T, k):
 
 # ---------------------------------------------------------------- e: the tensor-parallel bench path on real kernels
 
-@pytest.mark.parametrize("world,workload", [(2, "llama3-70b-tp"), (4, "qwen3-32b-tp")])
-def test_tp_bench_path_on_one_gpu(dev, world, workload):
+@pytest.mark.parametrize("world,workload,layers", [(2, "llama3-70b-tp", 2), (4, "qwen3-32b-tp", 2),
+                                                   (4, "qwen3.5-27b-class-tp", 4)])     # BASELINE config 5: 3 delta-net layers + 1 full-attention layer
+def test_tp_bench_path_on_one_gpu(dev, world, workload, layers):
     """`bench.py --gpus N --workload <70B-class>-tp` with N processes sharing this one GPU (gloo instead of RCCL, which
     refuses two ranks per device): every rank builds its Megatron shard, runs it through the HIP kernels, all-reduces
     after o / down, and rank 0 prints the contract line with n_gpus = N, scaling strong and the TP = 1 reference."""
@@ -1523,7 +1524,7 @@ def test_tp_bench_path_on_one_gpu(dev, world, workload):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", "2",
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", str(layers),
                           "--tp-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -1532,13 +1533,13 @@ def test_tp_bench_path_on_one_gpu(dev, world, workload):
     r = json.loads(lines[0])
     assert r["n_gpus"] == world and r["scaling"] == "strong" and r["config"]["parallelism"] == f"tp{world}"
     assert r["value"] > 0 and r["config"]["tp1_reference"]["tokens_per_s"] > 0
-    assert r["roofline"]["launches_per_step"] == 8
+    assert r["roofline"]["launches_per_step"] == 4 * layers
     # the collective is the one-shot kernel (self-tested against gloo inside the bench), so the TP step is one HIP graph
     assert r["config"]["allreduce"] == "oneshot" and r["config"]["hip_graph"] is True
     # ... and the library collective was timed on the same shards (A/B, the faster healthy leg is the headline)
     ab = r["config"]["allreduce_ab"]
     assert set(ab) == {"oneshot", "gloo"} and ab["oneshot"]["ms_per_step"] > 0 and ab["gloo"].get("ms_per_step", 0) > 0, ab
-    out2 = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", "2", "--no-oneshot",
+    out2 = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", workload, "--layers", str(layers), "--no-oneshot",
                            "--tp-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1"],
                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-3000:]

@@ -322,3 +322,32 @@ def test_gdn_fused_step_matches_the_two_launches_and_the_reference(nk, nv, hidde
         st3 = np.concatenate([st3[:, 1:], f64(qkvz[:cd])[:, None]], axis=1)
         assert po.rel_err(f64(outB), ref) < 1e-2 and po.rel_err(f64(SB), S_ref) < 5e-3, t
     assert int(wsB.view(torch.int32)[nv * 128:].abs().sum()) == 0                  # tickets back at zero
+
+
+@pytest.mark.parametrize("bad_pos", [-1, 64, 1 << 20])
+def test_gated_attention_position_outside_the_cache_writes_nothing(dev, bad_pos):
+    """`*pos` is read on the device (graph replay), so the kernel itself must refuse a position outside the cache: no KV
+    append, no LDS score write, NaN outputs -- like paro_attn_decode (attn.hip)."""
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+    Hq, Hkv, hd, rd, T = 4, 2, 256, 64, 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    qkv = torch.randn(1, (2 * Hq + 2 * Hkv) * hd, device=dev, dtype=torch.float16, generator=g)
+    kc = torch.full((Hkv, T, hd), 7.0, device=dev, dtype=torch.float16)
+    vc = torch.full((Hkv, T, hd), 7.0, device=dev, dtype=torch.float16)
+    guard = torch.full((4096,), 3.0, device=dev, dtype=torch.float16)          # (neighbours of the caches in the allocator: cheap tripwire)
+    out = torch.zeros(1, Hq * hd, device=dev, dtype=torch.float16)
+    rope = torch.randn(T, rd, device=dev, dtype=torch.float32, generator=g)
+    w = torch.zeros(hd, device=dev, dtype=torch.float16)
+    pos = torch.tensor([bad_pos], device=dev, dtype=torch.int32)
+    st = torch.cuda.current_stream().cuda_stream
+    nat.check(lib.paro_attn_decode_gated(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), pos.data_ptr(), rope.data_ptr(),
+                                         w.data_ptr(), w.data_ptr(), 1, 1e-6, hd ** -0.5, Hq, Hkv, hd, rd, T, 1, st))
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+    assert (kc == 7.0).all() and (vc == 7.0).all() and (guard == 3.0).all()
+    pos.fill_(5)                                                                  # a legal position on the same buffers still works
+    nat.check(lib.paro_attn_decode_gated(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), pos.data_ptr(), rope.data_ptr(),
+                                         w.data_ptr(), w.data_ptr(), 1, 1e-6, hd ** -0.5, Hq, Hkv, hd, rd, T, 1, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and not (kc[:, 5] == 7.0).all()

@@ -159,6 +159,24 @@ def test_vllm_config_and_loaders():
                                                                         "visual.blocks.0.attn.qkv"]
 
 
+def test_coalesce_partitions_of_tuple_shard_ids():
+    """Slots filled from ONE checkpoint rotation (tuple shard id, plugin.py:60-76) collapse into one kernel partition; only ADJACENT
+    equal slots merge (column order is the contract), different rotations stay apart."""
+    from paroquant_amd.linear import coalesce_partitions
+    K = 256
+    g = torch.Generator().manual_seed(0)
+    th = torch.randn(2, 8, K // 2, generator=g).half()
+    pr = torch.randint(0, 128, (2, 8, K), generator=g).to(torch.int16)
+    cs = torch.rand(2, 1, K, generator=g).half()
+    pick = lambda t, idx: torch.stack([t[i] for i in idx])
+    t4, p4, c4, sizes, keep = coalesce_partitions(pick(th, [0, 0, 0, 1]), pick(pr, [0, 0, 0, 1]), pick(cs, [0, 0, 0, 1]), [32, 32, 96, 96])
+    assert sizes == [160, 96] and keep == [0, 3] and torch.equal(t4, th) and torch.equal(p4, pr) and torch.equal(c4, cs)
+    _, _, _, sizes, keep = coalesce_partitions(pick(th, [0, 1, 0]), pick(pr, [0, 1, 0]), pick(cs, [0, 1, 0]), [16, 16, 16])
+    assert sizes == [16, 16, 16] and keep == [0, 1, 2]                     # equal but not adjacent: untouched
+    _, _, c1, sizes, _ = coalesce_partitions(pick(th, [0, 0]), pick(pr, [0, 0]), torch.stack([cs[0], cs[1]]), [16, 16])
+    assert sizes == [16, 16] and c1.shape[0] == 2                          # same pairs / angles, other channel scales: another rotation
+
+
 def test_hf_quantizer_swaps_only_quantized_linears(tmp_path):
     from safetensors.torch import save_file
 
