@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 14
+#define PARO_ABI_VERSION 15
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -527,6 +527,23 @@ int paro_engine_run(const paro_engine_t* e, const void* plan_dev, const void* x,
  * turns them into the per-edge timeline). */
 int paro_engine_trace(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
                       int64_t workspace_bytes, void* trace, void* stream);
+
+/* v15: the engine's second build (csrc/engine2.hip) -- the same five entry points, the same descriptors, another geometry: per CU one LOADER
+ * wave streams the INT4 tiles HBM -> LDS by LDS-DMA into a ring of 7 x 16 tiles and runs ahead across the linears; three CONSUMER waves
+ * complete the previous linear's K-chunk partial sums for the CU's OWN groups (one hop per edge), rotate them in registers and multiply out of
+ * LDS.  paro_engine_phase_t.flags & 0xf: 0 = the planner's K-split, 1..4 = that many K-chunks (tuning, tests).  trace: uint64
+ * [n_phases][n_cus][16] stamps of the 100 MHz counter -- consumer wave 0: 0 phase entered, 1 its first partial sums arrived, 2 its groups
+ * rotated and staged, 3 first tile multiplied, 4 its tiles done, 5 every wave's tiles done, 6 outputs published; loader: 8 first slot of the
+ * phase issued, 9 last slot issued.  Replaces rotate -> GEMM per linear of transformers/modules.py:57-71 / vllm/plugin.py:281-311 for a caller
+ * that owns the chain. */
+int paro_engine2_plan(const paro_engine_phase_t* phases, int n_phases, int n_cus, paro_engine_t* out);
+int paro_engine2_build(const paro_engine_phase_t* phases, const paro_engine_t* e, void* plan_host);
+int paro_engine2_describe(const paro_engine_phase_t* phases, const paro_engine_t* e, int phase, int32_t* out_split,
+                          int32_t* out_max_tiles, int32_t* out_min_tiles);
+int paro_engine2_run(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int paro_engine2_trace(const paro_engine_t* e, const void* plan_dev, const void* x, void* y, void* workspace,
+                       int64_t workspace_bytes, void* trace, void* stream);
 
 /* Dequantise packed weights back to a dense [K, N] matrix of act_dtype
  * (debug / verification aid; W[k,n] = (q - z) * s rounded once). */

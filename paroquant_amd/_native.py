@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 14
+PARO_ABI_VERSION = 15
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -71,6 +71,11 @@ EXPORTS = (
     "paro_engine_describe",
     "paro_engine_run",
     "paro_engine_trace",
+    "paro_engine2_plan",
+    "paro_engine2_build",
+    "paro_engine2_describe",
+    "paro_engine2_run",
+    "paro_engine2_trace",
     "paro_gdn_prep",
     "paro_gdn_step",
     "paro_gdn_workspace_bytes",
@@ -285,6 +290,10 @@ def load() -> ctypes.CDLL:
                                            c_int, c_int, c_int, c_void_p]
     lib.paro_engine_trace.restype = c_int
     lib.paro_engine_trace.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    for fn, ref in (("plan", lib.paro_engine_plan), ("build", lib.paro_engine_build), ("describe", lib.paro_engine_describe),
+                    ("run", lib.paro_engine_run), ("trace", lib.paro_engine_trace)):      # engine2.hip: the same signatures
+        f2 = getattr(lib, "paro_engine2_" + fn)
+        f2.restype, f2.argtypes = c_int, ref.argtypes
     if lib.paro_abi_version() != PARO_ABI_VERSION:
         raise RuntimeError(f"paroquant_amd: ABI version mismatch (library {lib.paro_abi_version()}, "
                            f"binding {PARO_ABI_VERSION})")

@@ -118,6 +118,24 @@ struct GivensRegs {
       }
     }
   }
+  // one stage of row 0 (callers that interleave the stage chains of several groups: engine2.hip)
+  __device__ __forceinline__ void stage(int t) {
+    const float keep = __builtin_fmaf(Pf[t], sa[0], Qf[t] * sb[0]);
+    const float give = __builtin_fmaf(Pf[t], sb[0], -(Qf[t] * sa[0]));
+    sb[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl[t], __builtin_bit_cast(int, give)));
+    sa[0] = keep;
+  }
+  // last checkpoint stage of row 0 into registers: the two rounded activations and their byte offsets inside the group's 128 halves
+  __device__ __forceinline__ void finish_vals(unsigned short& h1, unsigned short& h2, unsigned& oa, unsigned& ob) {
+    const unsigned w0 = rc[2][2], w1 = rc[2][3];
+    const float P = (float)(int)(short)(w0 & 0xffffu) * 0x1p-63f, Q = (float)((int)w0 >> 16) * 0x1p-63f;
+    oa = w1 & 0xfeu;
+    ob = (w1 >> 8) & 0xfeu;
+    const float o1 = __builtin_fmaf(P, sa[0], Q * sb[0]);
+    const float d = __builtin_fmaf(P, sb[0], -(Q * sa[0]));
+    h1 = A::from_f32(o1);
+    h2 = A::from_f32(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ (w1 & 0x80000000u)));
+  }
   // last checkpoint stage; ONE rounding; scattered into row buffers `xs` (128 halves per row) at the channels' places
   __device__ __forceinline__ void finish(unsigned short* xs) {
     const unsigned w0 = rc[2][2], w1 = rc[2][3];

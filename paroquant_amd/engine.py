@@ -22,8 +22,18 @@ from . import ops
 
 
 class DecodeEngine:
-    def __init__(self, layers: Sequence, in_col0: Optional[Sequence[int]] = None, dtype: torch.dtype = torch.float16, n_cus: int = 0):
+    def __init__(self, layers: Sequence, in_col0: Optional[Sequence[int]] = None, dtype: torch.dtype = torch.float16, n_cus: int = 0,
+                 version: int = 0, split: Optional[Sequence[int]] = None):
+        """``version`` 2: the loader / consumer build on the LDS-DMA ring (csrc/engine2.hip, ``paro_engine2_*``), 1: round 4's sixteen-wave
+        build (csrc/engine.hip); 0: ``PARO_ENGINE_VERSION`` or the default.  ``split`` (version 2): K-chunks per linear, 0 = the planner's."""
+        import os
         lib = nat.load()
+        self.version = int(version) or int(os.environ.get("PARO_ENGINE_VERSION", "2"))
+        if self.version not in (1, 2):
+            raise ValueError("engine version must be 1 or 2")
+        pre = "paro_engine_" if self.version == 1 else "paro_engine2_"
+        self._fn = {k: getattr(lib, pre + k) for k in ("plan", "build", "describe", "run", "trace")}
+        self._trace_words = 32 if self.version == 1 else 16
         if not layers:
             raise ValueError("DecodeEngine needs at least one linear")
         self.layers = list(layers)
@@ -45,12 +55,12 @@ class DecodeEngine:
         for i, d in enumerate(self._descs):
             self._phases[i].L = ctypes.pointer(d)
             self._phases[i].in_col0 = in_col0[i]
-            self._phases[i].flags = 0
+            self._phases[i].flags = int(split[i]) if (split is not None and self.version == 2) else 0
         self._e = nat.ParoEngine()
         with torch.cuda.device(dev):
-            nat.check(lib.paro_engine_plan(self._phases, n, int(n_cus), ctypes.byref(self._e)))
+            nat.check(self._fn["plan"](self._phases, n, int(n_cus), ctypes.byref(self._e)))
             host = np.zeros(int(self._e.plan_bytes), dtype=np.uint8)
-            nat.check(lib.paro_engine_build(self._phases, ctypes.byref(self._e), host.ctypes.data_as(ctypes.c_void_p)))
+            nat.check(self._fn["build"](self._phases, ctypes.byref(self._e), host.ctypes.data_as(ctypes.c_void_p)))
         self.plan = torch.from_numpy(host).to(dev)
         self.workspace = torch.zeros(int(self._e.workspace_bytes), dtype=torch.uint8, device=dev)     # zero-filled ONCE
         self.K, self.N = int(self._e.in_features), int(self._e.out_features)
@@ -61,7 +71,7 @@ class DecodeEngine:
         lib, out = nat.load(), []
         for i in range(len(self.layers)):
             s, mx, mn = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-            nat.check(lib.paro_engine_describe(self._phases, ctypes.byref(self._e), i, ctypes.byref(s), ctypes.byref(mx), ctypes.byref(mn)))
+            nat.check(self._fn["describe"](self._phases, ctypes.byref(self._e), i, ctypes.byref(s), ctypes.byref(mx), ctypes.byref(mn)))
             out.append((s.value, mx.value, mn.value))
         return out
 
@@ -73,16 +83,16 @@ class DecodeEngine:
         if y.dtype != self.dtype or y.numel() != self.N or not y.is_contiguous():
             raise ValueError(f"out must be a contiguous row of {self.N} {self.dtype} values")
         with torch.cuda.device(self.device):
-            nat.check(nat.load().paro_engine_run(ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), y.data_ptr(),
+            nat.check(self._fn["run"](ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), y.data_ptr(),
                                                  self.workspace.data_ptr(), self.workspace.numel(), nat.current_stream_ptr(self.device)))
         return y
 
     @torch.no_grad()
     def trace(self, x: torch.Tensor) -> torch.Tensor:
         """One launch of the diagnostic twin (``paro_engine_trace``): int64 [n_phases, n_cus, 32] stamps (16 events: 100 MHz counter, then the shader clock at the same events) of the 100 MHz counter."""
-        tr = torch.zeros(len(self.layers), int(self._e.n_cus), 32, dtype=torch.int64, device=self.device)
+        tr = torch.zeros(len(self.layers), int(self._e.n_cus), self._trace_words, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
-            nat.check(nat.load().paro_engine_trace(ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), self.y.data_ptr(),
+            nat.check(self._fn["trace"](ctypes.byref(self._e), self.plan.data_ptr(), x.data_ptr(), self.y.data_ptr(),
                                                   self.workspace.data_ptr(), self.workspace.numel(), tr.data_ptr(),
                                                   nat.current_stream_ptr(self.device)))
         torch.cuda.synchronize(self.device)
