@@ -50,6 +50,7 @@ ROUTE_REACH = {
     "fused": "every RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply call (the reference's per-linear operator API)",
     "parts": "a caller that owns the decoder loop (paroquant_amd.decoder.ParoDecoderLM; INTEGRATION.md 5b)",
     "engine": "a caller that hands over a whole chain of linears (paroquant_amd.engine.DecodeEngine, paro_engine_run)",
+    "engine2": "the same caller; the loader / consumer build of the persistent engine (DecodeEngine(version=2), paro_engine2_run: csrc/engine2.hip)",
 }
 
 MODELS = {
@@ -259,13 +260,13 @@ class DecodeStack:
         if route == "parts":
             from paroquant_amd.decoder import deferred_route_pays
             self.parts_pays = deferred_route_pays(self.hidden)      # the decode harness' gate (70B-class widths keep the in-launch reducer)
-        if route in ("chain", "parts", "engine") and tp != 1:
+        if route in ("chain", "parts", "engine", "engine2") and tp != 1:
             raise SystemExit(f"the {route} route is single-GPU")
-        if route in ("parts", "engine") and rows != 1:
+        if route in ("parts", "engine", "engine2") and rows != 1:
             raise SystemExit(f"the {route} route is batch-1")
         self.route = route
         self._engine = None
-        if route in ("parts", "engine") or (route == "fused" and rows == 1 and tp == 1):     # (the fused stack can also run the parts route: the A/B leg)
+        if route in ("parts", "engine", "engine2") or (route == "fused" and rows == 1 and tp == 1):     # (the fused stack can also run the parts route: the A/B leg)
             flat = [pk for lay in self.layers for pk in lay]
             self._flat = flat
             # producer i hands partial sums to consumer i + 1 (which reads the first K columns of i's output) when the launch shape for
@@ -285,8 +286,8 @@ class DecodeStack:
             self._y = {pk.N: torch.empty(1, pk.N, device=dev, dtype=torch.float16) for pk in flat}
             if route == "parts":
                 self.launches_per_step += 1 if self._nparts[-1] else 0
-            if route == "engine":
-                self._ensure_engine()
+            if route in ("engine", "engine2"):
+                self._ensure_engine(2 if route == "engine2" else 1)
         if route == "chain":
             self.launches_per_step += 1        # the head's rotate_parts
             flat = [pk for lay in self.layers for pk in lay]
@@ -301,23 +302,26 @@ class DecodeStack:
 
     def use_route(self, route: str):
         """Switch the one-row route of a built stack (config.route_ab legs)."""
-        if route in ("parts", "engine") and not hasattr(self, "_flat"):
+        if route in ("parts", "engine", "engine2") and not hasattr(self, "_flat"):
             raise RuntimeError(f"stack was not built for the {route} route")
-        if route == "engine":
-            self._ensure_engine()
+        if route in ("engine", "engine2"):
+            self._ensure_engine(2 if route == "engine2" else 1)
         self.route = route
 
-    def _ensure_engine(self):
-        if getattr(self, "_engine", None) is None:
+    def _ensure_engine(self, version: int = 1):
+        if getattr(self, "_engines", None) is None:
+            self._engines = {}
+        if version not in self._engines:
             from paroquant_amd.engine import DecodeEngine
             # the same chain as `step`: linear i + 1 reads the first K columns of linear i's output
-            self._engine = DecodeEngine(self._flat, in_col0=[0] * len(self._flat))
+            self._engines[version] = DecodeEngine(self._flat, in_col0=[0] * len(self._flat), version=version)
+        self._engine = self._engines[version]
 
     def _step_engine(self, x: torch.Tensor) -> torch.Tensor:
-        return self._engine(x)
+        return self._engines[2 if self.route == "engine2" else 1](x)
 
     def step(self, x: torch.Tensor) -> torch.Tensor:
-        if self.route == "engine":
+        if self.route in ("engine", "engine2"):
             return self._step_engine(x)
         if self.route == "chain":
             return self._step_chain(x)
@@ -780,7 +784,7 @@ def parse_args(argv=None):
     ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
     ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16)")
-    ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain", "engine"],
+    ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain", "engine", "engine2"],
                     help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
                          "launch (decode-chain family); parts = fused with the deferred K-split reduction of o / down (one row, one GPU); "
                          "auto = parts at one row on one GPU, chain at 2..16 rows, fused under tensor parallelism (measured: profiles/r03_chain_rows_sweep.jsonl, r03_parts_bench.jsonl)")
@@ -951,13 +955,13 @@ def run(args, rank: int, local_rank: int, world: int):
     # one row, one GPU: the same stack through the decoder-loop routes as well (deferred K-split reductions; the persistent engine):
     # config.route_ab = {route: {ms_per_step, roofline_frac, max_rel_diff_vs_headline}}
     route_ab = None
-    if stack.route in ("parts", "fused", "engine") and not tp_mode and args.rows == 1 and not args.no_route_ab:
+    if stack.route in ("parts", "fused", "engine", "engine2") and not tp_mode and args.rows == 1 and not args.no_route_ab:
         frac_of = lambda w_s: round(stack.bytes_per_step * args.steps / w_s / 1e9 / HBM_PEAK_GBPS, 4)
         route_ab = {stack.route: {"ms_per_step": round(wall * 1e3 / args.steps, 4), "roofline_frac": frac_of(wall),
                                   "reachable_through": ROUTE_REACH[stack.route]}}
         mine = stack.route
         y_mine = stack.step(stack.x).clone()
-        for other in [r for r in ("fused", "parts", "engine") if r != mine]:
+        for other in [r for r in ("fused", "parts", "engine", "engine2") if r != mine]:
             try:
                 stack.use_route(other)
                 y_other = stack.step(stack.x).clone()

@@ -1,34 +1,44 @@
 // Persistent decode engine, second build (round 5): a whole CHAIN of ParoQuant linears (batch 1) in ONE launch on the
-// LDS-DMA loader / consumer geometry that /opt/skills/guides/MI355X_MICROARCH.md measured to beat captured launches
-// (rows engine-vs-launches, prefetch-credit, ldsdma-fill, gather-pass).
+// LDS-DMA loader / consumer geometry of /opt/skills/guides/MI355X_MICROARCH.md (rows engine-vs-launches, prefetch-credit,
+// ldsdma-fill, gather-pass).
 //
 // What the reference does per linear: rotate -> INT4 GEMM (transformers/modules.py:57-71, vllm/plugin.py:281-311); at batch 1 a
-// chain of dependent launches.  Round 4's engine (engine.hip) kept one resident grid but lost to the launches: sixteen waves per CU
-// that each request, unpack, poll and publish spend ~250 instructions of bookkeeping per phase against ~75 of arithmetic, and an
-// edge was two dependent trips through memory (profiles/NOTES.md 4.2).  This build changes the geometry:
+// chain of dependent launches.  Round 4's engine (engine.hip) kept one resident grid of sixteen-wave workgroups in which every wave
+// requests, unpacks, polls and publishes, and an edge was two dependent trips through memory (profiles/NOTES.md 4.2).  This build:
 //
 //   * one workgroup per CU = ONE LOADER wave + kE2Cons CONSUMER waves.  The loader does nothing but stream: INT4 tiles (1 KiB,
 //     MFMA B-fragment order) and their scale / zero words go HBM -> LDS by LDS-DMA (`global_load_lds ... nt`) into a ring of
 //     kE2Ring slots of 16 tiles; it runs ahead ACROSS phases (the weights never depend on the activations), bounded only by the
-//     ring: up to 112 KiB of a CU's next tiles are in LDS when a phase's x arrives.  It owns the plan arithmetic (tile addresses);
-//     the consumers never touch HBM for weights.
+//     ring: up to 112 KiB of a CU's next tiles are in LDS when a phase's x arrives.  It owns the tile addresses; the consumers never
+//     touch HBM for weights.  Phase and work records reach both roles one phase ahead (scalar registers / four vector registers).
 //   * per phase (= linear) a CU owns (K-chunk s of S) x (a run of <= 16 tiles inside ONE rotation partition), tile order
-//     group-major.  Its consumers rotate the CU's own `ng` groups themselves -- ONE hop per edge: the K-chunks' fp32 partial sums
-//     {tag, fp32} of the previous linear are polled straight by the wave that needs them, added in slot order (+ bias), rounded
-//     once to the activation type (the value the reference's linear would have stored), scaled by channel_scales and run through
-//     the eight Givens stages in registers (GivensRegs, up to three groups' stage chains interleaved per wave); the rotated group
-//     and its two dequantisation sums go to LDS behind a per-group flag, so tiles of the first groups are consumed while the last
-//     are still being rotated.
-//   * a consumer's tile: one ds_read_b128 (the four B fragments), one scale / zero word, A = the rotated group broadcast to all
-//     16 MFMA rows, 4 x v_mfma_f32_16x16x32, one `ds_add_f32` into the wave's own accumulator row.  The waves' rows are added in a
-//     fixed order and published as {tag, fp32} granules (write-through stores; the data IS the flag).
+//     group-major.  Consumer wave w OWNS the groups w, w + C, ... of the CU's chunk: ONE hop per edge -- it issues the 16-byte
+//     write-through-coherent loads of those groups' {tag, fp32} partial sums FIRST, stages its first tiles (ring -> registers ->
+//     B fragments) and requests the rotation words under their flight, checks the tags (re-polls while they are not there), adds
+//     the K-chunks in slot order (+ bias), rounds ONCE to the activation type (the value the reference's linear would have
+//     stored), runs the eight Givens stages in registers (up to three groups' chains interleaved), transposes through LDS into A
+//     fragments -- and behind that there are only MFMAs: A = the group broadcast to all 16 rows, 4 x v_mfma_f32_16x16x32 per tile,
+//     the two dequantisation sums from the matrix cores too (B = ones / the unpack's offsets), one `ds_add_f32` per tile into the
+//     wave's own accumulator row.  Wide linears' remaining tiles follow two at a time.
+//   * the CU's waves meet at an LDS arrival counter; each adds the rows in wave order for ITS share of the columns and publishes
+//     {tag, fp32} granules (write-through stores; the data IS the flag).
 //   * tags = epoch + phase; the epoch word is advanced on the device by CU 0 after an arrival count: a captured launch replays
-//     without host work, nothing is ever re-armed; per-phase hop buffers.
+//     without host work, nothing is ever re-armed; per-phase hop buffers; every wait is bounded and a give-up is a NaN, never a
+//     silently wrong number.
+//
+// MEASURED (profiles/r05_engine2_timeline*.jsonl, profiles/NOTES.md round 5): parity-green at 3, 5 and 7 consumers, and SLOWER
+// than both the per-call launches and round 4's engine on every model (Qwen3-4B: 7.5 .. 8.7 us per linear against 6.5 per launch
+// and 6.5 in engine.hip).  Per phase the median CU needs ~1.2 us until its partial sums are there, ~1.0 us for the rotation chain,
+// 1 .. 4 us for its tiles and ~0.5 us to publish, and the SLOWEST CU is another ~2 us behind the median in every phase (a poll
+// that just misses the last producer pays a second trip under load).  It stays in the tree as `DecodeEngine(version=2)` /
+// `bench.py --route engine2`, not as a default: the kill criterion of VERDICT r4 item 2 applies.
 //
 // Numerics: per (K-chunk, column) the tiles are accumulated per wave in tile order, the waves in wave order, the K-chunks in slot
 // order, one rounding per linear: deterministic run to run (tests/test_gpu_engine.py), within the oracle tolerance; not
 // bit-identical to the per-call kernels (other K partition).
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -38,7 +48,7 @@
 #include "chain_impl.hpp"
 
 #ifndef PARO_E2_CONS
-#define PARO_E2_CONS 3
+#define PARO_E2_CONS 7
 #endif
 #ifndef PARO_E2_DEPTH
 #define PARO_E2_DEPTH 2
@@ -52,6 +62,14 @@ constexpr int kE2Ring = 7;                       // slots in the LDS ring
 constexpr int kE2SlotTiles = 16;
 constexpr int kE2SlotBytes = 17 * 1024;          // 16 tiles + 16 x 64 B of scale / zero words
 constexpr int kE2Depth = PARO_E2_DEPTH;          // slots the loader keeps in flight behind the one it has just issued
+#ifndef PARO_E2_STAGE1
+#define PARO_E2_STAGE1 6
+#endif
+#ifndef PARO_E2_STAGE3
+#define PARO_E2_STAGE3 2
+#endif
+constexpr int kE2StageOne = PARO_E2_STAGE1;      // tiles multiplied from registers when a wave owns one group of the K-chunk (a multiple of 3)
+constexpr int kE2StageThree = PARO_E2_STAGE3;    // ... per group when it owns more (1 or 2)
 constexpr int kE2MaxNg = 64;                     // groups of one K-chunk
 constexpr int kE2MaxNt = 16;                     // tiles of one CU's run
 constexpr int kE2MaxSplit = 4;                   // K-chunks per linear
@@ -60,17 +78,24 @@ constexpr int kE2XsStride = 136;                 // halves per rotated group in 
 constexpr unsigned kE2Spin = 1u << 20;             // bound of every wait (a give-up is sticky: later waits of the launch poll once)
 int validate_linear(const paro_linear_t* L);     // gemv.hip
 
-struct alignas(16) E2Phase {                     // 128 bytes per phase; read with scalar loads (constant address space)
+struct alignas(16) E2PhaseHead {                 // the loader's part of a phase record: 32 bytes, read with scalar loads one phase ahead
   const u32x4* wq;
   const unsigned* sz;
+  int tstride, gstride, szrow;                   // tile (t, g) = t * tstride + g * gstride (1 KiB units); words per group row of sz
+  int work_off_next;                             // first E2Work of the NEXT phase (records are fetched one phase ahead)
+};
+struct alignas(16) E2Phase {                     // 128 bytes per phase
+  E2PhaseHead h;
+  // the consumers' part: fetched one phase ahead by ONE vector load (16 bytes per lane, lanes 0..7 this record, lanes 8..9 the CU's
+  // E2Work) and spread to scalar registers with v_readlane at the head of the phase
   const unsigned* rot;
   const unsigned short* cs;                      // [P][K]
   const unsigned short* bias_prev;               // bias of the linear that produced this phase's input (added where its sums are completed)
   long long yoff, yoff_prev;                     // granule index of this phase's partial sums (slot s at yoff + s * N) / of the previous phase's
-  int tstride, gstride, szrow, work_off;         // tile (t, g) = t * tstride + g * gstride (1 KiB units); words per group row of sz; first E2Work
   int K, N, G, P;
   int S, S_prev, in_col0, N_prev;                // channel c of this phase = column in_col0 + c of the previous phase's output
-  int pad[4];
+  int work_off;                                  // first E2Work of this phase
+  int pad[5];
 };
 static_assert(sizeof(E2Phase) == 128, "phase record");
 
@@ -94,7 +119,9 @@ struct E2Args {
   const unsigned short* bias_last;
   long long yoff_last;
   int n_phases, ncu, N_last, S_last;
-  unsigned long long* trace;                     // TRACE builds: [n_phases][ncu][16] stamps of the 100 MHz counter
+  int work_off0;                                 // first E2Work of phase 0
+  int flags;                                     // bits 0..1: how the loader yields to a hand-off of its own CU (0 not at all, 1 one burst of 4 KiB in flight, 2 stands still)
+  unsigned long long* trace;                     // TRACE builds: [n_phases][ncu][8 waves][8 events] stamps of the 100 MHz counter
 };
 
 template <typename T>
@@ -174,52 +201,88 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
   typedef typename A::vec8 vec8;
   constexpr int RING_BYTES = kE2Ring * kE2SlotBytes;
   constexpr int XS_BYTES = kE2MaxNg * kE2XsStride * 2;
-  constexpr int XSUM_BYTES = kE2MaxNg * 8;
-  constexpr int GFLAG_BYTES = kE2MaxNg * 4;
   constexpr int RED_FLOATS = kE2MaxNt * 16;                               // one wave's accumulator row
   constexpr int RED_BYTES = 2 * kE2Cons * RED_FLOATS * 4;                 // double-buffered by the phase's parity
-  constexpr int CTL_BYTES = 128;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RING_BYTES + XS_BYTES + XSUM_BYTES + GFLAG_BYTES + RED_BYTES + CTL_BYTES];
+  constexpr int CTL_BYTES = 192;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RING_BYTES + XS_BYTES + RED_BYTES + CTL_BYTES];
   unsigned char* ring = lds;
   unsigned short* xs = (unsigned short*)(lds + RING_BYTES);
-  float* xsum = (float*)(lds + RING_BYTES + XS_BYTES);
-  unsigned* gflag = (unsigned*)(lds + RING_BYTES + XS_BYTES + XSUM_BYTES);
-  float* red = (float*)(lds + RING_BYTES + XS_BYTES + XSUM_BYTES + GFLAG_BYTES);
-  unsigned* lctl = (unsigned*)(lds + RING_BYTES + XS_BYTES + XSUM_BYTES + GFLAG_BYTES + RED_BYTES);
+  float* red = (float*)(lds + RING_BYTES + XS_BYTES);
+  unsigned* lctl = (unsigned*)(lds + RING_BYTES + XS_BYTES + RED_BYTES);
   unsigned* l_landed = lctl;                     // slots whose DMA has landed (a count: slot q is readable once landed > q)
+  unsigned* l_gath = lctl + 1;                   // consumer waves of this CU that are polling a hand-off right now (the loader thins its stream)
   unsigned* l_cdone = lctl + 4;                  // [kE2Cons] slots each consumer has finished reading
-  unsigned* l_pdone = lctl + 16;                 // [kE2Cons] phases each consumer has finished accumulating
+  unsigned* l_arrive = lctl + 20;                // [2] consumer waves that have finished accumulating, per phase parity (never reset)
+  unsigned* l_rdone = lctl + 22;                 // [2] consumer waves that have added up and published their share, per phase parity (never reset)
+  static_assert(kE2Cons <= 16, "control words");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cu = blockIdx.x;
-  if (tid < 32) lctl[tid] = 0u;
-  if (tid < kE2MaxNg) gflag[tid] = 0u;
+  if (tid < CTL_BYTES / 4) lctl[tid] = 0u;
   __syncthreads();
 
   auto stamp = [&](int pi, int slot) {
     if constexpr (TRACE) {
       const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0) a.trace[((long long)pi * a.ncu + cu) * 16 + slot] = t;
+      if (lane == 0) a.trace[(((long long)pi * a.ncu + cu) * 8 + wave) * 8 + slot] = t;     // [phase][cu][wave][event]
     }
   };
+  unsigned long long waited = 0;                 // TRACE: ticks of the 100 MHz counter this wave spent waiting inside the phase
+  auto tick = [&]() -> unsigned long long {
+    if constexpr (TRACE) return __builtin_amdgcn_s_memrealtime();
+    return 0ull;
+  };
+  unsigned limit = kE2Spin;                      // (0 once a wait of this launch was abandoned, here or on another CU: nothing waits twice)
+  auto bail = [&](unsigned spin) -> bool {
+    if (spin >= limit) {
+      if (lane == 0) __hip_atomic_store(a.ctl + 1, (unsigned)PARO_WS_STATUS_GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      limit = 0;
+      return true;
+    }
+    if ((spin & 2047u) == 2047u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      limit = 0;
+      return true;
+    }
+    return false;
+  };
+
+  // The phase and work records are fetched ONE PHASE AHEAD: read where they are needed they were two dependent scalar-cache misses
+  // (~0.5 us each beside a live weight stream) at the head of every phase.  The loader keeps its 64 bytes in scalar registers; a consumer
+  // wave holds the next phase's 160 bytes in four vector registers (lane j = 16-byte piece j) and spreads them with v_readlane.
 
   if (wave == 0) {
     // =================================================================== the LOADER: HBM -> LDS ring, ahead across the phases
+    __builtin_amdgcn_s_setprio(1);
     const unsigned lds_ring = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) unsigned char*)ring);
     const unsigned voff16 = (unsigned)lane * 16u;
     const int lq = lane >> 4, ln = lane & 15;
-    unsigned limit = kE2Spin;                    // (0 once a wait of this launch was abandoned: nothing waits twice)
+    const int thin_mode = a.flags & 3;            // 0: never throttled, 1 / 2: see the slot loop
+    const bool thin_on = thin_mode != 0;
+    unsigned long long gated = 0;
     unsigned seq = 0;                            // slots issued so far
     unsigned pub = 0;                            // the landed count the consumers have been told
     unsigned rslot = 0;                          // seq % kE2Ring
     int out1 = 0, out2 = 0;                      // VMEM instructions of the previous slot and of the one before (still possibly in flight)
+    E2PhaseHead ph_n = e2_sload(&a.phases[0].h);
+    E2Work wk_n = e2_sload(a.work + a.work_off0 + cu);
     for (int pi = 0; pi < a.n_phases; ++pi) {
-      const E2Phase ph = e2_sload(a.phases + pi);
-      const E2Work wk = e2_sload(a.work + ph.work_off + cu);
+#ifdef PARO_E2_DBG_SLOADREC
+      const E2Phase phf = e2_sload(a.phases + pi);
+      const E2PhaseHead ph = phf.h;
+      const E2Work wk = e2_sload(a.work + phf.work_off + cu);
+#else
+      const E2PhaseHead ph = ph_n;
+      const E2Work wk = wk_n;
+      if (pi + 1 < a.n_phases) {
+        ph_n = e2_sload(&a.phases[pi + 1].h);
+        wk_n = e2_sload(a.work + ph.work_off_next + cu);
+      }
+#endif
       const int ntile = wk.ntile, nt = wk.nt;
       const unsigned long long wqb = (unsigned long long)ph.wq, szb = (unsigned long long)ph.sz;
       int gi = 0, jt = 0;
+      waited = 0;
       for (int i0 = 0; i0 < ntile; i0 += kE2SlotTiles) {
         const int n = min(kE2SlotTiles, ntile - i0);
         if (seq >= (unsigned)kE2Ring) {
@@ -237,17 +300,36 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
             pub = seq;
             if (lane == 0) e2_lds_st(l_landed, pub);
             out1 = out2 = 0;
+            const unsigned long long t0 = tick();
             for (unsigned spin = 0; !freed(); ++spin) {
-              if (spin >= limit) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; limit = 0; break; }
+              if (bail(spin)) break;
               __builtin_amdgcn_s_sleep(2);
             }
+            waited += tick() - t0;
           }
         }
-        if (i0 == 0) stamp(pi, 8);
+        if (i0 == 0) stamp(pi, 0);
         const unsigned slot = lds_ring + rslot * (unsigned)kE2SlotBytes;
         // ---- the tiles: tile j of the slot is (group gi, tile jt) of the CU's run, group-major
 #pragma unroll
         for (int j = 0; j < kE2SlotTiles; ++j) {
+          if (thin_mode && (j & 3) == 0 && j < n) {
+            // every 4 KiB: is a consumer wave of this CU in a hand-off (polling granules, publishing partial sums)?  Its loads and
+            // stores queue behind this wave's refill burst in the CU's memory pipeline (measured: a publish of two stores per lane took
+            // 2.7 us behind an unthrottled stream).  Mode 1: drain what is in flight, then go on in 4 KiB steps; mode 2: stand still.
+            if (e2_lds_ld(l_gath) != 0u) {
+              const unsigned long long t0 = tick();
+              if (thin_mode >= 2) {
+                for (unsigned spin = 0; e2_lds_ld(l_gath) != 0u; ++spin) {
+                  if (bail(spin)) break;
+                  __builtin_amdgcn_s_sleep(1);
+                }
+              } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              }
+              gated += tick() - t0;
+            }
+          }
           if (j < n) {
             const unsigned toff = (unsigned)((wk.t0 + jt) * ph.tstride + (wk.g0 + gi) * ph.gstride);
             e2_dma16(voff16, wqb + (unsigned long long)toff * 1024ull, slot + (unsigned)j * 1024u);
@@ -267,10 +349,16 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
           }
         }
         const int cur = n + ((n + 3) >> 2);
-        // everything older than the last kE2Depth slots has landed once at most their instructions are outstanding
+        // How many slots stay in flight behind this wait: kE2Depth normally; ONE while a consumer wave of this CU polls a hand-off
+        // (its loads queue behind the CU's own refill burst otherwise: guide row gather-pass).
         {
-          const unsigned now = kE2Depth >= 2 ? seq - (seq ? 1u : 0u) : seq;        // slots 0 .. now - 1 have landed after this wait
-          e2_wait_vm(kE2Depth >= 2 ? cur + out1 : cur);
+          const bool thin = thin_on && e2_lds_ld(l_gath) != 0u;
+          int keep = cur;
+          unsigned behind = 1;                   // slots still in flight after the wait (this one included)
+          if (!thin && kE2Depth >= 2) { keep += out1; behind = 2; }
+          if (!thin && kE2Depth >= 3) { keep += out2; behind = 3; }
+          e2_wait_vm(keep);
+          const unsigned now = seq + 1u >= behind ? seq + 1u - behind : 0u;      // slots 0 .. now - 1 have landed
           if (now > pub) {
             pub = now;
             if (lane == 0) e2_lds_st(l_landed, pub);
@@ -281,14 +369,15 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
         ++seq;
         if (++rslot == (unsigned)kE2Ring) rslot = 0;
       }
-      stamp(pi, 9);
-      // a phase's tail must not wait for the NEXT phase's first slot to be issued before it counts as landed when the ring is about
-      // to stall anyway; the common case (the next phase has slots) publishes it one slot later
+      stamp(pi, 1);
+      if constexpr (TRACE) {
+        if (lane == 0) a.trace[(((long long)pi * a.ncu + cu) * 8 + 0) * 8 + 2] = waited;
+        if (lane == 0) a.trace[(((long long)pi * a.ncu + cu) * 8 + 0) * 8 + 3] = gated;
+        gated = 0;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) e2_lds_st(l_landed, seq);
-    (void)out2;
-    (void)pub;
     return;
   }
 
@@ -302,182 +391,430 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
   }
   const int mq = lane >> 4, n16 = lane & 15;
   const typename A::Unpack upk = A::unpack_consts();
-  const float off0 = A::to_f32((unsigned short)(A::kOffFrag0 & 0xffffu)), off1 = A::to_f32((unsigned short)(A::kOffFrag1 & 0xffffu));
-  unsigned seq = 0, rslot = 0;
-  unsigned limit = kE2Spin;                                  // (0 once any wait of this launch was abandoned, here or on another CU)
+  unsigned seq = 0;                                           // ring slots of the phases before this one
+  auto fetch_rec = [&](int pi, int work_off) -> u32x4 {       // lanes 0..7: the phase record, 8..9: this CU's work record, others: lane 9's
+    const int j = min(lane, 9);
+    const u32x4* src = j < 8 ? (const u32x4*)(a.phases + pi) + j : (const u32x4*)(a.work + work_off + cu) + (j - 8);
+    return *(CGP<u32x4>)src;
+  };
+  u32x4 rec_n = fetch_rec(0, a.work_off0);
 
   for (int pi = 0; pi < a.n_phases; ++pi) {
-    const E2Phase ph = e2_sload(a.phases + pi);
-    const E2Work wk = e2_sload(a.work + ph.work_off + cu);
-    if (__hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) limit = 0;
-    const unsigned tag = epoch + (unsigned)pi + 1u;          // of this phase's output (and of its rotated groups in LDS)
+    E2Phase ph;
+    E2Work wk;
+#ifdef PARO_E2_DBG_SLOADREC
+    ph = e2_sload(a.phases + pi);
+    wk = e2_sload(a.work + ph.work_off + cu);
+#else
+    {
+      unsigned w[40];
+#pragma unroll
+      for (int i = 0; i < 40; ++i) w[i] = (unsigned)__builtin_amdgcn_readlane((int)rec_n[i & 3], i >> 2);
+      __builtin_memcpy(&ph, w, 128);
+      __builtin_memcpy(&wk, w + 32, 32);
+    }
+#endif
+    if (pi + 1 < a.n_phases) rec_n = fetch_rec(pi + 1, ph.h.work_off_next);
+    const unsigned tag = epoch + (unsigned)pi + 1u;          // of this phase's output
     const unsigned tag_in = epoch + (unsigned)pi;            // of the previous phase's partial sums
     float* redp = red + ((pi & 1) * kE2Cons + cw) * RED_FLOATS;
-    if (cw == 0) stamp(pi, 0);
-    for (int o = lane; o < wk.nt * 16; o += 64) redp[o] = 0.f;
+    stamp(pi, 0);
+    waited = 0;
+    // the previous phase's granules through a buffer descriptor: 16-byte write-through-coherent loads (two granules = the lane's two
+    // channels per instruction), offsets in bytes from the phase's first granule
+    const __amdgpu_buffer_rsrc_t gsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.gran + ph.yoff_prev), 0, pi ? ph.S_prev * ph.N_prev * 8 : 0, 0x00020000);
 
-    // ---- the edge: this wave's groups (gi = cw, cw + C, ...) of the CU's K-chunk, up to three stage chains interleaved
-    auto edge = [&](auto nbtag, int gi0) {
+    // ---- Wave cw OWNS the groups gi = cw, cw + C, ... of the CU's K-chunk: it completes and rotates them (the edge) and multiplies
+    //      THEIR tiles.  The order of a phase is the order of its latencies:
+    //        1. the hand-off loads of the wave's first (up to three) groups are ISSUED -- a round trip of ~1 us;
+    //        2. under it, everything that does not depend on x: the rotation words are requested, the first tiles of those groups
+    //           (eight of one group, or two each of up to three) are read from the ring and unpacked to B fragments in registers;
+    //        3. the tags are checked (and polled again while they are not there), the partial sums added, rounded, rotated
+    //           (eight dependent cross-lane stages), transposed through LDS into A fragments;
+    //        4. behind that there are only MFMAs for the staged tiles; the rest of the tiles (wide linears) follow two at a time.
+    //      Hot paths are straight-line code: a taken branch costs ~20 ns here (profiles/NOTES.md, cold code), so a missing tile or
+    //      group is a clamped duplicate whose result adds +0 (or rewrites the same values), not a branch.
+    const int my_groups = wk.ng > cw ? (wk.ng - cw + kE2Cons - 1) / kE2Cons : 0;
+    const int nslots = (wk.ntile + kE2SlotTiles - 1) / kE2SlotTiles;
+    // groups of the first rotation batch: up to three when their staged tiles sit close enough in the ring -- a wave's groups are
+    // kE2Cons groups = kE2Cons * nt tiles apart, the loader is at most kE2Ring slots ahead of the slowest wave, and a wave that waited
+    // for a tile beyond that window while it holds back earlier slots would wait for ever -- else one
+    const int nb0 = (my_groups >= 2 && 2 * kE2Cons * wk.nt + kE2StageThree <= 4 * kE2SlotTiles) ? min(3, my_groups) : min(1, my_groups);
+    unsigned landed_seen = 0;                                // (a register copy of l_landed: most tiles' slots are known to have landed)
+    unsigned done = seq;                                     // slots of the ring this wave no longer needs (told to the loader)
+
+    // (everything a guard may skip starts defined: a value that is undefined on one path is carried around the phase loop --
+    // 36 registers of the previous phase's granules were spilled to scratch before these initialisers)
+    GivensRegs<AT, 1> gr[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) gr[b].rc[w] = (u32x4){0u, 0u, 0u, 0u};
+      gr[b].sa[0] = gr[b].sb[0] = 0.f;
+    }
+    unsigned csv[3] = {0u, 0u, 0u}, goff[3] = {0u, 0u, 0u};
+    int gis[3] = {0, 0, 0};
+    u32x4 q[3][kE2MaxSplit];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int s = 0; s < kE2MaxSplit; ++s) q[b][s] = (u32x4){0u, 0u, 0u, 0u};
+    float x0[3] = {0.f, 0.f, 0.f}, x1[3] = {0.f, 0.f, 0.f};
+    auto batch_groups = [&](int m0, int nb) {                  // the batch's groups (beyond nb: the last one again)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        gis[b] = cw + (m0 + min(b, nb - 1)) * kE2Cons;
+        goff[b] = (unsigned)(ph.in_col0 + (wk.g0 + gis[b]) * 128 + 2 * lane) * 8u;
+      }
+    };
+    auto poll_issue = [&](int nb) {                           // (uniform guards, ordered so that the common path falls through)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        if (b < nb) {
+#pragma unroll
+          for (int s = 0; s < kE2MaxSplit; ++s)
+            if (s < ph.S_prev)
+              q[b][s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(gsrc, goff[b] + (unsigned)(s * ph.N_prev) * 8u, 0, 16));   // aux 16 = sc1
+        }
+    };
+    auto poll_ok = [&](int nb) -> bool {
+      bool ok = true;
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        if (b < nb) {
+#pragma unroll
+          for (int s = 0; s < kE2MaxSplit; ++s)
+            if (s < ph.S_prev) {
+              const unsigned t0_ = q[b][s][1], t1_ = q[b][s][3];
+              ok = ok & (t0_ == tag_in) & (t1_ == tag_in);
+            }
+        }
+      return __all(ok);
+    };
+    auto rot_issue = [&](auto nbtag) {
       constexpr int NB = decltype(nbtag)::value;
-      GivensRegs<AT, 1> gr[NB];
-      unsigned csv[NB];
-      float x0[NB], x1[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int g = wk.g0 + gi0 + b * kE2Cons;
+        const int g = wk.g0 + gis[b];
         gr[b].load((CGP<unsigned>)ph.rot, (unsigned)(wk.p * ph.G + g), lane);
         csv[b] = *(CGP<unsigned>)(ph.cs + (unsigned)(wk.p * ph.K + g * 128 + 2 * lane));
       }
+    };
+    // the edge proper: x of the batch's groups is complete -> rounded, rotated, transposed into LDS rows
+    auto finish_edge = [&](auto nbtag, int nb, bool ok) {
+      constexpr int NB = decltype(nbtag)::value;
       if (pi == 0) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const int g = wk.g0 + gi0 + b * kE2Cons;
-          const unsigned xv = *(CGP<unsigned>)(a.x + (unsigned)(g * 128 + 2 * lane));
+          const unsigned xv = *(CGP<unsigned>)(a.x + (unsigned)((wk.g0 + gis[b]) * 128 + 2 * lane));
           x0[b] = A::to_f32(xv & 0xffffu);
           x1[b] = A::to_f32(xv >> 16);
         }
       } else {
-        unsigned long long q0[NB][kE2MaxSplit], q1[NB][kE2MaxSplit];
-        bool ok = false;
-        for (unsigned spin = 0; !ok; ++spin) {
-          ok = true;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const int g = wk.g0 + gi0 + b * kE2Cons;
-            const unsigned long long* src = a.gran + ph.yoff_prev + (unsigned)(ph.in_col0 + g * 128 + 2 * lane);
-            // (branch-free: the slots beyond S_prev re-read the last one -- a static request count keeps the waits counted, not drained)
-#pragma unroll
-            for (int s = 0; s < kE2MaxSplit; ++s) {
-              const long long so = (long long)min(s, ph.S_prev - 1) * ph.N_prev;
-              q0[b][s] = e2_ld_gran(src + so);
-              q1[b][s] = e2_ld_gran(src + so + 1);
-            }
-          }
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int s = 0; s < kE2MaxSplit; ++s) ok = ok && (unsigned)(q0[b][s] >> 32) == tag_in && (unsigned)(q1[b][s] >> 32) == tag_in;
-          ok = __all(ok);
-          if (!ok) {
-            if (spin >= limit) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; limit = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           float v0 = 0.f, v1 = 0.f;
+          if (b < nb) {
 #pragma unroll
-          for (int s = 0; s < kE2MaxSplit; ++s) {
-            v0 += s < ph.S_prev ? __builtin_bit_cast(float, (unsigned)q0[b][s]) : 0.f;
-            v1 += s < ph.S_prev ? __builtin_bit_cast(float, (unsigned)q1[b][s]) : 0.f;
+            for (int s = 0; s < kE2MaxSplit; ++s)
+              if (s < ph.S_prev) {                            // (slot order, as the per-call reducer adds them)
+                const unsigned u0 = q[b][s][0], u1 = q[b][s][2];   // (through scalars: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with hipcc 7.2)
+                v0 += __builtin_bit_cast(float, u0);
+                v1 += __builtin_bit_cast(float, u1);
+              }
           }
           if (!ok) v0 = v1 = __builtin_nanf("");              // a hand-off that gave up is never a silently wrong number
           if (ph.bias_prev) {
-            const int g = wk.g0 + gi0 + b * kE2Cons;
-            const unsigned bv = *(CGP<unsigned>)(ph.bias_prev + (unsigned)(ph.in_col0 + g * 128 + 2 * lane));
+            const unsigned bv = *(CGP<unsigned>)(ph.bias_prev + (unsigned)(ph.in_col0 + (wk.g0 + gis[b]) * 128 + 2 * lane));
             v0 += A::to_f32(bv & 0xffffu);
             v1 += A::to_f32(bv >> 16);
           }
           x0[b] = A::to_f32(A::from_f32(v0));                 // the one rounding of the producing linear
           x1[b] = A::to_f32(A::from_f32(v1));
         }
-      }
-      if (cw == 0 && gi0 == 0) stamp(pi, 1);
+        // (a batch of fewer than NB groups rotates its last group again: the twins take that group's input and rewrite its row with the same values)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        gr[b].prepare();
-        gr[b].seed(0, x0[b], x1[b], csv[b]);
+        for (int b = 1; b < NB; ++b)
+          if (b >= nb) { x0[b] = x0[b - 1]; x1[b] = x1[b - 1]; }
       }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) gr[b].seed(0, x0[b], x1[b], csv[b]);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gr[b].stage(t);
+        for (int b = 0; b < NB; ++b) gr[b].stage_direct(t);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int gi = gi0 + b * kE2Cons;
         unsigned short h1, h2;
         unsigned oa, ob;
         gr[b].finish_vals(h1, h2, oa, ob);
-        unsigned char* row = (unsigned char*)(xs + gi * kE2XsStride);
+        unsigned char* row = (unsigned char*)(xs + gis[b] * kE2XsStride);
         *(unsigned short*)(row + oa) = h1;
         *(unsigned short*)(row + ob) = h2;
-        // the two sums the dequantisation needs per group: sum(x) for the zero points, sum(x * off) for the offsets the cheap unpack
-        // leaves in (common.hpp: 1024 / 64 alternating per packed register for fp16, 128 for bf16); channel c sits in register (c / 2) & 1
-        const float f1 = A::to_f32(h1), f2 = A::to_f32(h2);
-        const float sx = wave_sum_dpp(f1 + f2);
-        const float so = wave_sum_dpp(f1 * ((oa & 4u) ? off1 : off0) + f2 * ((ob & 4u) ? off1 : off0));
-        if (lane == 63) *(f32x2*)(xsum + 2 * gi) = (f32x2){sx, so};
-        if (lane == 63) e2_lds_st(gflag + gi, tag);           // (a wave's LDS operations stay in order: the flag is the youngest)
+      }
+      asm volatile("" ::: "memory");                          // (the rows are read back by this wave only: its LDS operations stay in order)
+    };
+    auto poll_until = [&](int nb) -> bool {                   // the loads are in flight; true once every tag is this phase's
+      if (pi == 0) return true;
+      __hip_atomic_fetch_add(l_gath, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bool ok = poll_ok(nb);
+      for (unsigned spin = 0; !ok; ++spin) {
+        if (bail(spin)) break;
+        __builtin_amdgcn_s_sleep(1);
+        poll_issue(nb);
+        ok = poll_ok(nb);
+      }
+      __hip_atomic_fetch_sub(l_gath, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return ok;
+    };
+
+    // ---- ring access: tile i of the CU's run (group-major, i = gi * nt + jt) sits in slot seq + (i >> 4) at place i & 15
+    auto wait_landed = [&](int i_last) {
+      const unsigned need = seq + (unsigned)(i_last >> 4);    // slots land in order
+      if (landed_seen <= need) {
+        for (unsigned spin = 0; (landed_seen = e2_lds_ld(l_landed)) <= need; ++spin) {
+          if (bail(spin)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
       }
     };
-    for (int gi0 = cw; gi0 < wk.ng; gi0 += 3 * kE2Cons) {
-      const int left = (wk.ng - gi0 + kE2Cons - 1) / kE2Cons;
-      if (left >= 3) edge(std::integral_constant<int, 3>{}, gi0);
-      else if (left == 2) edge(std::integral_constant<int, 2>{}, gi0);
-      else edge(std::integral_constant<int, 1>{}, gi0);
-    }
-    if (cw == 0) stamp(pi, 2);
+    auto tile_at = [&](int i) -> const unsigned char* {
+      return ring + ((seq + (unsigned)(i >> 4)) % (unsigned)kE2Ring) * kE2SlotBytes + (i & 15) * 1024;
+    };
+    auto sz_at = [&](int i) -> const unsigned char* {
+      return ring + ((seq + (unsigned)(i >> 4)) % (unsigned)kE2Ring) * kE2SlotBytes + 16384 + (i & 15) * 64 + n16 * 4;
+    };
+    auto mark_free = [&](int i_next) {                        // this wave reads no tile below i_next any more (its reads so far are older LDS operations)
+      const unsigned nd = seq + (unsigned)(i_next < wk.ntile ? (i_next >> 4) : nslots);
+      if (nd > done) {
+        done = nd;
+        if (lane == 0) e2_lds_st(l_cdone + cw, done);
+      }
+    };
+    auto unpack16 = [&](const u32x4& pk, unsigned (&o)[16]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned w4[4];
+        A::unpack_fast(pk[k], w4, upk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[k * 4 + r] = w4[r];
+      }
+    };
+    auto mfma4 = [&](const vec8 (&af)[4], const unsigned (&b)[16]) -> f32x4 {
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32x4 w = {b[k * 4], b[k * 4 + 1], b[k * 4 + 2], b[k * 4 + 3]};
+        d = A::mfma(af[k], __builtin_bit_cast(vec8, w), d);
+      }
+      return d;
+    };
+    // A fragments of a rotated group and the two sums the dequantisation needs -- sum(x) for the zero points, sum(x * off) for the
+    // offsets the cheap unpack leaves in (common.hpp) -- from the matrix cores too (B = ones / the offsets' pattern: the k order of the tiles)
+    auto group_frags = [&](int gi, vec8 (&af)[4], float& sx, float& so) {
+      const unsigned short* xr = xs + gi * kE2XsStride + 8 * mq;     // every MFMA row carries x (16 lanes read one address: a broadcast)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) af[k] = *(const vec8*)(xr + 32 * k);
+      f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, doff = {0.f, 0.f, 0.f, 0.f};
+      const u32x4 ones4 = {A::kOnes, A::kOnes, A::kOnes, A::kOnes};
+      const u32x4 offs4 = {A::kOffFrag0, A::kOffFrag1, A::kOffFrag0, A::kOffFrag1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dsum = A::mfma(af[k], __builtin_bit_cast(vec8, ones4), dsum);
+        doff = A::mfma(af[k], __builtin_bit_cast(vec8, offs4), doff);
+      }
+      sx = dsum[0];
+      so = doff[0];
+    };
+    auto tile_value = [&](unsigned z, float d0, float sx, float so) -> float {
+      return f16_bits_to_f32(z & 0xffffu) * __builtin_fmaf(-f16_bits_to_f32(z >> 16), sx, d0 - so);
+    };
+    // the tiles jt >= jb of a rotated group, two at a time; the next pair's LDS reads fly under this pair's MFMAs
+    auto tiles_rest = [&](int gi, int jb, const vec8 (&af)[4], float sx, float so, int i_after) {
+      if (jb >= wk.nt) return;
+      const int ibase = gi * wk.nt, ilast = ibase + wk.nt - 1;
+      u32x4 pa, pb;
+      unsigned za, zb;
+      {
+        const int ia = ibase + jb, ib = min(ia + 1, ilast);
+        wait_landed(ib);
+        pa = *(const u32x4*)(tile_at(ia) + lane * 16);
+        pb = *(const u32x4*)(tile_at(ib) + lane * 16);
+        za = *(const unsigned*)sz_at(ia);
+        zb = *(const unsigned*)sz_at(ib);
+      }
+      for (int jt = jb; jt < wk.nt; jt += 2) {
+        unsigned ba[16], bb[16];
+        unpack16(pa, ba);
+        unpack16(pb, bb);
+        const unsigned z0 = za, z1 = zb;
+        const int two = jt + 1 < wk.nt ? 1 : 0;
+        {
+          // (the pair after this one, clamped to the group's last tile: a finished group re-reads it, nothing branches)
+          const int ia = min(ibase + jt + 2, ilast), ib = min(ia + 1, ilast);
+          wait_landed(ib);
+          pa = *(const u32x4*)(tile_at(ia) + lane * 16);
+          pb = *(const u32x4*)(tile_at(ib) + lane * 16);
+          za = *(const unsigned*)sz_at(ia);
+          zb = *(const unsigned*)sz_at(ib);
+          mark_free(jt + 2 < wk.nt ? ia : i_after);
+        }
+        const f32x4 d0 = mfma4(af, ba), d1 = mfma4(af, bb);
+        const float v0 = tile_value(z0, d0[0], sx, so);
+        const float v1 = two ? tile_value(z1, d1[0], sx, so) : 0.f;   // (a lone tile's twin is the tile itself: it adds +0 to the same column)
+        if (lane < 16) {
+          __hip_atomic_fetch_add(redp + jt * 16 + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(redp + (jt + two) * 16 + lane, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    };
 
-    // ---- the CU's tiles, slot by slot: this wave's contiguous share of every slot
-    int cur_g = -1;
-    vec8 af[4];
-    f32x2 sums = {0.f, 0.f};
-    bool first = true;
-    for (int i0 = 0; i0 < wk.ntile; i0 += kE2SlotTiles) {
-      const int n = min(kE2SlotTiles, wk.ntile - i0);
-      for (unsigned spin = 0; e2_lds_ld(l_landed) <= seq; ++spin) {
-        if (spin >= limit) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; limit = 0; break; }
+    if (my_groups > 0) {
+      // ================= 1. the first batch's hand-off loads
+      batch_groups(0, nb0);
+      if (pi != 0) poll_issue(nb0);
+      stamp(pi, 1);
+      // ================= 2. under their flight.  This wave's accumulator row of parity pi & 1 was last read by the reductions of
+      //                      phase pi - 2: every wave's share must be done before it is cleared
+      if (pi >= 2) {
+        const unsigned need = (unsigned)(pi >> 1) * (unsigned)kE2Cons;
+        for (unsigned spin = 0; e2_lds_ld(l_rdone + (pi & 1)) < need; ++spin) {
+          if (bail(spin)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      for (int o = lane; o < wk.nt * 16; o += 64) redp[o] = 0.f;
+      const int i_batch1 = my_groups > nb0 ? (cw + nb0 * kE2Cons) * wk.nt : wk.ntile; // the first tile this wave reads after its first batch
+      int staged = 0;                                       // tiles per group of the first batch that were multiplied from registers
+      if (nb0 == 1) {
+        // ---------- one group: its first six tiles staged
+        constexpr int PJ = kE2StageOne;
+        staged = PJ;
+        rot_issue(std::integral_constant<int, 1>{});
+        const int ibase = gis[0] * wk.nt, ilast = ibase + wk.nt - 1;
+        unsigned bf[PJ][16], zq[PJ];
+        wait_landed(min(ibase + PJ - 1, ilast));
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+          const int i = min(ibase + j, ilast);
+          const u32x4 pk = *(const u32x4*)(tile_at(i) + lane * 16);
+          zq[j] = *(const unsigned*)sz_at(i);
+          unpack16(pk, bf[j]);
+        }
+        mark_free(wk.nt > PJ ? ibase + PJ : i_batch1);
+        // ================= 3.
+        const bool ok = poll_until(1);
+        stamp(pi, 2);
+        finish_edge(std::integral_constant<int, 1>{}, 1, ok);
+        stamp(pi, 3);
+        // ================= 4.
+        vec8 af[4];
+        float sx, so;
+        group_frags(gis[0], af, sx, so);
+#pragma unroll
+        for (int h = 0; h < PJ; h += 3) {
+          f32x4 d[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) d[u] = mfma4(af, bf[h + u]);
+          float v[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) v[u] = h + u < wk.nt ? tile_value(zq[h + u], d[u][0], sx, so) : 0.f;
+          if (lane < 16) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+              __hip_atomic_fetch_add(redp + min(h + u, wk.nt - 1) * 16 + lane, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      } else {
+        // ---------- two or three groups (or the first three of more): two tiles of each staged
+        constexpr int PJ = kE2StageThree;
+        staged = PJ;
+        rot_issue(std::integral_constant<int, 3>{});
+        unsigned bf[3][PJ][16], zq[3][PJ];
+        wait_landed(gis[2] * wk.nt + min(PJ, wk.nt) - 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int j = 0; j < PJ; ++j) {
+            const int i = gis[m] * wk.nt + min(j, wk.nt - 1);
+            const u32x4 pk = *(const u32x4*)(tile_at(i) + lane * 16);
+            zq[m][j] = *(const unsigned*)sz_at(i);
+            unpack16(pk, bf[m][j]);
+          }
+        mark_free(wk.nt > PJ ? gis[0] * wk.nt + PJ : i_batch1);
+        const bool ok = poll_until(nb0);
+        stamp(pi, 2);
+        finish_edge(std::integral_constant<int, 3>{}, nb0, ok);
+        stamp(pi, 3);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          vec8 af[4];
+          float sx, so;
+          group_frags(gis[m], af, sx, so);
+          f32x4 d[PJ];
+#pragma unroll
+          for (int j = 0; j < PJ; ++j) d[j] = mfma4(af, bf[m][j]);
+          const bool live = m < nb0;                        // (a twin group's tiles add +0)
+          float v[PJ];
+#pragma unroll
+          for (int j = 0; j < PJ; ++j) v[j] = live && j < wk.nt ? tile_value(zq[m][j], d[j][0], sx, so) : 0.f;
+          if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < PJ; ++j)
+              __hip_atomic_fetch_add(redp + min(j, wk.nt - 1) * 16 + lane, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      // ================= the rest: what was not staged of the first batch's groups (wide linears), then further rotation batches
+      //                   (deep K-chunks: edge, then the groups' tiles), everything two tiles at a time
+      for (int m0 = 0; m0 < my_groups; m0 += (m0 == 0 ? nb0 : 3)) {
+        const int nb = m0 == 0 ? nb0 : min(3, my_groups - m0);
+        int jb = staged;
+        if (m0 != 0) {
+          jb = 0;
+          batch_groups(m0, nb);
+          if (pi != 0) poll_issue(nb);
+          rot_issue(std::integral_constant<int, 3>{});
+          const bool ok = poll_until(nb);
+          finish_edge(std::integral_constant<int, 3>{}, nb, ok);
+        }
+        if (jb < wk.nt) {
+          for (int b = 0; b < nb; ++b) {
+            vec8 af[4];
+            float sx, so;
+            group_frags(gis[b], af, sx, so);
+            const int i_after = b + 1 < nb ? gis[b + 1] * wk.nt + jb : (m0 + nb < my_groups ? (cw + (m0 + nb) * kE2Cons) * wk.nt : wk.ntile);
+            tiles_rest(gis[b], jb, af, sx, so, i_after);
+          }
+        }
+      }
+    } else {
+      stamp(pi, 1);
+      if (pi >= 2) {
+        const unsigned need = (unsigned)(pi >> 1) * (unsigned)kE2Cons;
+        for (unsigned spin = 0; e2_lds_ld(l_rdone + (pi & 1)) < need; ++spin) {
+          if (bail(spin)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      for (int o = lane; o < wk.nt * 16; o += 64) redp[o] = 0.f;
+    }
+    mark_free(wk.ntile);
+    seq += (unsigned)nslots;
+    stamp(pi, 4);
+
+    // ---- every consumer of the CU has accumulated its share: each adds the waves' rows (in wave order) for ITS share of the columns and
+    //      publishes {tag, fp32}.  (One wave doing it for all -- the last to arrive -- was measured: that wave enters the next phase 4 us
+    //      behind its siblings, is the last to arrive again, and the whole chain runs at the pace of one wave.)
+    {
+      if (lane == 0) __hip_atomic_fetch_add(l_arrive + (pi & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned all = (unsigned)((pi >> 1) + 1) * (unsigned)kE2Cons;
+      for (unsigned spin = 0; e2_lds_ld(l_arrive + (pi & 1)) < all; ++spin) {
+        if (bail(spin)) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      const int lo = (n * cw) / kE2Cons, hi = (n * (cw + 1)) / kE2Cons;
-      const unsigned char* slot = ring + rslot * kE2SlotBytes;
-      for (int idx = lo; idx < hi; ++idx) {
-        const int i = i0 + idx;
-        const int gi = (i * wk.inv_nt) >> 16, jt = i - gi * wk.nt;
-        const u32x4 q = *(const u32x4*)(slot + idx * 1024 + lane * 16);
-        const unsigned szw = *(const unsigned*)(slot + 16384 + idx * 64 + n16 * 4);
-        if (gi != cur_g) {
-          for (unsigned spin = 0; e2_lds_ld(gflag + gi) != tag; ++spin) {
-            if (spin >= limit) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; limit = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          const unsigned short* xr = xs + gi * kE2XsStride + 8 * mq;   // every MFMA row carries x (16 lanes read one address: a broadcast)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) af[k] = *(const vec8*)(xr + 32 * k);
-          sums = *(const f32x2*)(xsum + 2 * gi);
-          cur_g = gi;
-        }
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          unsigned w4[4];
-          A::unpack_fast(q[k], w4, upk);
-          const u32x4 wv4 = {w4[0], w4[1], w4[2], w4[3]};
-          d = A::mfma(af[k], __builtin_bit_cast(vec8, wv4), d);
-        }
-        const float s = f16_bits_to_f32(szw & 0xffffu), zf = f16_bits_to_f32(szw >> 16);
-        const float v = s * __builtin_fmaf(-zf, sums[0], d[0] - sums[1]);
-        if (lane < 16) __hip_atomic_fetch_add(redp + jt * 16 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cw == 0 && first) { stamp(pi, 3); first = false; }
-      }
-      ++seq;
-      if (lane == 0) e2_lds_st(l_cdone + cw, seq);           // (release: this wave's reads of the slot are complete)
-      if (++rslot == (unsigned)kE2Ring) rslot = 0;
-    }
-    if (cw == 0) stamp(pi, 4);
-
-    // ---- every consumer of the CU has accumulated its share: add the waves' rows in wave order, publish {tag, fp32}
-    if (lane == 0) e2_lds_st(l_pdone + cw, (unsigned)pi + 1u);
-    for (unsigned spin = 0;; ++spin) {
-      unsigned m = e2_lds_ld(l_pdone);
-#pragma unroll
-      for (int w = 1; w < kE2Cons; ++w) m = min(m, e2_lds_ld(l_pdone + w));
-      if (m >= (unsigned)pi + 1u) break;
-      if (spin >= limit) { if (lane == 0) a.ctl[1] = PARO_WS_STATUS_GIVEUP; limit = 0; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (cw == 0) stamp(pi, 5);
-    {
+      stamp(pi, 5);
       const float* r0 = red + (pi & 1) * kE2Cons * RED_FLOATS;
       for (int o = cw * 64 + lane; o < wk.nt * 16; o += kE2Cons * 64) {
         float v = 0.f;
@@ -485,8 +822,10 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
         for (int w = 0; w < kE2Cons; ++w) v += r0[w * RED_FLOATS + o];
         e2_st_gran(a.gran + ph.yoff + (long long)wk.s * ph.N + (unsigned)(wk.t0 * 16 + o), tag, __builtin_bit_cast(unsigned, v));
       }
+      // rows of this parity are free again once EVERY wave has read its share: counted like the arrivals
+      if (lane == 0) __hip_atomic_fetch_add(l_rdone + (pi & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      stamp(pi, 6);
     }
-    if (cw == 0) stamp(pi, 6);
   }
 
   // ---- the last phase's outputs: completed like an edge's input (slots in order, bias, one rounding), 128 columns per task
@@ -509,7 +848,7 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
               ok = ok && (unsigned)(g0[s] >> 32) == tag_in && (unsigned)(g1[s] >> 32) == tag_in;
             }
           if (!ok) {
-            if (spin >= limit) { a.ctl[1] = PARO_WS_STATUS_GIVEUP; break; }
+            if (spin >= limit) { __hip_atomic_store(a.ctl + 1, (unsigned)PARO_WS_STATUS_GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -526,7 +865,9 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
           v0 += A::to_f32(bv & 0xffffu);
           v1 += A::to_f32(bv >> 16);
         }
+#ifndef PARO_E2_DBG_DUMPX
         *(unsigned*)(a.y + c) = (unsigned)A::from_f32(v0) | ((unsigned)A::from_f32(v1) << 16);
+#endif
       }
     }
     // the next launch's tags start above this launch's: CU 0 waits (bounded) until every CU has read the epoch, clears the count and
@@ -549,8 +890,14 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
 }
 
 // ------------------------------------------------------------------------------------------------ host: the plan
+static int e2_env_int(const char* name, int dflt) {          // experiment knobs (tools/engine2_timeline.py); read per call, never cached
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 struct E2PhasePlan {
   int S = 1;
+  int ng_max = 0;                    // groups of the deepest K-chunk (what a CU gathers per slot of its predecessor)
   std::vector<E2Work> work;          // per CU
   long long cost = 0;
 };
@@ -586,6 +933,9 @@ static bool e2_plan_phase(const paro_linear_t* L, int ncu, int S, E2PhasePlan& o
     out.work.assign(ncu, idle);
   }
   long long worst = 0, total = 0;
+  // the cost model's constants (shader cycles; profiles/r05_engine2_timeline*.jsonl): PARO_E2_COST=rot,poll,pair,split overrides them
+  long long c_rot = 2400, c_poll = 2400, c_pair = 300, c_split = 300;
+  if (const char* v = getenv("PARO_E2_COST")) sscanf(v, "%lld,%lld,%lld,%lld", &c_rot, &c_poll, &c_pair, &c_split);
   for (int s = 0; s < S; ++s) {
     const int g0 = (int)((long long)G * s / S), ng = (int)((long long)G * (s + 1) / S) - g0;
     if (ng > kE2MaxNg || ng < 1) return false;
@@ -602,20 +952,28 @@ static bool e2_plan_phase(const paro_linear_t* L, int ncu, int S, E2PhasePlan& o
         if (w.nt > kE2MaxNt || w.nt < 1) return false;
         w.inv_nt = (65536 + w.nt - 1) / w.nt;
         w.ntile = w.nt * w.ng;
-        // cycles between "x is there" and "outputs published": the wave's rotation batches (three groups per batch), then its share of the tiles
+        // shader cycles between "x is there" and "outputs published" for the CU's busiest wave (it owns every kE2Cons-th group): its
+        // rotation batches (the first of up to three groups when their staged tiles fit the ring window, else one; then threes; every
+        // batch after the first polls again), then nt tiles per group, two at a time (the first batch's first tiles come from registers)
         const int gpw = (ng + kE2Cons - 1) / kE2Cons;
-        const long long rot = (long long)((gpw + 2) / 3) * 1300;
-        const long long eat = (long long)((w.ntile + kE2Cons - 1) / kE2Cons) * 135;
+        const int nb0 = (gpw >= 2 && 2 * kE2Cons * w.nt + kE2StageThree <= 4 * kE2SlotTiles) ? std::min(3, gpw) : 1;
+        const int batches = 1 + (gpw - nb0 + 2) / 3;
+        const long long rot = (long long)batches * c_rot + (long long)(batches - 1) * c_poll;
+        const int staged = nb0 == 1 ? std::min((int)w.nt, kE2StageOne) : nb0 * std::min((int)w.nt, kE2StageThree);
+        const long long eat = (long long)std::max(0, (gpw * w.nt - staged + 1) / 2) * c_pair + (long long)staged * (c_pair / 4);
         worst = std::max(worst, rot + eat);
         total += w.ntile;
       }
     }
   }
   // the stream is hidden behind the edges as long as the ring holds a phase's share; what stays visible is the slowest CU's chain
-  // plus what a split costs the NEXT linear (S slots to poll per group) and the chip-wide imbalance of the stream (98 cycles / KiB at 25 GB/s)
+  // plus what a split costs the NEXT linear (S slots to gather per group) and the chip-wide imbalance of the stream (98 cycles / KiB at 25 GB/s)
   long long mx = 0;
   for (const E2Work& w : out.work) mx = std::max<long long>(mx, w.ntile);
-  out.cost = worst + 150ll * S + std::max(0ll, mx - total / ncu) * 98;
+  out.cost = worst + std::max(0ll, mx - total / ncu) * 98;
+  out.ng_max = 0;
+  for (const E2Work& w : out.work) out.ng_max = std::max(out.ng_max, (int)w.ng);
+  (void)c_split;
   return true;
 }
 
@@ -649,49 +1007,88 @@ static int e2_build_plan(const paro_engine_phase_t* ph, int n, int ncu, E2PlanHo
   }
   H.phases.resize(n);
   H.work.clear();
-  struct Key { long long K, N; int P; int cols[PARO_MAX_PARTS]; int force; int off; int S; };
-  std::vector<Key> seen;
+  // ---- the distinct linear shapes of the chain, their candidate plans per K-chunk count, and the choice: a linear's K-chunks are
+  //      what its SUCCESSOR gathers per group (ng_next * S granule rows of 1 KiB per CU, ~c_gath cycles each through a CU's memory
+  //      pipeline beside the weight stream), so the counts are chosen together -- coordinate descent from the cheapest per-shape
+  //      choice over the whole chain (chains repeat a layer's few shapes: a sweep is shapes x 4 evaluations of an O(n) sum)
+  struct Shape { long long K, N; int P; int cols[PARO_MAX_PARTS]; int force; E2PhasePlan cand[kE2MaxSplit + 1]; bool ok[kE2MaxSplit + 1]; int S; int off; };
+  std::vector<Shape> shapes;
+  std::vector<int> shape_of(n);
+  for (int i = 0; i < n; ++i) {
+    const paro_linear_t* L = ph[i].L;
+    const int force = ph[i].flags & 0xf;                     // 0: the planner's choice; 1..4: this many K-chunks (tuning, tests)
+    int id = -1;
+    for (size_t k = 0; k < shapes.size() && id < 0; ++k) {
+      bool same = shapes[k].K == L->K && shapes[k].N == L->N && shapes[k].P == L->n_parts && shapes[k].force == force;
+      for (int p = 0; same && p < L->n_parts; ++p) same = shapes[k].cols[p] == L->part_cols[p];
+      if (same) id = (int)k;
+    }
+    if (id < 0) {
+      if ((int)shapes.size() >= kE2MaxShapes) return fail(PARO_ERR_UNSUPPORTED, "engine: more than %d distinct linear shapes in one chain", kE2MaxShapes);
+      shapes.emplace_back();
+      Shape& sh = shapes.back();
+      sh.K = L->K; sh.N = L->N; sh.P = L->n_parts; sh.force = force; sh.S = 0; sh.off = 0;
+      for (int p = 0; p < PARO_MAX_PARTS; ++p) sh.cols[p] = p < L->n_parts ? L->part_cols[p] : 0;
+      for (int sp = 1; sp <= kE2MaxSplit; ++sp) {
+        sh.ok[sp] = (!force || sp == force) && e2_plan_phase(L, ncu, sp, sh.cand[sp]);
+        if (sh.ok[sp] && (sh.S == 0 || sh.cand[sp].cost < sh.cand[sh.S].cost)) sh.S = sp;
+      }
+      if (sh.S == 0) return fail(PARO_ERR_UNSUPPORTED, "engine: no work split for a [%lld, %lld] linear on %d compute units", (long long)L->K, (long long)L->N, ncu);
+      id = (int)shapes.size() - 1;
+    }
+    shape_of[i] = id;
+  }
+  {
+    long long c_gath = 90;
+    if (const char* v = getenv("PARO_E2_COST_GATHER")) c_gath = atoll(v);
+    auto total = [&]() {
+      long long t = 0;
+      for (int i = 0; i < n; ++i) {
+        const Shape& sh = shapes[shape_of[i]];
+        t += sh.cand[sh.S].cost;
+        if (i > 0) t += c_gath * sh.cand[sh.S].ng_max * shapes[shape_of[i - 1]].S;
+      }
+      return t;
+    };
+    for (int sweep = 0; sweep < 4; ++sweep) {
+      bool moved = false;
+      for (Shape& sh : shapes) {
+        int best = sh.S;
+        long long bc = total();
+        const int keep = sh.S;
+        for (int sp = 1; sp <= kE2MaxSplit; ++sp) {
+          if (!sh.ok[sp] || sp == keep) continue;
+          sh.S = sp;
+          const long long c = total();
+          if (c < bc) { bc = c; best = sp; }
+        }
+        sh.S = best;
+        moved = moved || best != keep;
+      }
+      if (!moved) break;
+    }
+  }
+  for (Shape& sh : shapes) {
+    sh.off = (int)H.work.size();
+    H.shape_off.push_back(sh.off);
+    H.work.insert(H.work.end(), sh.cand[sh.S].work.begin(), sh.cand[sh.S].work.end());
+  }
   int S_prev = 1;
   long long gran = 0, yoff_prev = 0;
   for (int i = 0; i < n; ++i) {
     const paro_linear_t* L = ph[i].L;
     const int G = (int)(L->K / 128);
-    const int force = ph[i].flags & 0xf;                     // 0: the planner's choice; 1..8: this many K-chunks (tuning, tests)
-    int off = -1, S = 1;
-    for (const Key& k : seen) {
-      bool same = k.K == L->K && k.N == L->N && k.P == L->n_parts && k.force == force;
-      for (int p = 0; same && p < L->n_parts; ++p) same = k.cols[p] == L->part_cols[p];
-      if (same) { off = k.off; S = k.S; break; }
-    }
-    if (off < 0) {
-      E2PhasePlan best;
-      bool any = false;
-      for (int s = 1; s <= kE2MaxSplit; ++s) {
-        if (force && s != force) continue;
-        E2PhasePlan cand;
-        if (!e2_plan_phase(L, ncu, s, cand)) continue;
-        if (!any || cand.cost < best.cost) { best = cand; any = true; }
-      }
-      if (!any) return fail(PARO_ERR_UNSUPPORTED, "engine: no work split for a [%lld, %lld] linear on %d compute units", (long long)L->K, (long long)L->N, ncu);
-      if ((int)seen.size() >= kE2MaxShapes) return fail(PARO_ERR_UNSUPPORTED, "engine: more than %d distinct linear shapes in one chain", kE2MaxShapes);
-      off = (int)H.work.size();
-      S = best.S;
-      H.shape_off.push_back(off);
-      H.work.insert(H.work.end(), best.work.begin(), best.work.end());
-      Key k{L->K, L->N, L->n_parts, {0}, force, off, S};
-      for (int p = 0; p < L->n_parts; ++p) k.cols[p] = L->part_cols[p];
-      seen.push_back(k);
-    }
+    const int off = shapes[shape_of[i]].off, S = shapes[shape_of[i]].S;
     E2Phase& e = H.phases[i];
     memset(&e, 0, sizeof(e));
     PartTable pt;
     fill_part_table(pt, L->n_parts, L->part_cols, 1);
-    e.wq = (const u32x4*)L->wq; e.sz = (const unsigned*)L->sz; e.rot = (const unsigned*)L->rot; e.cs = (const unsigned short*)L->channel_scales;
+    e.h.wq = (const u32x4*)L->wq; e.h.sz = (const unsigned*)L->sz; e.rot = (const unsigned*)L->rot; e.cs = (const unsigned short*)L->channel_scales;
     e.bias_prev = i > 0 ? (const unsigned short*)ph[i - 1].L->bias : nullptr;
     e.G = G;
-    e.tstride = L->wq_order ? 1 : G;
-    e.gstride = L->wq_order ? pt.tiles : 1;
-    e.szrow = (pt.tsz >> 2) * 64;
+    e.h.tstride = L->wq_order ? 1 : G;
+    e.h.gstride = L->wq_order ? pt.tiles : 1;
+    e.h.szrow = (pt.tsz >> 2) * 64;
     e.P = L->n_parts; e.S = S; e.S_prev = S_prev;
     e.in_col0 = (int)ph[i].in_col0;
     e.N = (int)L->N; e.K = (int)L->K;
@@ -703,6 +1100,7 @@ static int e2_build_plan(const paro_engine_phase_t* ph, int n, int ncu, E2PlanHo
     yoff_prev = e.yoff;
     S_prev = S;
   }
+  for (int i = 0; i + 1 < n; ++i) H.phases[i].h.work_off_next = H.phases[i + 1].work_off;
   H.S_last = S_prev;
   H.yoff_last = yoff_prev;
   H.granules = gran;
@@ -732,6 +1130,8 @@ static int e2_launch(const paro_engine_t* e, const void* plan_dev, const void* x
   a.N_last = (int)e->out_features;
   a.S_last = e->last_split;
   a.trace = trace;
+  a.work_off0 = 0;                               // (phase 0's shape is the first one planned)
+  a.flags = (e2_env_int("PARO_E2_THIN", 0) & 3) | (e2_env_int("PARO_E2_SLOWPOLL", 0) ? 8 : 0);
   // every workgroup of the grid must be resident at once (they wait for each other): one workgroup per CU -- checked per DEVICE
   {
     int dev = 0;

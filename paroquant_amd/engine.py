@@ -24,16 +24,17 @@ from . import ops
 class DecodeEngine:
     def __init__(self, layers: Sequence, in_col0: Optional[Sequence[int]] = None, dtype: torch.dtype = torch.float16, n_cus: int = 0,
                  version: int = 0, split: Optional[Sequence[int]] = None):
-        """``version`` 2: the loader / consumer build on the LDS-DMA ring (csrc/engine2.hip, ``paro_engine2_*``), 1: round 4's sixteen-wave
-        build (csrc/engine.hip); 0: ``PARO_ENGINE_VERSION`` or the default.  ``split`` (version 2): K-chunks per linear, 0 = the planner's."""
+        """``version`` 1: the sixteen-wave build (csrc/engine.hip, ``paro_engine_*``) -- the default: it is the faster one on every measured
+        model (profiles/NOTES.md, round 5); 2: the loader / consumer build on the LDS-DMA ring (csrc/engine2.hip, ``paro_engine2_*``);
+        0: ``PARO_ENGINE_VERSION`` or the default.  ``split`` (version 2): K-chunks per linear, 0 = the planner's."""
         import os
         lib = nat.load()
-        self.version = int(version) or int(os.environ.get("PARO_ENGINE_VERSION", "2"))
+        self.version = int(version) or int(os.environ.get("PARO_ENGINE_VERSION", "1"))
         if self.version not in (1, 2):
             raise ValueError("engine version must be 1 or 2")
         pre = "paro_engine_" if self.version == 1 else "paro_engine2_"
         self._fn = {k: getattr(lib, pre + k) for k in ("plan", "build", "describe", "run", "trace")}
-        self._trace_words = 32 if self.version == 1 else 16
+        self._trace_words = 32 if self.version == 1 else 64
         if not layers:
             raise ValueError("DecodeEngine needs at least one linear")
         self.layers = list(layers)

@@ -1,5 +1,5 @@
-"""GPU tests of the persistent decode engine (``paro_engine_*``, csrc/engine.hip; ``paroquant_amd.engine.DecodeEngine``): a chain of
-ParoQuant linears at batch 1 in ONE launch.  Checked against the CPU oracle applied linear by linear on the same seeded inputs (the
+"""GPU tests of the persistent decode engines (``paro_engine_*``, csrc/engine.hip, and the loader / consumer build ``paro_engine2_*``,
+csrc/engine2.hip; ``paroquant_amd.engine.DecodeEngine(version=1 | 2)``): a chain of ParoQuant linears at batch 1 in ONE launch.  Checked against the CPU oracle applied linear by linear on the same seeded inputs (the
 north star's 1e-2 gate, and the tight tolerance of tests/test_gpu_parity.py per stage), against the per-call kernels on the same chain,
 and for run-to-run bit identity (eager and HIP-graph replay): the engine's hand-offs are placement-independent by construction, the
 determinism loop is what would catch a protocol error that a tolerance test passes most of the time."""
@@ -30,13 +30,17 @@ SINGLE = [(256, [48, 16]), (1024, [2048, 1024, 1024]), (2560, [4096, 1024, 1024]
           (4096, [4096]), (512, [16]), (128, [272])]
 
 
+VERSIONS = [1, 2]
+
+
+@pytest.mark.parametrize("version", VERSIONS)
 @pytest.mark.parametrize("K,sizes", SINGLE)
 @pytest.mark.parametrize("dtype,act,tol", [(torch.float16, "f16", TIGHT_F16), (torch.bfloat16, "bf16", TIGHT_BF16)])
-def test_engine_single_linear_matches_oracle(dev, K, sizes, dtype, act, tol):
+def test_engine_single_linear_matches_oracle(dev, K, sizes, dtype, act, tol, version):
     from paroquant_amd.engine import DecodeEngine
     L = po.make_layer(K + sum(sizes), K, sizes, bias=(K == 4096))
     pk = _packed(L, dev, L.get("bias"))
-    eng = DecodeEngine([pk], dtype=dtype)
+    eng = DecodeEngine([pk], dtype=dtype, version=version)
     rng = np.random.default_rng(K)
     x = _t(rng.standard_normal((1, K)).astype(np.float32), dev, dtype)
     y = eng(x).clone()
@@ -63,12 +67,16 @@ CHAINS = [
     ([(512, [400, 112]), (256, [384]), (384, [128, 64])], [0, 144, 0]),
     # Llama-3-8B o -> gate_up -> down (the widest edge: 28672 partial-sum columns)
     ([(4096, [4096]), (4096, [14336, 14336]), (14336, [4096])], [0, 0, 0]),
+    # a very deep consumer behind a wide producer (Llama-3-70B-class down_proj: 224 groups -- several rotation batches per wave in
+    # engine 2 -- and a phase whose tiles exceed the loader's ring several times over)
+    ([(1024, [28672]), (28672, [512])], [0, 0]),
 ]
 
 
+@pytest.mark.parametrize("version", VERSIONS)
 @pytest.mark.parametrize("ci", range(len(CHAINS)))
 @pytest.mark.parametrize("dtype,act,tol", [(torch.float16, "f16", TIGHT_F16), (torch.bfloat16, "bf16", TIGHT_BF16)])
-def test_engine_chain_matches_oracle_and_per_call_kernels(dev, ci, dtype, act, tol):
+def test_engine_chain_matches_oracle_and_per_call_kernels(dev, ci, dtype, act, tol, version):
     from paroquant_amd.engine import DecodeEngine
     shapes, in_col0 = CHAINS[ci]
     layers = []
@@ -79,7 +87,7 @@ def test_engine_chain_matches_oracle_and_per_call_kernels(dev, ci, dtype, act, t
         L["scales"] = (L["scales"].astype(np.float32) * gain).astype(np.float16)
         layers.append(L)
     pks = [_packed(L, dev, L.get("bias")) for L in layers]
-    eng = DecodeEngine(pks, in_col0=in_col0, dtype=dtype)
+    eng = DecodeEngine(pks, in_col0=in_col0, dtype=dtype, version=version)
     rng = np.random.default_rng(ci)
     x = _t(rng.standard_normal((1, shapes[0][0])).astype(np.float32), dev, dtype)
     y = eng(x).clone()
@@ -104,7 +112,8 @@ def test_engine_chain_matches_oracle_and_per_call_kernels(dev, ci, dtype, act, t
     assert not torch.equal(y2, y) and torch.equal(eng(x), y)
 
 
-def test_engine_graph_replay_and_determinism(dev):
+@pytest.mark.parametrize("version", VERSIONS)
+def test_engine_graph_replay_and_determinism(dev, version):
     """One captured launch replayed 200 times on changing inputs: every replay equals the eager result of the same input bit for bit
     (no host work between replays: the epoch word advances on the device)."""
     from paroquant_amd.engine import DecodeEngine
@@ -115,7 +124,7 @@ def test_engine_graph_replay_and_determinism(dev):
         gain = 1.0 / (6.52 * np.sqrt(K) * np.sqrt(1.75) * np.sqrt(13.0 / 12.0)) / 0.011
         L["scales"] = (L["scales"].astype(np.float32) * gain).astype(np.float16)
         pks.append(_packed(L, dev))
-    eng = DecodeEngine(pks)
+    eng = DecodeEngine(pks, version=version)
     xs = [torch.randn(1, 2560, device=dev, dtype=torch.float16) for _ in range(4)]
     eager = [eng(x).clone() for x in xs]
     xbuf = xs[0].clone()
@@ -135,8 +144,10 @@ def test_engine_graph_replay_and_determinism(dev):
     assert all(s_ >= 1 and mx >= mn for s_, mx, mn in eng.describe())
 
 
-def test_engine_argument_errors(dev):
-    from paroquant_amd.engine import DecodeEngine
+@pytest.mark.parametrize("version", VERSIONS)
+def test_engine_argument_errors(dev, version):
+    from paroquant_amd.engine import DecodeEngine as _DE
+    DecodeEngine = lambda *a_, **k_: _DE(*a_, version=version, **k_)
     a = _packed(po.make_layer(1, 256, [128]), dev)
     b = _packed(po.make_layer(2, 256, [64]), dev)
     with pytest.raises(RuntimeError, match="reads columns"):

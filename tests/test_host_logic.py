@@ -667,3 +667,58 @@ def test_round4_launch_shape_heuristics():
     # the un-merged k_proj / v_proj of an HF module tree; o_proj keeps its one-row shape at 2..4 rows and stays fused to 16 rows
     assert shape(4096, [1024]) == (1, 4, 4, 0)
     assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 4, 8, 0)
+
+
+def test_engine2_planner_covers_every_tile_once(lib):
+    """`paro_engine2_plan / _build` (host only; csrc/engine2.hip): the plan blob decoded here -- every (group, 16-column tile) of every
+    linear belongs to exactly ONE compute unit, a CU's run of tiles lies inside one rotation partition and fits a ring slot row
+    (<= 16 tiles), the K-chunks partition the groups, every record names the next phase's work records (they are fetched one phase
+    ahead), the partial-sum slabs do not overlap; forced K-chunk counts are honoured."""
+    import ctypes
+    import numpy as np
+    from paroquant_amd import _native as nat
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import engine2_plan as ep
+
+    cases = {256: list(ep.MODELS.values()) + [ep.MODELS["qwen3-4b"] * 2],
+             64: [[(512, [400, 112]), (512, [384]), (384, [128, 64, 16])]]}
+    for ncu, chains in cases.items():
+        for shapes in chains:
+            for split in (None, [2], [1, 2, 3, 4]):
+                try:
+                    e, blob, _ = ep.plan(lib, shapes, ncu, split)
+                except RuntimeError:
+                    assert split is not None            # a forced split may be impossible (more chunks than groups, > 64 groups per chunk)
+                    continue
+                n = len(shapes)
+                ph = blob[: n * 128].reshape(n, 128)
+                work = blob[n * 128:].view(ep.WORK)
+                i4 = lambda i, off: int(ph[i, off:off + 4].view("<i4")[0])
+                i8 = lambda i, off: int(ph[i, off:off + 8].view("<i8")[0])
+                spans = []
+                for i, (K, sizes) in enumerate(shapes):
+                    G, T, S = K // 128, sum(sizes) // 16, i4(i, 88)
+                    assert (i4(i, 72), i4(i, 76), i4(i, 80), i4(i, 84)) == (K, sum(sizes), G, len(sizes)) and 1 <= S <= 4
+                    if split:
+                        assert S == split[i % len(split)]
+                    assert i4(i, 92) == (i4(i - 1, 88) if i else 1) and i8(i, 64) == (i8(i - 1, 56) if i else 0)
+                    if i + 1 < n:
+                        assert i4(i, 28) == i4(i + 1, 104)                  # work_off_next
+                    cover = np.zeros((G, T), dtype=np.int32)
+                    tstart = np.concatenate([[0], np.cumsum(np.asarray(sizes) // 16)])
+                    for c in range(ncu):
+                        w = work[i4(i, 104) + c]
+                        if w["ng"] == 0:
+                            assert w["ntile"] == 0 and w["nt"] == 0
+                            continue
+                        cover[w["g0"]:w["g0"] + w["ng"], w["t0"]:w["t0"] + w["nt"]] += 1
+                        assert tstart[w["p"]] <= w["t0"] and w["t0"] + w["nt"] <= tstart[w["p"] + 1]
+                        assert 1 <= w["nt"] <= 16 and 1 <= w["ng"] <= 64 and w["ntile"] == int(w["nt"]) * int(w["ng"]) and 0 <= w["s"] < S
+                        assert all((j * int(w["inv_nt"])) >> 16 == j // int(w["nt"]) for j in range(int(w["ntile"])))
+                        assert w["tz0"] == sum((m // 16 + 7) // 8 * 8 for m in sizes[:w["p"]]) + (w["t0"] - tstart[w["p"]])
+                    assert (cover == 1).all(), (ncu, i, K, sizes)
+                    spans.append((i8(i, 56), i8(i, 56) + S * sum(sizes)))
+                spans.sort()
+                assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:])) and 256 + spans[-1][1] * 8 == e.workspace_bytes
+                assert e.last_split == i4(n - 1, 88) and e.last_out_offset == i8(n - 1, 56)

@@ -1,19 +1,16 @@
 #!/usr/bin/env python3
 """Per-edge timeline of the loader / consumer engine (paro_engine2_trace, csrc/engine2.hip): where a phase's time goes.
 
-    python tools/engine2_timeline.py [--model qwen3-4b] [--layers 4] [--reps 5] [--split 0,0,0,0]
+    python tools/engine2_timeline.py [--model qwen3-4b] [--layers 4] [--reps 5] [--split 0,0,0,0] [--dump qkv_proj]
 
-For every phase kind of the model's decoder layer (qkv, o, gate_up, down) prints, in microseconds after the LAST compute unit has
-published the previous phase's outputs (the edge's time zero), the median / latest over the compute units of consumer wave 0's stamps:
-  enter   the wave is in the phase (its previous publish is behind it)
-  got     all partial sums of its first batch of groups have arrived            (the hop: store flight + poll)
-  rot     its groups are rotated and flagged in LDS                             (eight Givens stages)
-  tile0   its first tile is accumulated                                         (waits for the loader's slot and the other waves' groups)
-  tiles   its share of every slot is accumulated
-  bar     every consumer of the CU has accumulated
-  pub     the CU's outputs are published = the next edge's time zero            (phase duration = pub_max)
-and of the loader: ld0 = first slot of the phase issued, ld1 = last slot issued (negative = ahead of the edge);
-durations: w_poll = wave 0 in the hand-off poll, w_stream = wave 0 waiting for the loader's slots, w_ring = the loader waiting for a free slot.
+The trace holds, per (phase, compute unit, wave), eight stamps of the 100 MHz counter.  Consumer waves (rows 1..):
+  enter   the wave is in the phase                         poll    it starts to poll the hand-off (its own CU has published the previous phase)
+  got     the partial sums of its first groups are there    rot     ... rotated and in LDS as A fragments
+  tiles   its tiles are accumulated                          red / pub / ack   (the wave that arrived last) starts to add the waves' rows /
+                                                                               has issued the granule stores / the stores have left the CU
+and the loader (row 0): ld0 / ld1 first / last slot of the phase issued, ring = ticks waiting for a free slot, gate = ticks yielding to hand-offs.
+Per phase kind, in microseconds after the LAST compute unit has issued the previous phase's stores (the edge's time zero): the median
+over the compute units of each event of the FIRST and of the LAST wave to reach it, and the latest compute unit.
 The last line is the production kernel's whole-chain time per phase from a graph replay."""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +20,7 @@ import torch
 import bench
 from paroquant_amd.engine import DecodeEngine
 
-EV = {"enter": 0, "got": 1, "rot": 2, "tile0": 3, "tiles": 4, "bar": 5, "pub": 6, "ld0": 8, "ld1": 9}
-DUR = {"w_stream": 7, "w_ring": 10, "w_poll": 11}      # ticks spent waiting: consumer wave 0 for the loader's slots, the loader for a free slot, wave 0 in the hand-off poll
+EV = ["enter", "poll", "got", "rot", "tiles", "red", "pub", "ack"]
 
 
 def main():
@@ -34,6 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--split", default="", help="K-chunks per phase kind, e.g. 3,3,4,3 (0 = the planner's)")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--dump", default="", help="phase kind: print the slowest compute units of that phase, wave by wave")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     stack = bench.DecodeStack(args.model, dev, n_layers=args.layers, route="fused")
@@ -50,30 +47,51 @@ def main():
     if not eng.status_ok():
         print(json.dumps({"model": args.model, "error": "a hand-off gave up"}), flush=True)
     acc = {}
+    tr = None
     for rep in range(args.reps):
-        tr = eng.trace(stack.x).cpu().numpy().astype(np.int64)        # [phases, cus, 16], 10 ns ticks
+        tr = eng.trace(stack.x).cpu().numpy().astype(np.int64)        # [phases, cus, 64] = [phases, cus, 8 waves, 8 events], 10 ns ticks
+        tr = tr.reshape(tr.shape[0], tr.shape[1], 8, 8)
         n_ph = tr.shape[0]
         for p in range(1, n_ph):
-            t0 = tr[p - 1, :, 6].max()
+            t0 = tr[p - 1, :, 1:, 6].max()
             kind = names[p % len(names)]
-            busy = tr[p, :, 6] > 0                                      # CUs with work in this phase stamp
+            cons = tr[p, :, 1:, :].astype(np.float64)                  # [cus, waves, events]
+            cons[cons == 0] = np.nan
+            busy = np.isfinite(cons[:, :, 6]).any(axis=1)
             row = {}
-            for name, ix in EV.items():
-                v = tr[p, busy, ix]
-                v = v[v > 0]
-                if v.size:
-                    row[name + "_med"] = float(np.median(v) - t0)
-                    row[name + "_max"] = float(v.max() - t0)
-            for name, ix in DUR.items():
-                v = tr[p, busy, ix]
-                row[name + "_med"] = float(np.median(v))
-                row[name + "_max"] = float(v.max())
+            with np.errstate(all="ignore"):
+                for e, name in enumerate(EV):
+                    v = cons[busy][:, :, e] - t0
+                    if not np.isfinite(v).any():
+                        continue
+                    first, last = np.nanmin(v, axis=1), np.nanmax(v, axis=1)
+                    row[name + "_first_med"] = float(np.nanmedian(first))
+                    row[name + "_last_med"] = float(np.nanmedian(last))
+                    row[name + "_last_max"] = float(np.nanmax(last))
+            ld = tr[p, busy, 0, :].astype(np.float64)
+            row["ld0_med"] = float(np.median(ld[:, 0]) - t0)
+            row["ld1_med"] = float(np.median(ld[:, 1]) - t0)
+            row["ring_med"] = float(np.median(ld[:, 2]))
+            row["gate_med"] = float(np.median(ld[:, 3]))
             for k, v in row.items():
                 acc.setdefault(kind, {}).setdefault(k, []).append(v * 0.01)      # -> microseconds
+    if args.dump:
+        k = names.index(args.dump)
+        p = k + len(names) * (args.layers - 1)                # the last layer's phase of that kind
+        t0 = tr[p - 1, :, 1:, 6].max()
+        pubs = tr[p, :, 1:, 6].max(axis=1)
+        order = np.argsort(-pubs)[:6]
+        for c in list(order) + [int(np.argsort(pubs)[len(pubs) // 2])]:
+            print(json.dumps({"cu": int(c), "pub": round(float(pubs[c] - t0) * 0.01, 2)}), flush=True)
+            for w in range(1, 8):
+                st = tr[p, c, w, :]
+                if st[0] == 0:
+                    continue
+                print("   wave", w, " ".join(f"{n}={(st[e] - t0) * 0.01:6.2f}" if st[e] else f"{n}=   -  " for e, n in enumerate(EV)), flush=True)
     desc = eng.describe()
     for i, kind in enumerate(names):
         if kind in acc:
-            print(json.dumps({"model": args.model, "tag": args.tag, "phase": kind, "split": desc[i][0], "tiles_max": desc[i][1], "tiles_min": desc[i][2],
+            print(json.dumps({"model": args.model, "tag": args.tag, "phase": kind, "split": desc[i][0], "ntile_max": desc[i][1], "ntile_min": desc[i][2],
                               **{k: round(float(np.median(v)), 2) for k, v in acc[kind].items()}}), flush=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     g = torch.cuda.CUDAGraph()
