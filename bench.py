@@ -1137,6 +1137,22 @@ def run(args, rank: int, local_rank: int, world: int):
                 ex["configs"] = config_steps(dev)
             except Exception as e:
                 ex["configs"] = {"error": f"{type(e).__name__}: {e}"}
+            try:       # the launch shapes of the headline workload's layers, MEASURED (paroquant_amd/autotune.py), plus three shapes no sweep saw
+                from paroquant_amd import autotune as _at
+                rows_at = []
+                gen_at = torch.Generator(device=dev).manual_seed(99)
+                seen_at = [(n, K, list(sz)) for n, K, sz, _ in layer_plan(model, 1, 1)[0]] + [("unseen 3584->18944", 3584, [18944]),
+                                                                                              ("unseen 5120->27648", 5120, [27648]), ("unseen 6144->4096", 6144, [4096])]
+                for name_at, K_at, sz_at in seen_at:
+                    rep = synth_packed(K_at, sz_at, dev, gen_at).autotune(force=True)
+                    cand = sorted(rep["candidates"].items(), key=lambda kv: kv[1])
+                    rows_at.append({"linear": name_at, "K": K_at, "N": sum(sz_at), "rule_tree": rep["default"], "rule_tree_us": rep["default_us"], "choice": rep["choice"],
+                                    "choice_us": rep["choice_us"], "candidates": len(cand), "best_three": cand[:3]})
+                ex["autotune"] = {"rows": rows_at, "note": "per layer shape: every legal (tiles_per_wave, ksplit, waves) timed at load time over rotating weight copies "
+                                                          "(60 graph-replayed launches each); the rule tree's shape is kept unless one is >= 2 % faster; PARO_AUTOTUNE=1 "
+                                                          "runs this inside process_weights_after_loading / RotateQuantizedLinear.prepare"}
+            except Exception as e:
+                ex["autotune"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(model, args.cpu_budget)
             try:       # SURVEY 8d's per-shape table (B1 torch-CPU, B2 C port); context, never fatal for the contract line

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 15
+#define PARO_ABI_VERSION 16
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -156,8 +156,14 @@ typedef struct paro_linear {
                                          [n_parts][K/128][128 n][128 k] = (diag(cs) G_1..G_krot)^T, used by
                                          the prefill pre-pass on the matrix cores; NULL = stage kernel */
   int32_t group_size;                 /* quantisation group: 128 (0 is read as 128) or 64 channels per (scale, zero) */
-  int32_t reserved0;
+  int32_t launch_hint;                /* v16: 0 = the built-in launch-shape rules; else the shape MEASURED for this layer at load time
+                                         (PARO_LAUNCH_HINT(tiles_per_wave, ksplit, waves)): used by ONE-ROW launches whose knobs are
+                                         all auto -- paro_w4a16_linear, paro_w4a16_gemv(.., 0, 0, 0, ..), the fused entry -- and never
+                                         for the deferred K-split route (that one fixes its own split).  An illegal hint is clamped
+                                         like explicit knobs are.  The reference has no counterpart: its INT4 GEMM is a third-party
+                                         kernel (AutoAWQ / Marlin) with its own shape selection behind plugin.py:251-311. */
 } paro_linear_t;
+#define PARO_LAUNCH_HINT(tiles_per_wave, ksplit, waves) (((tiles_per_wave) & 0xff) | (((ksplit) & 0xff) << 8) | (((waves) & 0xff) << 16))
 
 /* Bytes of caller-provided scratch the fused ops may need for `rows` rows
  * (split-K granules for the GEMV paths, rotated activations for the GEMM path).  The first PARO_WS_COUNTER_BYTES of the

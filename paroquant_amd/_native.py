@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 15
+PARO_ABI_VERSION = 16
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -105,7 +105,7 @@ class ParoLinearDesc(Structure):
         ("bias", c_void_p),
         ("rmat", c_void_p),
         ("group_size", c_int32),
-        ("reserved0", c_int32),
+        ("launch_hint", c_int32),
     ]
 
 

@@ -180,6 +180,16 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
 namespace paro {
 // The launch shape a GEMV call ends up with: caller's knobs (0 = auto, mode -1 = auto) -> final values.
 int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ksp, int& wv, int& mode, bool deferred = false) {
+  // a shape measured for this layer at load time (paro_linear_t.launch_hint, PackedParoWeights.autotune): one-row launches whose
+  // knobs are all auto take it instead of the rules below; everything after this point treats it like explicit knobs
+  if (rows == 1 && !deferred && tpw == 0 && ksp == 0 && wv == 0 && L->launch_hint != 0) {
+    tpw = L->launch_hint & 0xff;
+    ksp = (L->launch_hint >> 8) & 0xff;
+    wv = (L->launch_hint >> 16) & 0xff;
+    if (tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8) tpw = 0;
+    if (ksp > kMaxKsplit) ksp = 0;
+    if (wv != 4 && wv != 8 && wv != 16) wv = 0;
+  }
   const int waves_in = wv;
   if (tpw != 0 && tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8)
     return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave must be 0 (auto), 1, 2, 4 or 8 (got %d)", tpw);

@@ -167,6 +167,13 @@ class PackedParoWeights:
                                            stream)
         return self
 
+    def autotune(self, dtype: torch.dtype = torch.float16, **kw) -> dict:
+        """Measure the batch-1 GEMV's launch shapes for this layer once (paroquant_amd/autotune.py; cached per distinct shape) and keep
+        the fastest as ``launch_hint`` -- the one-time counterpart of the reference's ``process_weights_after_loading`` repack
+        (vllm/plugin.py:251-279).  Allocates and launches: call it at load time, never inside a captured graph."""
+        from .autotune import autotune_packed
+        return autotune_packed(self, dtype, **kw)
+
     def apply(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self.bias if bias is None else bias
         if b is not None and b.dtype != x.dtype:
@@ -175,7 +182,7 @@ class PackedParoWeights:
         rmat = self.rotation_matrices(x.dtype) if rows >= 256 else None
         return torch.ops.paro.w4a16_linear(x, self.wq, self.sz, self.rot, self.pairs, self.theta,
                                            self.channel_scales, b, self.partition_sizes, self.workspace,
-                                           self.wq_order, rmat)
+                                           self.wq_order, rmat, getattr(self, "launch_hint", 0))
 
     def fold_norm_weight(self, weight: torch.Tensor, plus_one: bool = False) -> "PackedParoWeights":
         """Fold the weight of the RMSNorm that feeds this linear into the channel scales
@@ -251,6 +258,9 @@ class RotateQuantizedLinear(nn.Module):
                                          self.group_size, self.w_bit)
         if prefill:
             self._packed.prepare_prefill()
+        from . import autotune
+        if autotune.enabled():
+            self._packed.autotune()
         return self
 
     def release_checkpoint_buffers(self) -> "RotateQuantizedLinear":

@@ -152,7 +152,7 @@ def _pack_rotation_fake(pairs, theta):
 
 
 def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torch.dtype, wq, sz, rot, pairs,
-              theta, channel_scales, bias, wq_order: int = 0, rmat=None, group_size: int = 0) -> nat.ParoLinearDesc:
+              theta, channel_scales, bias, wq_order: int = 0, rmat=None, group_size: int = 0, launch_hint: int = 0) -> nat.ParoLinearDesc:
     """``group_size`` 0: read it off the packed scale/zero tensor (rows = K / group_size); stacked expert tensors
     (moe.py) pass it explicitly."""
     d = nat.ParoLinearDesc()
@@ -163,6 +163,7 @@ def make_desc(K: int, partition_sizes: Sequence[int], krot: int, act_dtype: torc
     if group_size not in (64, 128):
         raise ValueError(f"Unsupported group_size: {group_size}; expected 64 or 128")
     d.group_size = int(group_size)
+    d.launch_hint = int(launch_hint)
     d.K = K
     d.N = int(sum(partition_sizes))
     d.n_parts = len(partition_sizes)
@@ -206,7 +207,7 @@ def _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes):
 def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.Tensor, pairs: torch.Tensor,
                 theta: torch.Tensor, channel_scales: torch.Tensor, bias: Optional[torch.Tensor],
                 partition_sizes: Sequence[int], workspace: torch.Tensor, wq_order: int = 0,
-                rmat: Optional[torch.Tensor] = None) -> torch.Tensor:
+                rmat: Optional[torch.Tensor] = None, launch_hint: int = 0) -> torch.Tensor:
     lib = nat.load()
     partition_sizes = [int(s) for s in partition_sizes]
     _check_linear_args(x, pairs, theta, channel_scales, bias, partition_sizes)
@@ -218,7 +219,7 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
     if rows == 0:
         return y.reshape(*x.shape[:-1], N)
     d = make_desc(K, partition_sizes, int(pairs.size(1)), x.dtype, wq, sz, rot, pairs, theta, channel_scales, bias,
-                  wq_order, rmat)
+                  wq_order, rmat, launch_hint=launch_hint)
     # Scratch: K-split granules / rotated activations / fp32 partial tiles.  NEVER uninitialised memory: the
     # granule protocol of the split-K GEMV reads {tag, partial} words and needs the slabs to start at zero, so a
     # workspace that is too small is replaced by the cached zero-filled one (grown with torch.zeros).
@@ -233,7 +234,7 @@ def _w4a16_impl(x: torch.Tensor, wq: torch.Tensor, sz: torch.Tensor, rot: torch.
 
 
 def _w4a16_fake(x, wq, sz, rot, pairs, theta, channel_scales, bias, partition_sizes, workspace, wq_order=0,
-                rmat=None):
+                rmat=None, launch_hint=0):
     return x.new_empty((*x.shape[:-1], int(sum(partition_sizes))))
 
 
@@ -431,7 +432,7 @@ def parts_finish(parts: torch.Tensor, x: Optional[torch.Tensor] = None, out: Opt
 def pk_desc(pk, act_dtype: torch.dtype, bias=None, rmat=None) -> nat.ParoLinearDesc:
     """``paro_linear_t`` of a :class:`paroquant_amd.linear.PackedParoWeights`."""
     return make_desc(pk.K, pk.partition_sizes, int(pk.pairs.size(1)), act_dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                     pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order, rmat)
+                     pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order, rmat, launch_hint=int(getattr(pk, "launch_hint", 0)))
 
 
 def rotate_parts(x: torch.Tensor, pk, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -699,7 +700,7 @@ def _register() -> None:
     torch.library.register_fake("paro::pack_rotation", _pack_rotation_fake, lib=par)
     par.define("w4a16_linear(Tensor x, Tensor wq, Tensor sz, Tensor rot, Tensor pairs, Tensor theta, "
                "Tensor channel_scales, Tensor? bias, int[] partition_sizes, Tensor workspace, int wq_order=0, "
-               "Tensor? rmat=None) -> Tensor")
+               "Tensor? rmat=None, int launch_hint=0) -> Tensor")
     par.impl("w4a16_linear", _w4a16_impl, "CUDA")
     torch.library.register_fake("paro::w4a16_linear", _w4a16_fake, lib=par)
     _libs.append(par)

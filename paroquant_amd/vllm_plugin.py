@@ -283,6 +283,9 @@ class ParoQuantLinearMethod(LinearMethodBase):
         theta, pairs, cs, kernel_sizes, _ = coalesce_partitions(layer.theta.data, layer.pairs.data, layer.channel_scales.data, padded)
         layer.paro_packed = PackedParoWeights(qw.contiguous(), qz.contiguous(), sc.contiguous(), theta, pairs, cs, kernel_sizes, None,
                                               self.quant_config.group_size, self.quant_config.bits)
+        from . import autotune
+        if autotune.enabled():                  # PARO_AUTOTUNE=1: measured launch shapes, once per distinct layer shape (autotune.py)
+            layer.paro_packed.autotune(torch.bfloat16 if layer.scales.dtype == torch.bfloat16 else torch.float16)
         layer.kernel_partition_sizes = kernel_sizes
         layer.padded_partition_sizes = padded
         layer.rot_theta = layer.paro_packed.theta

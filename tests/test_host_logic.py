@@ -722,3 +722,38 @@ def test_engine2_planner_covers_every_tile_once(lib):
                 spans.sort()
                 assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:])) and 256 + spans[-1][1] * 8 == e.workspace_bytes
                 assert e.last_split == i4(n - 1, 88) and e.last_out_offset == i8(n - 1, 56)
+
+
+def test_autotune_candidates_and_hint_resolution(lib):
+    """paroquant_amd/autotune.py on the host: the candidate list of a layer is made of shapes the library resolves to themselves and holds
+    the rule tree's own; a `launch_hint` (ABI v16) is what one-row auto-knob calls resolve to, explicit knobs and other row counts ignore it,
+    an illegal hint falls back to the rules."""
+    import ctypes
+    from paroquant_amd import _native as nat, autotune
+
+    def desc(K, sizes):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.group_size = K, sum(sizes), len(sizes), 8, 1, 128
+        for i, n in enumerate(sizes):
+            d.part_cols[i] = n
+        d.wq_order = 1 if d.N // 16 >= 1024 else 0
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)
+        return d
+
+    def resolve(d, rows, t=0, k=0, w=0):
+        a, b, c, m = ctypes.c_int(t), ctypes.c_int(k), ctypes.c_int(w), ctypes.c_int(-1)
+        assert lib.paro_gemv_launch_shape(ctypes.byref(d), rows, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(m)) == 0
+        return (a.value, b.value, c.value)
+
+    for K, sizes in [(4096, [4096]), (2560, [4096, 1024, 1024]), (3584, [18944]), (9728, [2560]), (6144, [4096])]:
+        d = desc(K, sizes)
+        rule = resolve(d, 1)
+        other = next(s for s in [(2, 2, 8), (4, 1, 8), (1, 4, 4)] if resolve(d, 1, *s) == s and s != rule)
+        d.launch_hint = autotune.launch_hint(*other)
+        assert resolve(d, 1) == other                                   # one row, auto knobs: the hint
+        assert resolve(d, 1, *rule) == rule                             # explicit knobs win
+        assert resolve(d, 8) == resolve(desc(K, sizes), 8)              # other row counts: the rules
+        d.launch_hint = autotune.launch_hint(3, 0, 5)                   # illegal tiles / waves: the rules
+        assert resolve(d, 1) == rule
+    assert autotune.launch_hint(4, 3, 8) == 4 | (3 << 8) | (8 << 16)
