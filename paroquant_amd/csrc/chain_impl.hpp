@@ -125,18 +125,6 @@ struct GivensRegs {
     sb[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl[t], __builtin_bit_cast(int, give)));
     sa[0] = keep;
   }
-  // one stage of row 0 straight from the packed words (no prepare(): 24 registers fewer per group; the converts ride in the shadow of
-  // the previous stage's cross-lane exchange when several groups' chains are interleaved: engine2.hip)
-  __device__ __forceinline__ void stage_direct(int t) {
-    const unsigned w = rc[t >> 2][t & 3];
-    const unsigned sw = rc[2][t >> 2];
-    const float P = (float)(int)(short)(w & 0xffffu), Q = (float)((int)w >> 16);
-    const int src = (int)((sw >> (8 * (t & 3))) & 0xffu);
-    const float keep = __builtin_fmaf(P, sa[0], Q * sb[0]);
-    const float give = __builtin_fmaf(P, sb[0], -(Q * sa[0]));
-    sb[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, give)));
-    sa[0] = keep;
-  }
   // last checkpoint stage of row 0 into registers: the two rounded activations and their byte offsets inside the group's 128 halves
   __device__ __forceinline__ void finish_vals(unsigned short& h1, unsigned short& h2, unsigned& oa, unsigned& ob) {
     const unsigned w0 = rc[2][2], w1 = rc[2][3];

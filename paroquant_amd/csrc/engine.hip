@@ -808,8 +808,16 @@ static int engine_launch(const paro_engine_t* e, const void* plan_dev, const voi
   for (int i = 0; i < kEngMaxShapes; ++i) a.shape_off[i] = e->shape_off[i];
   // every workgroup of the grid must be resident at once (they wait for each other): one 16-wave workgroup per CU
   {
-    static int per_cu[3] = {-1, -1, -1};
-    int& per = per_cu[e->act_dtype];
+    // (per DEVICE: another GPU of the process may differ; the worst a racing first call does is ask twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PARO_ERR_LAUNCH, "engine: no current device");
+    static int per_cu[64][3];
+    static bool known[64][3];
+    if (!known[dev][e->act_dtype]) {
+      per_cu[dev][e->act_dtype] = -1;
+      known[dev][e->act_dtype] = true;
+    }
+    int& per = per_cu[dev][e->act_dtype];
     if (per < 0) {
       int v = 0;
       hipError_t er = e->act_dtype == PARO_DTYPE_F16

@@ -195,6 +195,20 @@ __device__ __forceinline__ void e2_wait_vm(int pend) {
   }
 }
 
+// one Givens stage of row 0 straight from the packed words (no GivensRegs::prepare(): 24 registers fewer per group; the converts ride
+// in the shadow of the previous stage's cross-lane exchange when several groups' chains are interleaved)
+template <typename GR>
+__device__ __forceinline__ void e2_stage_direct(GR& g, int t) {
+  const unsigned w = g.rc[t >> 2][t & 3];
+  const unsigned sw = g.rc[2][t >> 2];
+  const float P = (float)(int)(short)(w & 0xffffu), Q = (float)((int)w >> 16);
+  const int src = (int)((sw >> (8 * (t & 3))) & 0xffu);
+  const float keep = __builtin_fmaf(P, g.sa[0], Q * g.sb[0]);
+  const float give = __builtin_fmaf(P, g.sb[0], -(Q * g.sa[0]));
+  g.sb[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, give)));
+  g.sa[0] = keep;
+}
+
 template <typename AT, bool TRACE = false>
 __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) {
   typedef Act<AT> A;
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(kE2Waves * 64) void engine2_kernel(const E2Args a) 
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gr[b].stage_direct(t);
+        for (int b = 0; b < NB; ++b) e2_stage_direct(gr[b], t);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         unsigned short h1, h2;

@@ -359,7 +359,7 @@ class ParoQwen35DecoderLM:
         with torch.cuda.device(dev):
             for L in self.layers:
                 r0 = rs(h)
-                y = (L.mix_in.apply(h).float() * r0).to(dt)                            # the norm's weight is folded into the channel scales
+                y = L.mix_in.apply((h.float() * r0).to(dt))                            # normalised FIRST (an un-normalised fp16 projection of a residual-stream outlier can overflow before the scalar shrinks it); the norm's weight is folded into the channel scales
                 if L.full:
                     qg = y[:, : 2 * nh * HD].view(T, nh, 2, HD)
                     q, gate = qg[:, :, 0].float(), qg[:, :, 1].float()
@@ -398,7 +398,7 @@ class ParoQwen35DecoderLM:
                     wn = (L.gdn_norm.float() * n).to(dt).float()
                     mix = (wn * (z * torch.sigmoid(z))).to(dt).reshape(T, vd)
                 h = h + L.mix_out.apply(mix.contiguous())
-                gu = (L.gate_up.apply(h).float() * rs(h)).to(dt)
+                gu = L.gate_up.apply((h.float() * rs(h)).to(dt))
                 act = (torch.nn.functional.silu(gu[:, : c.inter].float()) * gu[:, c.inter:].float()).to(dt)
                 h = h + L.down.apply(act.contiguous())
             x = h[-1:].float()

@@ -165,7 +165,11 @@ class ParoHfExperts(nn.Module):
             self.register_buffer(f"{name}_channel_scales", torch.ones(1, K, dtype=torch.float16))
         self._packed = None
 
-    def prepare(self, release: bool = True) -> "ParoHfExperts":
+    def prepare(self, release: Optional[bool] = None) -> "ParoHfExperts":
+        """``release``: drop the AWQ-format per-expert buffers once the kernel-layout copy exists; None = what the quantization config's
+        ``free_checkpoint_buffers`` said when the module was built (the lazy path of ``forward`` honours it too)."""
+        if release is None:
+            release = bool(getattr(self, "free_checkpoint_buffers", False))
         from .moe import ParoMoEExperts
         dev = self.gate_up_weight_theta.device
         if dev.type != "cuda":
@@ -208,7 +212,9 @@ def replace_experts(model: nn.Module, blocks: dict, qcfg) -> int:
         if H is None or I is None:
             log.warning("ParoQuant: cannot read the geometry of %s (%s); its experts stay unconverted.", path, type(old).__name__)
             continue
-        setattr(owner, leaf, ParoHfExperts(n_experts, int(H), int(I), qcfg.group_size, qcfg.krot))
+        mod = ParoHfExperts(n_experts, int(H), int(I), qcfg.group_size, qcfg.krot)
+        mod.free_checkpoint_buffers = bool(getattr(qcfg, "free_checkpoint_buffers", False))   # (the lazy prepare() of forward honours it)
+        setattr(owner, leaf, mod)
         replaced += 1
     return replaced
 
