@@ -535,12 +535,17 @@ int paro_engine_trace(const paro_engine_t* e, const void* plan_dev, const void* 
                       int64_t workspace_bytes, void* trace, void* stream);
 
 /* v15: the engine's second build (csrc/engine2.hip) -- the same five entry points, the same descriptors, another geometry: per CU one LOADER
- * wave streams the INT4 tiles HBM -> LDS by LDS-DMA into a ring of 7 x 16 tiles and runs ahead across the linears; three CONSUMER waves
- * complete the previous linear's K-chunk partial sums for the CU's OWN groups (one hop per edge), rotate them in registers and multiply out of
- * LDS.  paro_engine_phase_t.flags & 0xf: 0 = the planner's K-split, 1..4 = that many K-chunks (tuning, tests).  trace: uint64
- * [n_phases][n_cus][16] stamps of the 100 MHz counter -- consumer wave 0: 0 phase entered, 1 its first partial sums arrived, 2 its groups
- * rotated and staged, 3 first tile multiplied, 4 its tiles done, 5 every wave's tiles done, 6 outputs published; loader: 8 first slot of the
- * phase issued, 9 last slot issued.  Replaces rotate -> GEMM per linear of transformers/modules.py:57-71 / vllm/plugin.py:281-311 for a caller
+ * wave streams the INT4 tiles HBM -> LDS by LDS-DMA into a ring of 7 x 16 tiles and runs ahead across the linears; seven CONSUMER waves
+ * (a build parameter) each own every 7th group of the CU's K-chunk: they complete the previous linear's K-chunk partial sums for those
+ * groups (one hop per edge), rotate them in registers and multiply their tiles out of LDS.  Parity-tested; measured SLOWER than the engine
+ * above and than the per-call launches (profiles/NOTES.md 5.1): kept for whoever continues the design.
+ * paro_engine_phase_t.flags & 0xf: 0 = the planner's K-split, 1..4 = that many K-chunks (tuning, tests).  trace: uint64
+ * [n_phases][n_cus][8 waves][8 events] stamps of the 100 MHz counter -- consumer waves (rows 1..): 0 phase entered, 1 hand-off loads
+ * issued, 2 its first groups' partial sums there, 3 rotated and in LDS, 4 its tiles accumulated, 5 every wave of the CU has arrived, 6 its
+ * share of the outputs published; the loader (row 0): 0 first slot of the phase issued, 1 last slot issued, 2 ticks waiting for a free
+ * slot, 3 ticks yielding to hand-offs.  Environment (experiments, read per call): PARO_E2_THIN = 0 / 1 / 2 (how the loader yields while
+ * a wave of its CU polls: not / one 4 KiB burst in flight / stands still; default 0), PARO_E2_COST, PARO_E2_COST_GATHER
+ * (the planner's constants).  Replaces rotate -> GEMM per linear of transformers/modules.py:57-71 / vllm/plugin.py:281-311 for a caller
  * that owns the chain. */
 int paro_engine2_plan(const paro_engine_phase_t* phases, int n_phases, int n_cus, paro_engine_t* out);
 int paro_engine2_build(const paro_engine_phase_t* phases, const paro_engine_t* e, void* plan_host);

@@ -1145,7 +1145,7 @@ static int e2_launch(const paro_engine_t* e, const void* plan_dev, const void* x
   a.S_last = e->last_split;
   a.trace = trace;
   a.work_off0 = 0;                               // (phase 0's shape is the first one planned)
-  a.flags = (e2_env_int("PARO_E2_THIN", 0) & 3) | (e2_env_int("PARO_E2_SLOWPOLL", 0) ? 8 : 0);
+  a.flags = (e2_env_int("PARO_E2_THIN", 0) & 3);
   // every workgroup of the grid must be resident at once (they wait for each other): one workgroup per CU -- checked per DEVICE
   {
     int dev = 0;
