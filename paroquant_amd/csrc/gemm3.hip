@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = blockIdx.x;
+  const int cb = blockIdx.x + a.cb0;
   const int row0 = blockIdx.y * BMR;
 
   const u32x4* wq_base = a.wq;

@@ -20,6 +20,7 @@ struct GemmArgs {
   const int* block_expert = nullptr;
   long long wq_estride = 0, sz_estride = 0;   // u32x4 / u32 elements between consecutive experts' packed buffers
   int n_experts = 0;                          // block_expert entries outside [0, n_experts) are skipped on the device
+  int cb0 = 0;                                // variant 4: first column block of this launch (per-partition launches of a merged projection)
 };
 
 }  // namespace paro

@@ -1632,3 +1632,46 @@ def test_oneshot_allreduce_absent_peer_gives_up_once(dev):
         torch.cuda.synchronize(dev)
         for b in bufs:
             lib.paro_allreduce_buffer_destroy(b)
+
+
+def test_prefill_per_partition_overlap_in_a_graph(dev):
+    """The per-partition prefill path of merged projections (csrc/gemm.hip: rotate partition p + 1 on a side stream while the GEMM of
+    partition p runs) forks and joins inside ONE call: the same bits eagerly, from a captured HIP graph, and as the
+    single pre-pass + single GEMM launch it replaces (same kernels, same per-partition arithmetic); reference semantics: per-partition
+    rotate then GEMM, vllm/plugin.py:288-306."""
+    import os
+    K, sizes, rows = 2048, [2048, 512, 512], 4096
+    L = _random_gpu_layer(dev, K, sizes, seed=77)
+    pk = _pack_gpu_layer(L).prepare_prefill(torch.float16)
+    x = torch.randn(rows, K, device=dev, dtype=torch.float16)
+    sample = torch.arange(0, rows, rows // 32, device=dev)
+    ideal = _oracle_rows(L, x[sample])
+    y_single = pk.apply(x).clone()                    # the shipping path: one pre-pass launch, one GEMM launch
+    os.environ["PARO_PREFILL_OVERLAP"] = "1"          # (the library reads it per call)
+    try:
+        _overlap_checks(dev, pk, x, sample, ideal, y_single)
+    finally:
+        del os.environ["PARO_PREFILL_OVERLAP"]
+
+
+def _overlap_checks(dev, pk, x, sample, ideal, y_single):
+    y_eager = pk.apply(x).clone()
+    assert torch.equal(y_eager, y_single)
+    assert po.rel_err(_np(y_eager[sample]), ideal) < TIGHT_F16
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        pk.apply(x)
+    torch.cuda.current_stream(dev).wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_g = pk.apply(x)
+    for _ in range(3):
+        y_g.zero_()
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(y_g, y_eager)
+    # three calls back to back on one stream (the events are reused), then the result of the last
+    for _ in range(3):
+        y2 = pk.apply(x)
+    assert torch.equal(y2, y_eager)
