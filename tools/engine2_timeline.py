@@ -82,7 +82,10 @@ def main():
         pubs = tr[p, :, 1:, 6].max(axis=1)
         order = np.argsort(-pubs)[:6]
         for c in list(order) + [int(np.argsort(pubs)[len(pubs) // 2])]:
-            print(json.dumps({"cu": int(c), "pub": round(float(pubs[c] - t0) * 0.01, 2)}), flush=True)
+            ldr = tr[p, c, 0, :]
+            print(json.dumps({"cu": int(c), "pub": round(float(pubs[c] - t0) * 0.01, 2), "loader": {"ld0": round(float(ldr[0] - t0) * 0.01, 2), "ld1": round(float(ldr[1] - t0) * 0.01, 2),
+                                                                                                   "ring_wait": round(float(ldr[2]) * 0.01, 2), "gate_wait": round(float(ldr[3]) * 0.01, 2)},
+                              "loader_next_phase": {"ld0": round(float(tr[min(p + 1, tr.shape[0] - 1), c, 0, 0] - t0) * 0.01, 2), "ld1": round(float(tr[min(p + 1, tr.shape[0] - 1), c, 0, 1] - t0) * 0.01, 2)}}), flush=True)
             for w in range(1, 8):
                 st = tr[p, c, w, :]
                 if st[0] == 0:
