@@ -69,7 +69,18 @@ def candidates(pk, dtype: torch.dtype = torch.float16) -> Tuple[Tuple[int, int, 
 
 def _key(pk, dtype) -> tuple:
     dev = pk.wq.device
-    return (torch.cuda.get_device_name(dev), pk.K, tuple(pk.partition_sizes), int(getattr(pk, "group_size", 128)), int(pk.wq_order), str(dtype))
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else str(dev)
+    return (name, pk.K, tuple(pk.partition_sizes), int(getattr(pk, "group_size", 128)), int(pk.wq_order), str(dtype))
+
+
+def choose(default: Tuple[int, int, int], shapes: List[Tuple[int, int, int]], times: Dict[Tuple[int, int, int], float],
+           min_gain: float = 0.02, tie: float = 0.01) -> Tuple[int, int, int]:
+    """The selection rule on measured times: the rule tree's shape unless the best candidate is more than ``min_gain`` ahead of it; then
+    the FIRST shape in the fixed candidate order within ``tie`` of the best (two runs agree unless shapes really are within the noise)."""
+    t_best = min(times.values())
+    if times[default] <= t_best * (1.0 + min_gain):
+        return default
+    return next(s for s in shapes if s in times and times[s] <= t_best * (1.0 + tie))
 
 
 @torch.no_grad()
@@ -138,10 +149,7 @@ def autotune_packed(pk, dtype: torch.dtype = torch.float16, min_gain: float = 0.
         times = measure(pk, shapes, dtype, **kw)
         if default not in times:
             raise RuntimeError("autotune: the rule tree's own launch shape failed to run")
-        t_best = min(times.values())
-        choice = default
-        if times[default] > t_best * (1.0 + min_gain):
-            choice = next(s for s in shapes if s in times and times[s] <= t_best * (1.0 + tie))     # fixed order among near-ties
+        choice = choose(default, shapes, times, min_gain, tie)
         rep = {"default": list(default), "default_us": round(times[default], 3), "choice": list(choice), "choice_us": round(times[choice], 3),
                "candidates": {"%d,%d,%d" % s: round(t, 3) for s, t in sorted(times.items())}}
         _CACHE[key] = rep

@@ -757,3 +757,30 @@ def test_autotune_candidates_and_hint_resolution(lib):
         d.launch_hint = autotune.launch_hint(3, 0, 5)                   # illegal tiles / waves: the rules
         assert resolve(d, 1) == rule
     assert autotune.launch_hint(4, 3, 8) == 4 | (3 << 8) | (8 << 16)
+
+
+def test_autotune_selection_rule_and_cache(monkeypatch):
+    """paroquant_amd/autotune.py without a GPU: the selection rule on given timings (the rule tree's shape stays unless a candidate is more
+    than 2 % ahead; near-ties break in the fixed candidate order), the hint it leaves on the layer, and the per-shape cache."""
+    import types
+    from paroquant_amd import autotune
+    shapes = [(1, 1, 8), (2, 1, 8), (4, 2, 8), (4, 4, 4)]
+    default = (4, 2, 8)
+    t = {(1, 1, 8): 6.0, (2, 1, 8): 5.05, (4, 2, 8): 5.1, (4, 4, 4): 5.0}
+    assert autotune.choose(default, shapes, t) == default                                   # 2 % rule: 5.1 <= 5.0 * 1.02
+    t[(4, 2, 8)] = 5.3
+    assert autotune.choose(default, shapes, t) == (2, 1, 8)                                 # 5.05 is within 1 % of the best and comes first
+    t[(2, 1, 8)] = 5.2
+    assert autotune.choose(default, shapes, t) == (4, 4, 4)
+    calls = []
+    monkeypatch.setattr(autotune, "candidates", lambda pk, dtype=None: (default, shapes))
+    monkeypatch.setattr(autotune, "measure", lambda pk, s, dtype=None, **kw: (calls.append(1), dict(t))[1])
+    autotune._CACHE.clear()
+    pk = types.SimpleNamespace(wq=types.SimpleNamespace(device=torch.device("cpu")), K=512, partition_sizes=[256], group_size=128, wq_order=0)
+    rep = autotune.autotune_packed(pk, torch.float16)
+    assert rep["choice"] == [4, 4, 4] and pk.launch_hint == autotune.launch_hint(4, 4, 4) and rep["default_us"] == 5.3
+    twin = types.SimpleNamespace(wq=pk.wq, K=512, partition_sizes=[256], group_size=128, wq_order=0)
+    assert autotune.autotune_packed(twin, torch.float16)["choice"] == [4, 4, 4] and len(calls) == 1      # same shape: from the cache
+    t[(4, 2, 8)] = 5.0
+    assert autotune.autotune_packed(twin, torch.float16, force=True)["choice"] == [4, 2, 8] and twin.launch_hint == 0 and len(calls) == 2
+    autotune._CACHE.clear()
