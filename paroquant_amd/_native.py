@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 16
+PARO_ABI_VERSION = 17
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -66,6 +66,18 @@ EXPORTS = (
     "paro_allreduce_buffer_destroy",
     "paro_allreduce_status",
     "paro_allreduce_oneshot",
+    "paro_gdn_prep",
+    "paro_gdn_step",
+    "paro_gdn_workspace_bytes",
+    "paro_gdn_sequence",
+    "paro_gdn_fused_step",
+    "paro_attn_decode_gated",
+)
+
+
+# include/paro_abi_experimental.h: only in a library built with `make EXPERIMENTAL=1` (the persistent decode engines; measured slower
+# than one launch per linear, profiles/NOTES.md 4.2 / 5.1).  Bound when present, never required.
+EXPERIMENTAL_EXPORTS = (
     "paro_engine_plan",
     "paro_engine_build",
     "paro_engine_describe",
@@ -76,12 +88,6 @@ EXPORTS = (
     "paro_engine2_describe",
     "paro_engine2_run",
     "paro_engine2_trace",
-    "paro_gdn_prep",
-    "paro_gdn_step",
-    "paro_gdn_workspace_bytes",
-    "paro_gdn_sequence",
-    "paro_gdn_fused_step",
-    "paro_attn_decode_gated",
 )
 
 
@@ -265,14 +271,6 @@ def load() -> ctypes.CDLL:
     lib.paro_allreduce_oneshot.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]
     lib.paro_dequant_packed.restype = c_int
     lib.paro_dequant_packed.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p]
-    lib.paro_engine_plan.restype = c_int
-    lib.paro_engine_plan.argtypes = [POINTER(ParoEnginePhase), c_int, c_int, POINTER(ParoEngine)]
-    lib.paro_engine_build.restype = c_int
-    lib.paro_engine_build.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_void_p]
-    lib.paro_engine_describe.restype = c_int
-    lib.paro_engine_describe.argtypes = [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
-    lib.paro_engine_run.restype = c_int
-    lib.paro_engine_run.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     f32 = ctypes.c_float
     lib.paro_gdn_prep.restype = c_int
     lib.paro_gdn_prep.argtypes = [c_void_p, c_void_p, c_void_p, f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -288,17 +286,27 @@ def load() -> ctypes.CDLL:
     lib.paro_attn_decode_gated.restype = c_int
     lib.paro_attn_decode_gated.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, f32, f32, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p]
-    lib.paro_engine_trace.restype = c_int
-    lib.paro_engine_trace.argtypes = [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
-    for fn, ref in (("plan", lib.paro_engine_plan), ("build", lib.paro_engine_build), ("describe", lib.paro_engine_describe),
-                    ("run", lib.paro_engine_run), ("trace", lib.paro_engine_trace)):      # engine2.hip: the same signatures
-        f2 = getattr(lib, "paro_engine2_" + fn)
-        f2.restype, f2.argtypes = c_int, ref.argtypes
+    if all(hasattr(lib, sym) for sym in EXPERIMENTAL_EXPORTS):      # a `make EXPERIMENTAL=1` library (include/paro_abi_experimental.h)
+        sigs = {"plan": [POINTER(ParoEnginePhase), c_int, c_int, POINTER(ParoEngine)],
+                "build": [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_void_p],
+                "describe": [POINTER(ParoEnginePhase), POINTER(ParoEngine), c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)],
+                "run": [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+                "trace": [POINTER(ParoEngine), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]}
+        for prefix in ("paro_engine_", "paro_engine2_"):               # engine2.hip: the same signatures
+            for fn, argtypes in sigs.items():
+                f = getattr(lib, prefix + fn)
+                f.restype, f.argtypes = c_int, argtypes
     if lib.paro_abi_version() != PARO_ABI_VERSION:
         raise RuntimeError(f"paroquant_amd: ABI version mismatch (library {lib.paro_abi_version()}, "
                            f"binding {PARO_ABI_VERSION})")
     _lib = lib
     return lib
+
+
+def has_experimental() -> bool:
+    """True when the loaded library was built with ``make EXPERIMENTAL=1`` (the persistent decode engines)."""
+    lib = load()
+    return all(hasattr(lib, sym) for sym in EXPERIMENTAL_EXPORTS)
 
 
 def check(rc: int) -> None:

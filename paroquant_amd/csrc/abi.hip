@@ -44,39 +44,10 @@ extern "C" const char* paro_last_error(void) { return paro::error_buffer(); }
 // RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply entry point
 // (transformers/modules.py:57-71, vllm/plugin.py:281-311): small batches stream the weights
 // once through the fused GEMV kernel, everything else goes rotate pre-pass + MFMA GEMM.
-// 9..16 rows through the boundary (what a vLLM decode batch reaches): the GEMV family rotates up front from 9 rows on
-// (mode 1: stage kernel, then the GEMV on rotated x).  The alternative second launch -- the chain family's kernel on the same rotated
-// activations -- was measured and is SLOWER behind a separate rotation launch (Qwen3-4B 16 rows 2.62 vs 2.42 ms per step, Llama-3-8B
-// 8 layers 0.656 vs 0.618; 9 and 12 rows alike: profiles/r05_rows_boundary.jsonl): the chain kernel earns its 1.7x-of-one-row only
-// when its producer rotates for it.  The route stays behind PARO_ROWS_CHAIN_MIN (first row count that takes it; default 17 = never).
-static bool rows_chain_route(const paro_linear_t* L, int64_t rows) {
-  static const int first = getenv("PARO_ROWS_CHAIN_MIN") ? atoi(getenv("PARO_ROWS_CHAIN_MIN")) : 17;
-  if (!L || rows < first || rows < 2 || rows > 16) return false;
-  if (L->group_size != 0 && L->group_size != 128) return false;
-  if (L->n_parts < 1 || L->n_parts > PARO_MAX_PARTS) return false;
-  for (int i = 0; i < L->n_parts; ++i)
-    if (L->part_cols[i] % 128 != 0) return false;
-  if ((uint64_t)L->N * (uint64_t)rows >= (1ull << 31) || (uint64_t)L->K * (uint64_t)rows * L->n_parts >= (1ull << 31)) return false;
-  return true;
-}
-
+// (9..16 rows: the alternative second launch behind a rotation launch -- the chain family's kernel -- was measured SLOWER than the GEMV on
+// rotated x, profiles/r05_rows_boundary.jsonl, and its host branch was removed in round 6: profiles/NOTES.md 5.4.)
 extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  if (rows <= 16 && rows_chain_route(L, rows)) {
-    // workspace (sized by paro_linear_workspace_bytes): [epoch words | the chain kernel's K-split granules | rotated activations]
-    const int64_t chain_ws = paro_chain_workspace_bytes(L, rows);
-    const int64_t xrot_bytes = (int64_t)L->n_parts * rows * L->K * 2;
-    if (chain_ws > 0 && workspace && workspace_bytes >= chain_ws + xrot_bytes && x && y) {
-      void* xrot = (char*)workspace + chain_ws;
-      int rc = paro_rotate_parts(L, x, xrot, rows, stream);
-      if (rc != PARO_OK) return rc;
-      paro_chain_t C;
-      memset(&C, 0, sizeof(C));
-      C.x_rot = xrot;
-      C.y = y;
-      return paro_w4a16_gemv_chain(L, &C, rows, workspace, chain_ws, 0, 0, stream);
-    }
-  }
   if (rows <= 16) return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, -1, stream);
   // 17..32 rows: the GEMV kernel on pre-rotated activations with 2 MFMA row tiles per weight fragment (measured,
   // Llama-3-8B shapes at 24 rows, us GEMV / MFMA GEMM: qkv 25 / 30, o 24 / 26, gate_up 31 / 68, down 24 / 45); from 33

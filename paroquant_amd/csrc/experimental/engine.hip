@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "chain_impl.hpp"
+#include "paro_abi_experimental.h"
 
 namespace paro {
 

@@ -46,6 +46,7 @@
 #include <vector>
 
 #include "chain_impl.hpp"
+#include "paro_abi_experimental.h"
 
 #ifndef PARO_E2_CONS
 #define PARO_E2_CONS 7

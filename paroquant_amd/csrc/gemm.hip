@@ -430,25 +430,6 @@ int gemm4_ksplit(const paro_linear_t* L, int64_t rows) {
 namespace paro {
 int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, int diag, int qs, int rt);   // gemm3.hip
 
-// side stream + events of the per-partition prefill path (one set per host thread and device, created on first use, never destroyed)
-struct OverlapCtx {
-  hipStream_t side;
-  hipEvent_t fork, first, part[PARO_MAX_PARTS];
-};
-static OverlapCtx* overlap_ctx() {
-  static thread_local OverlapCtx* ctx[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!ctx[dev]) {
-    OverlapCtx* c = new OverlapCtx();
-    bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->first, hipEventDisableTiming) == hipSuccess;
-    for (int p = 0; ok && p < PARO_MAX_PARTS; ++p) ok = hipEventCreateWithFlags(&c->part[p], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { delete c; (void)hipGetLastError(); return nullptr; }
-    ctx[dev] = c;
-  }
-  return ctx[dev];
-}
 }
 
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
@@ -493,20 +474,10 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     return fail(PARO_ERR_INVALID, "workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES);
-  // Merged projections at prefill sizes: the pre-pass writes one rotated copy of A per partition (12 % of a Llama-3-8B
-  // qkv call at M = 65536) and is bound by the vector-memory path, the GEMM by the matrix cores.  Per partition on two streams -- rotate
-  // p + 1 on a side stream while the GEMM of p runs, fork / join by events inside this call (graph-capturable) -- would hide all but the
-  // first partition's rotation IF the two kernels could share a CU.  They cannot: a GEMM workgroup holds 128 KB of LDS, a pre-pass
-  // workgroup 68 KB, a CU has 160 KB.  Measured (profiles/r05_prefill_overlap.txt): qkv 3.50 -> 3.69 ms (three narrower GEMM launches,
-  // nothing hidden), gate_up unchanged.  The path stays, tested, behind PARO_PREFILL_OVERLAP=1 (read per call); default: the single
-  // pre-pass + single GEMM launch.
-  const char* env_ov = getenv("PARO_PREFILL_OVERLAP");
-  const int env_overlap = env_ov ? atoi(env_ov) : 0;
-  const bool overlap = env_overlap && v == 4 && L->rmat && rows >= 4096 && L->n_parts > 1 && ksplit_req <= 1 && !diag;
-  OverlapCtx* oc = overlap ? overlap_ctx() : nullptr;
-  if (oc) {
-    // (filled below, once the GEMM arguments exist)
-  } else if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
+  // (Merged projections: rotating partition p + 1 on a side stream while the GEMM of partition p runs was built in round 5 and does not
+  // overlap -- a GEMM workgroup holds 128 KB of LDS, a pre-pass workgroup 68 KB, a CU has 160 KB: profiles/r05_prefill_overlap.txt, NOTES 5.4;
+  // the host branch was removed in round 6.)
+  if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
     rc = launch_rotate_mfma(x, xrot, L->rmat, rows, L->K, L->n_parts, L->act_dtype, st);
   else
     rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
@@ -538,35 +509,6 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     a.partial = (float*)((char*)workspace + PARO_WS_COUNTER_BYTES + ((xrot_bytes + 255) / 256) * 256);
   }
   dim3 grid((unsigned)a.pt.cbs, (unsigned)rb, (unsigned)a.ksplit);
-  if (oc) {
-    const int P = L->n_parts;
-    const int64_t part_elems = rows * L->K, rmat_elems = (L->K / 128) * 128 * 128;
-    auto rot = [&](int p, hipStream_t s) {
-      return launch_rotate_mfma(x, xrot + (int64_t)p * part_elems, (const unsigned short*)L->rmat + (int64_t)p * rmat_elems, rows, L->K, 1, L->act_dtype, s);
-    };
-    bool ok = hipEventRecord(oc->fork, st) == hipSuccess && hipStreamWaitEvent(oc->side, oc->fork, 0) == hipSuccess;
-    if (ok) {
-      rc = rot(0, st);
-      if (rc != PARO_OK) return rc;
-      ok = hipEventRecord(oc->first, st) == hipSuccess && hipStreamWaitEvent(oc->side, oc->first, 0) == hipSuccess;   // (one rotation at a time: they share the memory path)
-      for (int p = 1; ok && p < P; ++p) {
-        rc = rot(p, oc->side);
-        if (rc != PARO_OK) return rc;
-        ok = hipEventRecord(oc->part[p], oc->side) == hipSuccess;
-      }
-      for (int p = 0; ok && p < P; ++p) {
-        if (p > 0) ok = hipStreamWaitEvent(st, oc->part[p], 0) == hipSuccess;      // joins the side stream: its last work is partition P - 1's rotation
-        if (!ok) break;
-        GemmArgs ap = a;
-        ap.cb0 = a.pt.cb_start[p];
-        const dim3 gp((unsigned)(a.pt.cb_start[p + 1] - a.pt.cb_start[p]), (unsigned)rb, 1u);
-        rc = launch_gemm3(ap, L->act_dtype, gp, st, 0, qs, rt4);
-        if (rc != PARO_OK) return rc;
-      }
-    }
-    if (!ok) return fail(PARO_ERR_LAUNCH, "paro_w4a16_gemm: stream fork / join failed: %s", hipGetErrorString(hipGetLastError()));
-    return check_launch("paro_w4a16_gemm");
-  }
   if (v == 4) {
     rc = launch_gemm3(a, L->act_dtype, grid, st, diag, qs, rt4);
     if (rc != PARO_OK) return rc;

@@ -1,4 +1,8 @@
-"""``DecodeEngine`` -- a chain of ParoQuant linears at batch 1 in ONE persistent launch (``paro_engine_*``, csrc/engine.hip).
+"""``DecodeEngine`` -- a chain of ParoQuant linears at batch 1 in ONE persistent launch (``paro_engine_*``, csrc/experimental/engine.hip).
+
+EXPERIMENTAL (round 6): both engine builds are parity-green and measured slower than one launch per linear on every shape this repo
+times (profiles/NOTES.md 4.2, 5.1), so they left the default library -- this class needs ``make -C paroquant_amd/csrc EXPERIMENTAL=1``
+(include/paro_abi_experimental.h) and raises otherwise.  Nothing in the product path constructs it.
 
 The reference runs ``rotate -> INT4 GEMM`` per linear (``transformers/modules.py:57-71``, ``vllm/plugin.py:281-311``); an HF MLP block is
 three such linears plus the activation (``down(act(gate(x)) * up(x))``).  At one row those are dependent launches of a few microseconds
@@ -29,6 +33,9 @@ class DecodeEngine:
         0: ``PARO_ENGINE_VERSION`` or the default.  ``split`` (version 2): K-chunks per linear, 0 = the planner's."""
         import os
         lib = nat.load()
+        if not nat.has_experimental():
+            raise RuntimeError("DecodeEngine needs a library built with `make -C paroquant_amd/csrc EXPERIMENTAL=1` "
+                               "(the persistent engines are not part of the default libparo_mi355x.so: include/paro_abi_experimental.h)")
         self.version = int(version) or int(os.environ.get("PARO_ENGINE_VERSION", "1"))
         if self.version not in (1, 2):
             raise ValueError("engine version must be 1 or 2")

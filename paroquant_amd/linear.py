@@ -259,8 +259,8 @@ class RotateQuantizedLinear(nn.Module):
         if prefill:
             self._packed.prepare_prefill()
         from . import autotune
-        if autotune.enabled():
-            self._packed.autotune()
+        if autotune.enabled():                  # PARO_AUTOTUNE=1: tuned with the module's activation type (scales carry it: modules.py:43-55)
+            self._packed.autotune(torch.bfloat16 if self.scales.dtype == torch.bfloat16 else torch.float16)
         return self
 
     def release_checkpoint_buffers(self) -> "RotateQuantizedLinear":

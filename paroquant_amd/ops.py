@@ -265,7 +265,7 @@ def w4a16_gemv_tuned(x, pk, tiles_per_wave: int = 0, ksplit: int = 0, waves: int
     rows = x2.size(0)
     y = torch.empty((rows, N), dtype=x.dtype, device=x.device)
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                  pk.channel_scales, bias, pk.wq_order)
+                  pk.channel_scales, bias, pk.wq_order, launch_hint=getattr(pk, "launch_hint", 0))   # (explicit knobs override the hint: gemv.hip)
     ws = pk.workspace
     need = lib.paro_linear_workspace_bytes(ctypes.byref(d), rows)
     if ws.numel() * ws.element_size() < need:
@@ -375,7 +375,7 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N or not residual.is_contiguous()):
         raise ValueError("residual must be a contiguous [rows, N] tensor of the activation dtype")
     d = make_desc(K, pk.partition_sizes, int(pk.pairs.size(1)), x.dtype, pk.wq, pk.sz, pk.rot, pk.pairs, pk.theta,
-                  pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order)
+                  pk.channel_scales, bias if bias is not None else pk.bias, pk.wq_order, launch_hint=getattr(pk, "launch_hint", 0))
     f = nat.ParoFusion()
     f.prologue, f.eps, f.x_stride = int(prologue), float(eps), int(x2.stride(0))
     f.residual = residual.data_ptr() if residual is not None else None
@@ -673,7 +673,7 @@ def check_workspace(ws: torch.Tensor) -> None:
 
 def decode_workspace_bytes(K: int, N: int, n_parts: int, rows: int = 16) -> int:
     """Mirror of ``paro_linear_workspace_bytes`` for rows <= 16."""
-    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 8 + n_parts * rows * K * 2
+    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 8 + n_parts * rows * K * 4
 
 
 # --------------------------------------------------------------------------------------

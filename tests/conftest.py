@@ -22,3 +22,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def experimental_library() -> bool:
+    """True when paroquant_amd/_lib/libparo_mi355x.so was built with ``make EXPERIMENTAL=1`` (the persistent decode engines,
+    include/paro_abi_experimental.h).  They are outside the default library and the default test run."""
+    try:
+        from paroquant_amd import _native
+        return _native.has_experimental()
+    except Exception:
+        return False
+
+
+needs_experimental = pytest.mark.skipif(not experimental_library(), reason="needs `make -C paroquant_amd/csrc EXPERIMENTAL=1` (persistent engines)")

@@ -14,7 +14,7 @@ from oracle import paro_oracle as po
 pytestmark = pytest.mark.gpu
 
 TIGHT_F16 = 3e-3
-TIGHT_BF16 = 2e-2
+TIGHT_BF16 = 8e-3
 
 
 @pytest.fixture(scope="module")

@@ -1,4 +1,4 @@
-"""GPU tests of the persistent decode engines (``paro_engine_*``, csrc/engine.hip, and the loader / consumer build ``paro_engine2_*``,
+"""GPU tests of the persistent decode engines (EXPERIMENTAL build only -- ``paro_engine_*``, csrc/experimental/engine.hip, and the loader / consumer build ``paro_engine2_*``,
 csrc/engine2.hip; ``paroquant_amd.engine.DecodeEngine(version=1 | 2)``): a chain of ParoQuant linears at batch 1 in ONE launch.  Checked against the CPU oracle applied linear by linear on the same seeded inputs (the
 north star's 1e-2 gate, and the tight tolerance of tests/test_gpu_parity.py per stage), against the per-call kernels on the same chain,
 and for run-to-run bit identity (eager and HIP-graph replay): the engine's hand-offs are placement-independent by construction, the
@@ -10,7 +10,9 @@ import torch
 from oracle import paro_oracle as po
 from tests.test_gpu_parity import REL_TOL, TIGHT_BF16, TIGHT_F16, _np, _packed, _t, dev  # noqa: F401
 
-pytestmark = pytest.mark.gpu
+from tests.conftest import needs_experimental
+
+pytestmark = [pytest.mark.gpu, needs_experimental]   # experimental build only: the engines are not in the default library
 
 
 def _oracle_chain(x, layers, in_col0, act):

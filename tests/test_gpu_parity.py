@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-2          # the north-star gate
 TIGHT_F16 = 3e-3        # what we actually expect for fp16 activations
-TIGHT_BF16 = 2e-2       # bf16 activations carry 8 mantissa bits
+TIGHT_BF16 = 8e-3       # bf16 activations carry 8 mantissa bits: one rounding of the rotated input + one of the output (was 2e-2)
 
 
 @pytest.fixture(scope="module")
@@ -48,14 +48,17 @@ def _packed(L, dev, bias=None):
 
 # ---------------------------------------------------------------- rotation::rotate
 
-@pytest.mark.parametrize("dtype,mode,tol", [(torch.float16, "f16", 4e-3), (torch.bfloat16, "bf16", 3e-2),
-                                            (torch.float32, "f32", 2e-5)])
+# tol: against the float64 ideal (ONE rounding to the activation type here); ftol: against the reference-faithful mode, whose
+# bf16 leg is the lossy one -- the reference casts theta and the channel scales to bf16 (rotation.cu:75-78) and re-rounds the state
+# after every stage (rotation.cuh:143-153): 8 stages x 2^-9 plus a 2^-9 angle error is what 6e-2 allows for, not this kernel
+@pytest.mark.parametrize("dtype,mode,tol,ftol", [(torch.float16, "f16", 4e-3, 8e-3), (torch.bfloat16, "bf16", 1e-2, 6e-2),
+                                                 (torch.float32, "f32", 2e-5, 4e-5)])
 @pytest.mark.parametrize("rows,hidden,gs,krot,with_scale", [
     (1, 128, 128, 8, True), (1, 4096, 128, 8, True), (3, 512, 128, 8, False), (4, 2560, 128, 8, True),
     (7, 1024, 128, 1, True), (33, 1024, 128, 3, True), (5, 256, 64, 8, True), (2, 192, 64, 1, False),
     (4100, 256, 128, 8, True), (0, 256, 128, 8, True),
 ])
-def test_rotate_matches_oracle(dev, dtype, mode, tol, rows, hidden, gs, krot, with_scale):
+def test_rotate_matches_oracle(dev, dtype, mode, tol, ftol, rows, hidden, gs, krot, with_scale):
     rng = np.random.default_rng(rows * 7919 + hidden + krot)
     x = rng.standard_normal((rows, hidden)).astype(np.float32)
     G = hidden // gs
@@ -72,7 +75,7 @@ def test_rotate_matches_oracle(dev, dtype, mode, tol, rows, hidden, gs, krot, wi
     faithful = po.rotate(xin, idx, theta, sc, gs, mode)
     got = _np(out)
     assert po.rel_err(got, ideal) < tol
-    assert po.rel_err(got, faithful) < 2 * tol
+    assert po.rel_err(got, faithful) < ftol
     if dtype != torch.float32:   # one rounding at the end: at least as close to the ideal as the reference-faithful path
         assert po.rel_err(got, ideal) <= po.rel_err(faithful, ideal) * 1.5 + 1e-4
 
@@ -1634,24 +1637,19 @@ def test_oneshot_allreduce_absent_peer_gives_up_once(dev):
             lib.paro_allreduce_buffer_destroy(b)
 
 
-def test_prefill_per_partition_overlap_in_a_graph(dev):
-    """The per-partition prefill path of merged projections (csrc/gemm.hip: rotate partition p + 1 on a side stream while the GEMM of
-    partition p runs) forks and joins inside ONE call: the same bits eagerly, from a captured HIP graph, and as the
-    single pre-pass + single GEMM launch it replaces (same kernels, same per-partition arithmetic); reference semantics: per-partition
-    rotate then GEMM, vllm/plugin.py:288-306."""
-    import os
+def test_prefill_merged_projection_in_a_graph(dev):
+    """The prefill path of a merged projection (csrc/gemm.hip: pre-pass + GEMM inside ONE call) gives the same bits eagerly, from a
+    captured HIP graph and over repeated calls on one stream; reference semantics: per-partition rotate then GEMM,
+    vllm/plugin.py:288-306.  (Round 5's two-stream per-partition variant of this call was measured slower and removed in round 6:
+    profiles/NOTES.md 5.4.)"""
     K, sizes, rows = 2048, [2048, 512, 512], 4096
     L = _random_gpu_layer(dev, K, sizes, seed=77)
     pk = _pack_gpu_layer(L).prepare_prefill(torch.float16)
     x = torch.randn(rows, K, device=dev, dtype=torch.float16)
     sample = torch.arange(0, rows, rows // 32, device=dev)
     ideal = _oracle_rows(L, x[sample])
-    y_single = pk.apply(x).clone()                    # the shipping path: one pre-pass launch, one GEMM launch
-    os.environ["PARO_PREFILL_OVERLAP"] = "1"          # (the library reads it per call)
-    try:
-        _overlap_checks(dev, pk, x, sample, ideal, y_single)
-    finally:
-        del os.environ["PARO_PREFILL_OVERLAP"]
+    y_single = pk.apply(x).clone()
+    _overlap_checks(dev, pk, x, sample, ideal, y_single)
 
 
 def _overlap_checks(dev, pk, x, sample, ideal, y_single):

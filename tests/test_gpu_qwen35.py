@@ -92,7 +92,26 @@ QWEN35_DEFAULT_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("name,K,sizes", QWEN35_DEFAULT_SHAPES)
+
+
+def _bench_hybrid_shapes(model):
+    """The six linear shapes bench.py times for a HYBRID model (`extra.configs` / `extra.prefill` for BASELINE config 3): taken from
+    bench.hybrid_layer_shapes itself so that the tested dims ARE the timed dims (VERDICT r5 missing #6)."""
+    import bench
+    seen, out = set(), []
+    for full in (True, False):
+        for name, K, sizes, _ in bench.hybrid_layer_shapes(model, full):
+            key = (K, tuple(sizes))
+            if key not in seen:
+                seen.add(key)
+                out.append((f"{model}:{name}", K, list(sizes)))
+    return out
+
+
+QWEN35_4B_CLASS_SHAPES = _bench_hybrid_shapes("qwen3.5-4b-class")
+
+
+@pytest.mark.parametrize("name,K,sizes", QWEN35_DEFAULT_SHAPES + QWEN35_4B_CLASS_SHAPES)
 @pytest.mark.parametrize("rows", [1, 8])
 def test_qwen35_default_config_linear_shapes(dev, name, K, sizes, rows):
     """Decode GEMV (fused family at one row, chain family at eight) at the REAL dimensions of the Qwen3.5 linear set,

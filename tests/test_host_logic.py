@@ -8,6 +8,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from tests.conftest import needs_experimental as _needs_experimental  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -415,7 +416,9 @@ def test_allreduce_epilogue_host_checks(lib):
     t, k, w, m = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(2)
     assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == 0 and m.value == 2
     assert t.value in (1, 2, 4, 8)
-    m = ctypes.c_int(3)
+    m = ctypes.c_int(3)      # ABI v17: mode 3 = the rotation shared inside the launch
+    assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == 0 and m.value == 3
+    m = ctypes.c_int(4)
     assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == -1
     # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
     assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
@@ -480,6 +483,7 @@ def test_decoder_rope_scaling_and_unsupported_configs():
     assert "partial_rotary_factor" not in (ok.rope_scaling or {})
 
 
+@_needs_experimental
 def test_engine_planner_covers_every_tile_once(lib):
     """`paro_engine_plan / _build` (host only; csrc/engine.hip): for the bench models' decoder layers on 256 CUs and a small odd case
     on 64, the plan blob is decoded here and checked -- every (group, 16-column tile) of every linear belongs to exactly ONE compute
@@ -611,14 +615,20 @@ def test_no_kernel_reads_the_dispatch_packet():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     blob = open(lib, "rb").read()
-    n, bad = 0, []
+    n, bad, n_shared = 0, [], 0
     for triple, co in m.code_objects(blob):
         if "gfx950" in triple and co[:4] == b"\x7fELF":
             for name, props, priv in m.kernels(co):
                 n += 1
-                if props & 0b110:
+                # bit 1: dispatch-packet pointer -- never.  bit 2: queue pointer -- only the shared-rotation instantiations of the GEMV
+                # (gemv_kernel<..., FUSED = 32, ...>): they take the queue's ADDRESS (two preloaded SGPRs, no memory access) into
+                # their launch tag so that two queues' equal dispatch ids never match (gemv_impl.hpp, FUSED | 32)
+                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi32ELi[12]EEE", name) is not None
+                if props & 0b010 or (props & 0b100 and not shared_rot):
                     bad.append(name)
+                n_shared += int(shared_rot and bool(props & 0b100))
     assert n > 100 and not bad, bad[:5]
+    assert n_shared > 0
 
 
 def test_round4_launch_shape_heuristics():
@@ -669,6 +679,7 @@ def test_round4_launch_shape_heuristics():
     assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 4, 8, 0)
 
 
+@_needs_experimental
 def test_engine2_planner_covers_every_tile_once(lib):
     """`paro_engine2_plan / _build` (host only; csrc/engine2.hip): the plan blob decoded here -- every (group, 16-column tile) of every
     linear belongs to exactly ONE compute unit, a CU's run of tiles lies inside one rotation partition and fits a ring slot row
@@ -678,7 +689,7 @@ def test_engine2_planner_covers_every_tile_once(lib):
     import numpy as np
     from paroquant_amd import _native as nat
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tools", "experimental"))
     import engine2_plan as ep
 
     cases = {256: list(ep.MODELS.values()) + [ep.MODELS["qwen3-4b"] * 2],
@@ -784,3 +795,53 @@ def test_autotune_selection_rule_and_cache(monkeypatch):
     t[(4, 2, 8)] = 5.0
     assert autotune.autotune_packed(twin, torch.float16, force=True)["choice"] == [4, 2, 8] and twin.launch_hint == 0 and len(calls) == 2
     autotune._CACHE.clear()
+
+
+def test_tp_first_run_plan_plumbing():
+    """tools/tp_first_run.py (the first-multi-GPU-box checklist) -- host logic only, no GPU: the plan it would run on an
+    N-GPU node names the steps in order (environment, one-shot all-reduce set-up + self-test, RCCL eager + graph probe, then
+    bench.py --gpus {1, 2, 4} per tensor-parallel workload), every multi-rank command goes through torch.distributed.run on 127.0.0.1 with
+    HSA_ENABLE_IPC_MODE_LEGACY=0, N > 1 bench lines must carry config.allreduce_ab, and bad arguments are refused.  Reference for what the
+    workloads shard: vllm/plugin.py:33-50."""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "tp_first_run.py")
+    out = subprocess.run([sys.executable, tool, "--gpus", "4", "--dry-run"], capture_output=True, text=True, check=True).stdout
+    plan = json.loads(out)
+    steps = plan["steps"]
+    assert [s["step"] for s in steps[:3]] == ["environment", "oneshot", "rccl"]
+    bench = [s for s in steps if s["step"] == "bench"]
+    assert [(s["workload"], s["n"]) for s in bench] == [(w, n) for w in ("qwen3.5-27b-class-tp", "llama3-70b-tp") for n in (1, 2, 4)]
+    ports = []
+    for s in steps:
+        assert s["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and s["env"]["MASTER_ADDR"] == "127.0.0.1"
+        if s["cmd"] and s["n"] > 1:
+            assert s["cmd"][1:3] == ["-m", "torch.distributed.run"] and f"--nproc-per-node={s['n']}" in s["cmd"]
+            assert s["cmd"][s["cmd"].index("--master-addr") + 1] == "127.0.0.1"
+            ports.append(s["cmd"][s["cmd"].index("--master-port") + 1])
+        if s["step"] == "bench":
+            assert ("config.allreduce_ab" in s["must_have"]) == (s["n"] > 1)
+            assert s["cmd"][s["cmd"].index("--gpus") + 1] == str(s["n"]) and s["cmd"][s["cmd"].index("--workload") + 1] == s["workload"]
+    assert len(set(ports)) == len(ports)          # one rendezvous port per multi-rank command
+    # 6 ranks: 1, 2, 4, then 6 itself; --skip drops steps; a non-TP workload and a world of one are refused
+    p6 = json.loads(subprocess.run([sys.executable, tool, "--gpus", "6", "--dry-run", "--skip", "oneshot,rccl", "--workloads", "llama3-70b-tp"],
+                                   capture_output=True, text=True, check=True).stdout)
+    assert [s["step"] for s in p6["steps"]] == ["environment"] + ["bench"] * 4 and [s["n"] for s in p6["steps"][1:]] == [1, 2, 4, 6]
+    bad = subprocess.run([sys.executable, tool, "--gpus", "4", "--dry-run", "--workloads", "qwen3-4b"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "not tensor-parallel" in bad.stderr
+    bad = subprocess.run([sys.executable, tool, "--gpus", "1", "--dry-run"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "must be >= 2" in bad.stderr
+    # the bench commands of the plan parse with bench.py's own parser
+    import bench
+    for s in bench_steps_of(plan):
+        a = bench.parse_args(s)
+        assert a.workload.endswith("-tp") and a.no_cpu_baseline
+
+
+def bench_steps_of(plan):
+    out = []
+    for s in plan["steps"]:
+        if s["step"] == "bench":
+            out.append(s["cmd"][s["cmd"].index(os.path.join(ROOT, "bench.py")) + 1:])
+    return out

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which phase of an engine-2 chain first disagrees with the per-call kernels (prefix chains of the Qwen3-4B layer)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

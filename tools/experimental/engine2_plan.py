@@ -3,7 +3,7 @@
 
 Per linear of the model's decoder layer: K-chunks, groups per chunk, tiles per CU (min .. max), groups of the busiest wave."""
 import argparse, ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from paroquant_amd import _native as nat

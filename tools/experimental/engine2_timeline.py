@@ -13,7 +13,7 @@ Per phase kind, in microseconds after the LAST compute unit has issued the previ
 over the compute units of each event of the FIRST and of the LAST wave to reach it, and the latest compute unit.
 The last line is the production kernel's whole-chain time per phase from a graph replay."""
 import argparse, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -12,7 +12,7 @@ published the previous phase's outputs (the edge's time zero), the median / late
   w0units wave 0 has consumed its units;   units  ... and staged its partial sums;   b2  the CU is past the second barrier
   pub     it has published its outputs = the next edge's time zero     (phase duration)"""
 import argparse, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

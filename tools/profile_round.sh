@@ -69,9 +69,7 @@ for m in qwen3-4b llama3-8b; do PARO_SPLIT_ATTN=0 timeout 300 python tools/bench
 # ---- deferred K-split reduction per launch and per producer -> consumer pair
 rm -f $P/${R}_parts_micro.jsonl
 for m in qwen3-4b llama3-8b; do timeout 300 python tools/bench_parts.py --model $m >> $P/${R}_parts_micro.jsonl 2>> $OUT/parts.err; done
-# ---- the persistent engine: per-edge timeline (paro_engine_trace) of two models
-rm -f $P/${R}_engine_timeline.jsonl
-for m in qwen3-4b llama3-8b; do timeout 300 python tools/engine_timeline.py --model $m --layers 4 >> $P/${R}_engine_timeline.jsonl 2>> $OUT/engine.err; done
+# (the persistent engine's per-edge timeline: EXPERIMENTAL builds only -- tools/engine_timeline.py; profiles/r04_engine_timeline*)
 # ---- determinism stress of the fused GEMV family (10 000 iterations x 8 cases; tools/stress_fused.py)
 timeout 900 python tools/stress_fused.py 10000 2>&1 | grep -v amdgpu.ids | tail -3 > $P/${R}_stress_fused.txt
 # ---- prefill

@@ -24,10 +24,7 @@ timeout 300 python tools/bench_gemm.py --model llama3-8b --rows 65536 --variants
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/gemm_pmc1 -o p -- python $ROOT/tools/bench_gemm.py --model llama3-8b --rows 65536 --variants 0 --rounds 1 --reps 1 > $OUT/gemm_pmc1.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/gemm_pmc2 -o p -- python $ROOT/tools/bench_gemm.py --model llama3-8b --rows 65536 --variants 0 --rounds 1 --reps 1 > $OUT/gemm_pmc2.log 2>&1)
 python tools/pmc_gemm_summary.py $OUT/gemm_pmc1 $OUT/gemm_pmc2 > $P/${R}_gemm_pmc.json 2>> $OUT/gemm.err
-# the persistent engines: per-edge timelines
-rm -f $P/${R}_engine_timeline.jsonl
-timeout 200 python tools/engine_timeline.py --model qwen3-4b --layers 4 >> $P/${R}_engine_timeline.jsonl 2>> $OUT/engine.err
-for m in qwen3-4b llama3-8b; do timeout 200 python tools/engine2_timeline.py --model $m --layers 4 --reps 5 --tag engine2 >> $P/${R}_engine_timeline.jsonl 2>> $OUT/engine.err; done
+# (the persistent engines' timelines: EXPERIMENTAL builds only -- tools/engine_timeline.py, tools/engine2_timeline.py; profiles/r05_engine*)
 # ---- PMC passes LAST
 cd /tmp
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e --no-route-ab --no-north-star --no-extra > $OUT/fetch.log 2>&1
