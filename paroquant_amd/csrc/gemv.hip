@@ -196,8 +196,8 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
-  if (mode != 0 && mode != 1 && mode != 2 && mode != 3)
-    return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (rotation inside every workgroup), 1 (rotate pre-pass), 2 (x is already rotated) or 3 (rotation shared inside the launch)");
+  if (mode != 0 && mode != 1 && mode != 2)
+    return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused), 1 (rotate pre-pass) or 2 (x is already rotated)");
   if (mode != 2 && (L->krot > 8 || rows > 16)) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
   // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
   // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
@@ -209,13 +209,14 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // below 9 rows only the wide merged projections still prefer the pre-pass)
   // (round 4, profiles/r04_sweep_rows16_*.jsonl: a NARROW single-partition output with K < 8192 -- o_proj: 40 column blocks x 4 K-slices --
   // replicates so little rotation that the fused form stays ahead up to 16 rows: 11.4 us against 13.5 / 13.7 with the pre-pass)
+  // (round 6, profiles/r06_rot_modes_sweep.jsonl -- Qwen3-4B, Llama-3-8B, Qwen3-0.6B shapes at 2..16 rows, us fused / pre-pass: at 5..8 rows
+  // the fused form now wins EVERYWHERE, the wide merged projections included -- Qwen3-4B gate_up 11.7 / 14.7, Llama-3-8B gate_up 17.7 /
+  // 19.5: round 2's rule for them dated from the kernels with packed-FP32 ops -- and at 9..16 rows it still wins where a workgroup rotates
+  // few groups for few columns: up to 24 groups below 1024 tiles -- Qwen3-4B qkv 12.6 / 13.6, Qwen3-0.6B qkv 7.7 / 9.9, gate_up 8.2 / 10.2;
+  // deep K and wide outputs keep the pre-pass there: Qwen3-4B gate_up 29.6 / 16.6, down 17.8 / 15.3, Llama-3-8B qkv 15.2 / 14.2)
   const bool narrow_single = L->n_parts == 1 && L->N / 16 <= 320 && L->K / 128 < 64;
-  if (mode_auto && mode == 0 && ((rows > 8 && !narrow_single) || (rows > 4 && L->n_parts > 1 && L->N / 16 >= 1024))) mode = 1;
-  // Round 6: the rotation shared inside the launch (mode 3: every (partition, group) rotated once per launch, handed over as tagged
-  // granules) removes the replicated rotation without a second launch.  PARO_SHARED_ROT_MIN_ROWS = first row count that takes it
-  // automatically (plain calls; 17 = never).
-  static const int shr_min = getenv("PARO_SHARED_ROT_MIN_ROWS") ? atoi(getenv("PARO_SHARED_ROT_MIN_ROWS")) : 17;
-  if (mode_auto && !deferred && L->krot <= 8 && rows <= 16 && rows >= shr_min) mode = 3;
+  const bool few_groups = L->K / 128 <= 24 && L->N / 16 < 1024;
+  if (mode_auto && rows > 8 && !narrow_single && !few_groups) mode = 1;
   gemv_autotune(L, rows, tpw, ksp, wv, deferred);
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   (void)waves_in;
@@ -245,7 +246,7 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (validate_linear(L) != PARO_OK) return -1;
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
-  const int64_t xrot = (int64_t)L->n_parts * r * L->K * (r <= 16 ? 4 : 2);  // rotated activations (GEMM path / mode 1 / krot > 8); <= 16 rows: as 8-byte {tag, two channels} granules (mode 3)
+  const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
   // 8-byte {tag, partial} granules of the GEMV K-split: any split up to kMaxKsplit for <= 16 rows (the
   // launch-shape knobs are the caller's), the automatic one for 17..64 rows
   int64_t slabs = 0;
@@ -336,7 +337,6 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     const int64_t min_stride = (F->prologue >= PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
   }
-  if (mode == 3 && (fused || pout)) return fail(PARO_ERR_UNSUPPORTED, "mode 3 (shared rotation) runs the plain linear: no prologue / epilogue fusion, no partial sums");
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
   if (E && tpw == 0 && wv == 0) {
     // expert slots: the grid is (column blocks) x (slots), so the slots fill the chip and fat column blocks cut the rotation every
@@ -417,12 +417,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 
   const int64_t slab_bytes = (a.ksplit > 1 && !pout) ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
-  const bool shared = mode == 3 && !fused;
-  if (mode == 3 && !shared) mode = 0;
-  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : (shared ? (int64_t)L->n_parts * rows * L->K * 4 : 0);
-  a.shared_rot = shared ? 1 : 0;
-  a.xg = nullptr;
-  a.shr_units = L->n_parts * G;
+  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
   const int64_t need = PARO_WS_COUNTER_BYTES + slab_bytes + xrot_bytes;
   if (slab_bytes + xrot_bytes > 0) {
     if (!workspace || workspace_bytes < need)
@@ -431,7 +426,6 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
-  if (shared) a.xg = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);   // [n_parts][G][rows][64] granules
   if (pout) a.slabs = (unsigned long long*)F->parts_out;        // float [N][4]
   if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
@@ -454,7 +448,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
        {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, nullptr, launch_gemv_f16_1_t4, nullptr, nullptr, nullptr, launch_gemv_f16_1_t8}},
       {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, nullptr, launch_gemv_bf16_0_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_0_t8},
        {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, nullptr, launch_gemv_bf16_1_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_1_t8}}};
-  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][(mode == 1 || mode == 2) ? 1 : 0][tpw - 1] : nullptr;
+  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode >= 1 ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
   rc = fn(a, wv, grid, st);
   if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1 && !pout) {
@@ -463,11 +457,6 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     gps = G;
     repack_hot();
     rc = fn(a, wv, dim3((unsigned)pt.cbs, 1), st);
-  }
-  if (rc == PARO_ERR_NOT_RESIDENT && shared) {
-    // the grid does not fit the chip at once (nobody may wait for a producer that is not running): the replicated rotation is always legal
-    a.shared_rot = 0;
-    rc = fn(a, wv, dim3((unsigned)pt.cbs, (unsigned)a.ksplit), st);
   }
   if (rc == PARO_ERR_NOT_RESIDENT) rc = PARO_ERR_UNSUPPORTED;
   if (rc != PARO_OK) return rc;

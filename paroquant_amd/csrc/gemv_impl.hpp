@@ -81,10 +81,6 @@ struct GemvArgs {
   long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
   int x_div;
   int n_experts;                         // ids outside [0, n_experts) read expert 0 and give NaN outputs (checked on the device: graph replays too)
-  // shared rotation (FUSED | 32, mode 3): every (partition, group) of x is rotated ONCE per launch -- by one wave of the grid -- and
-  // handed to the workgroups that multiply by it as {launch tag, two rotated channels} granules: [n_parts][G][rows][64 lanes] x 8 bytes
-  unsigned long long* xg;
-  int shr_units;                         // n_parts * G
   // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
   // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
   unsigned char* ar_peer[kArMaxWorld];   // every rank's buffer as mapped in this process, BY VALUE: a pointer fetched from device
@@ -98,7 +94,6 @@ struct GemvArgs {
   int rows, ksplit, prologue;
   int parts_out;                 // deferred K-split reduction (paro_fusion_t, v12): this launch leaves partial sums
   int attn_in;                   // x is a split attention launch's slots (paro_fusion_t.attn_in, v14): parts_in / x_out carry its two pointers
-  int shared_rot;                // mode 3: the rotation is shared inside the launch (FUSED | 32)
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
 };
@@ -156,17 +151,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr bool ATTN_IN = (FUSED & 16) != 0;    // x = the merge of a split attention launch's slots, completed while seeding
   static_assert(!PARTS_IN || ((FMODE == 0 || FMODE == 1) && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
   static_assert(!ATTN_IN || (FMODE == 0 && MB == 1 && !AREP && !PREROT && !PARTS_IN), "attention slots feed the plain one-row kernel");
-  // FUSED | 32 (FUSED & 31 == 0; 1..16 rows): SHARED ROTATION.  The in-kernel rotation above is replicated in every workgroup and its VALU cost grows
-  // with the rows (8 rows: 1.9x the one-row launch for identical bytes, profiles/r05_rows_boundary.jsonl).  Here every (partition, group)
-  // of x is rotated ONCE per launch: unit u = (p, g) belongs to wave u / n_wgs of workgroup u % n_wgs (one producer per CU first), which
-  // rotates it in registers exactly as below and publishes it as 8-byte {launch tag, channels 2l | 2l+1} granules with ONE write-through
-  // store per lane and row; every wave then GATHERS the groups it multiplies by (one 8-byte load per lane and row, checked against the
-  // tag, bounded re-poll) instead of rotating them.  The tag is the hardware's dispatch id of this launch (the AQL packet index: the same
-  // in every workgroup, new for every launch and every graph replay -- tools/probes/dispatch_id_probe.hip) mixed with the queue address:
-  // no epoch word, no re-arm, a stale or foreign granule is never consumed.  Same values, same rounding as the replicated form (the
-  // producer runs the same seed / stage / finish code): the outputs are bit-identical to mode 0.  Needs the whole grid resident (checked).
-  constexpr bool SHR = (FUSED & 32) != 0;
-  static_assert(!SHR || ((FUSED & 31) == 0 && !PREROT && MB <= 16), "the shared rotation feeds the plain kernel");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -350,8 +334,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
-    unsigned long long gr[SHR ? MB : 1];   // SHR: this lane's granule of every row: {tag, rotated channels 2l | 2l + 1}
-    GP<unsigned long long> gp;             // SHR: where they came from (the re-poll)
   };
   struct TBuf {
     u32x4 q[TPW];
@@ -364,8 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // per term, in a prologue every wave of the CU executes on the one shared scalar unit
   GP<unsigned short> xrot_p = x_p + (PREROT ? (unsigned)(p * h.rows * h.K) : 0u);
 
-  // the rotation inputs of group g of partition pu: exchange schedule, channel scales, x (SHR: the producer's unit -- any partition)
-  auto load_rot = [&](PBuf& b, int pu, int g) {
+  auto load_p = [&](PBuf& b, int g) {
     if constexpr (PREROT) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -395,10 +376,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         b.am[1] = ml[1];
       }
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
-      GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((pu * h.G + g) * 192 + lane);
+      GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
 #pragma unroll
       for (int q = 0; q < 3; ++q) b.rc[q] = rp[q * 64];
-      b.csv = *(GP<unsigned>)(h.cs + (unsigned)(pu * h.K + g * 128 + 2 * lane));
+      b.csv = *(GP<unsigned>)(h.cs + (unsigned)(p * h.K + g * 128 + 2 * lane));
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         const int rr = r < h.rows ? r : 0;  // clamp instead of branching: keeps the load count static
@@ -414,20 +395,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
     }
   };
-  // what a wave needs of group g before it can multiply: the rotation inputs -- or, with the shared rotation, the group's granules
-  // (write-through loads: they bypass this CU's L1, which another CU's stores never refresh)
-  auto load_p = [&](PBuf& b, int g) {
-    if constexpr (SHR) {
-      b.gp = (GP<unsigned long long>)a.xg + (unsigned)(((p * h.G + g) * h.rows) * 64 + lane);
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        const int rr = r < h.rows ? r : 0;
-        b.gr[r] = __hip_atomic_load((const unsigned long long*)(b.gp + rr * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else {
-      load_rot(b, p, g);
-    }
-  };
   // ---- first unit's coefficient requests, at priority 3 (see the note at the driver loop), then the bookkeeping
   // K-split epoch word of this column block (see ks_tag below): the wave's OLDEST vector request -- unconditional (any
   // readable word when the launch is not split), so it is waited for with the first coefficients, costs no round trip of its
@@ -436,26 +403,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const bool ks_handoff = h.ksplit > 1 && !h.parts_out;   // this launch reduces its K-splits itself (granules + epochs)
   const unsigned ep_raw = *(GP<unsigned>)((ks_handoff ? (GP<unsigned>)cnt_ptr : (GP<unsigned>)h.cs) + (ks_handoff ? (unsigned)cb : 0u));
   PBuf pc_first;
-  // SHR: this wave's producer unit u = (p_u, g_u) -- wave w of workgroup b owns u = b + w * n_wgs (one producer per CU before a second
-  // wave of any CU gets one); its rotation inputs are the wave's FIRST requests (clamped, unconditional: a wave without a unit loads
-  // unit 0's and discards them), the gather of its own first group follows the publish
-  PBuf pp_first;
-  int shr_u = 0;
-  bool shr_producer = false;
-  unsigned xtag = 0;
-  if constexpr (SHR) {
-    const int n_wgs = (int)(gridDim.x * gridDim.y);
-    shr_u = (ks * (int)gridDim.x + cb) + wave * n_wgs;
-    shr_producer = shr_u < a.shr_units;
-    if (!shr_producer) shr_u = 0;
-    // launch tag: the dispatch id (AQL packet index of this launch on its queue) + the queue's address, never zero
-    const unsigned long long did = paro_dispatch_id();
-    const unsigned long long qp = (unsigned long long)__builtin_amdgcn_queue_ptr();
-    xtag = ((unsigned)did + (unsigned)(qp >> 6) * 0x9E3779B1u) | 0x80000000u;
-  }
   if (h.prio) __builtin_amdgcn_s_setprio(3);
-  if constexpr (SHR) load_rot(pp_first, shr_u / h.G, shr_u % h.G);
-  else load_p(pc_first, gf_first);
+  load_p(pc_first, gf_first);
   __builtin_amdgcn_sched_barrier(0);
   if (h.prio) __builtin_amdgcn_s_setprio(0);
 
@@ -727,85 +676,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
   };
 
-  // ---- SHR: the producer's unit -- rotated like any unit of the replicated form, then published instead of consumed
-  if constexpr (SHR) {
-    if (shr_producer) {
-      float sa[MB], sb[MB];
-      seed(pp_first, sa, sb);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (t < h.krot) stage(pp_first, t, sa, sb);
-      }
-      finish(pp_first, xh, sa, sb);
-      __builtin_amdgcn_wave_barrier();
-      // the fragment rows hold the channels in their natural order: lane l re-reads channels 2l, 2l + 1 of every row and publishes them
-      unsigned long long* dst = a.xg + (unsigned)((shr_u * h.rows) * 64 + lane);
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        if (r < h.rows) {
-          const unsigned v = *(const unsigned*)(xh + r * kXhStride + 2 * lane);
-          __hip_atomic_store(dst + r * 64, ((unsigned long long)xtag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    // units beyond one per wave of the grid (tiny grids only): the same, one after the other
-    {
-      const int stride = (int)(gridDim.x * gridDim.y) * WAVES;
-      for (int u = (ks * (int)gridDim.x + cb) + wave * (int)(gridDim.x * gridDim.y) + stride; u < a.shr_units; u += stride) {
-        PBuf pq;
-        load_rot(pq, u / h.G, u % h.G);
-        float sa[MB], sb[MB];
-        seed(pq, sa, sb);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (t < h.krot) stage(pq, t, sa, sb);
-        }
-        finish(pq, xh, sa, sb);
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long* dst = a.xg + (unsigned)((u * h.rows) * 64 + lane);
-#pragma unroll
-        for (int r = 0; r < MB; ++r) {
-          if (r < h.rows) {
-            const unsigned v = *(const unsigned*)(xh + r * kXhStride + 2 * lane);
-            __hip_atomic_store(dst + r * 64, ((unsigned long long)xtag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    // now the gather of this wave's own first group
-    load_p(pc_first, gf_first);
-  }
-  // SHR: every lane's granules of the group must carry THIS launch's tag before they are used; a granule that does not yet is polled
-  // again (bounded; the re-poll is inline assembly with its own wait, so that the compiler's vmcnt bookkeeping of the pipelined loads
-  // around it stays exact -- the hardware counter is at zero when it leaves).  Give-up: NaN channels (they reach every output of the
-  // group through the matrix cores) and the workspace's sticky status word -- never a silently stale activation.
-  bool shr_gaveup = false;
-  auto shr_validate = [&](PBuf& b) {
-    bool bad = false;
-#pragma unroll
-    for (int r = 0; r < MB; ++r) bad = bad || (r < h.rows && (unsigned)(b.gr[r] >> 32) != xtag);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0ull, 0)) {
-#pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        if (r < h.rows) {
-          unsigned long long v = b.gr[r];
-          GP<unsigned long long> src = b.gp + r * 64;
-          for (int spin = 0; __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) != xtag) != 0ull && spin < (1 << 16); ++spin) {
-            __builtin_amdgcn_s_sleep(4);
-            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
-          }
-          if ((unsigned)(v >> 32) != xtag) {
-            v = 0x7fc07fc0ull;   // a NaN in both activation types (bf16 0x7fc0; read as fp16 the same bits are a NaN too)
-            shr_gaveup = true;
-          }
-          b.gr[r] = v;
-        }
-      }
-    }
-  };
-
   bool has_work_any = true;
   {
     // One unit at a time, distance-1 software pipeline.
@@ -829,12 +699,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if constexpr (PREROT) {
 #pragma unroll
         for (int i = 0; i < 4 * RT; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
-      } else if constexpr (SHR) {
-        shr_validate(pc);
-#pragma unroll
-        for (int r = 0; r < MB; ++r) *(unsigned*)(xh + r * kXhStride + 2 * lane) = (unsigned)pc.gr[r];
-        __builtin_amdgcn_wave_barrier();
-        frags_from_lds(xh, af);
       } else {
         float sa[MB], sb[MB];
         seed(pc, sa, sb);
@@ -1113,9 +977,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   }
   if (ks_handoff && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
-  if constexpr (SHR) {
-    if (shr_gaveup) a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
-  }
   if constexpr (FMODE == 1) {
     // RMSNorm prologue on a launch that leaves partial sums: no workgroup sees all of K, so the norm's scalar travels with the partial
     // sums -- row N of the buffer gets this K-slice's sum of squares (same slot order, unused slots zero) and whoever completes the
@@ -1165,7 +1026,7 @@ constexpr int PARO_ERR_NOT_RESIDENT = -100;   // internal: mapped to PARO_ERR_UN
 int device_cu_count();
 template <auto Kern, int THREADS>
 int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
-  if ((a.ksplit > 1 && !a.parts_out) || a.shared_rot) {   // (partial sums left to the consumer: nobody waits inside the launch; shared rotation: every wave waits for the producers)
+  if (a.ksplit > 1 && !a.parts_out) {   // (partial sums left to the consumer: nobody waits inside the launch)
     static int per_cu = -1;
     if (per_cu < 0) {
       int v = 0;
@@ -1174,8 +1035,8 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
     }
     const long long cap = (long long)per_cu * device_cu_count();
     if ((long long)grid.x * grid.y > cap)
-      return fail(PARO_ERR_NOT_RESIDENT, "%s grid of %u x %u workgroups exceeds the %lld that are resident at once; "
-                  "use a smaller ksplit or more tiles per wave", a.shared_rot ? "shared-rotation" : "K-split", grid.x, grid.y, cap);
+      return fail(PARO_ERR_NOT_RESIDENT, "K-split grid of %u x %u workgroups exceeds the %lld that are resident at once; "
+                  "use a smaller ksplit or more tiles per wave", grid.x, grid.y, cap);
   }
   hipLaunchKernelGGL(Kern, grid, dim3(THREADS), 0, st, a);
   return PARO_OK;
@@ -1241,24 +1102,6 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d tiles per wave x %d batch rows", waves, TPW, MB);
 }
 
-// shared rotation (FUSED = 32): plain kernel, 1..16 rows, power-of-two tiles per wave, group_size 128 and 64
-template <typename AT, int TPW, int MB>
-int launch_waves_shared(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if constexpr (tpw_is_pow2(TPW) && (MB <= 8 || TPW <= 4)) {
-    if (a.qs == 2) {
-      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32, 2>, 512>(a, grid, st);
-      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32, 2>, 256>(a, grid, st);
-      return fail(PARO_ERR_UNSUPPORTED, "group_size 64: the shared rotation is built for 4 or 8 waves per workgroup (got %d)", waves);
-    }
-    if constexpr (TPW < 8 && MB <= 4) {
-      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, 32>, 1024>(a, grid, st);
-    }
-    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32>, 512>(a, grid, st);
-    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32>, 256>(a, grid, st);
-  }
-  return fail(PARO_ERR_UNSUPPORTED, "shared rotation: not built for %d tiles per wave x %d waves x %d rows", TPW, waves, MB);
-}
-
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 #ifdef PARO_GEMV_DIAG   // make DIAG=1: diagnostic builds of the M = 1 kernel, selected with PARO_GEMV_PD = 11 / 21 / 31 / 41
@@ -1272,10 +1115,6 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
-  if (a.shared_rot) {
-    if constexpr (!PREROT && MB <= 16) return launch_waves_shared<AT, TPW, MB>(a, waves, grid, st);
-    return fail(PARO_ERR_UNSUPPORTED, "the shared rotation runs on un-rotated activations, 1..16 rows");
-  }
   if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine || a.parts_in || a.attn_in) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
 }
