@@ -535,6 +535,9 @@ NORTH_STAR_SHAPES = [("q_proj / o_proj", 4096, [4096], "row"), ("k_proj / v_proj
                      ("down_proj", 14336, [4096], "row")]
 
 
+LAUNCH_FLOOR_US, LAUNCH_FLOOR_GBPS = 2.4, 7500.0     # a dependent streaming launch on MI355X: profiles/r03_overlap_probe2.jsonl, DESIGN 3.1
+
+
 def per_shape_table(model: str, dev, reps: int = 400, shapes=None, min_bytes: int = 1 << 30):
     """Per-linear GEMV timing through the per-call operator (`PackedParoWeights.apply` = what RotateQuantizedLinear.forward /
     ParoQuantLinearMethod.apply run): events around `reps` back-to-back launches cycling >= `min_bytes` of distinct weights so
@@ -562,8 +565,12 @@ def per_shape_table(model: str, dev, reps: int = 400, shapes=None, min_bytes: in
         e1.record()
         torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / reps
+        floor_us = LAUNCH_FLOOR_US + nb / LAUNCH_FLOOR_GBPS / 1e3
         rows.append({"linear": name, "K": K, "N": sum(sizes), "P": len(sizes), "bytes": nb, "us_per_launch": round(us, 3),
-                     "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4)})
+                     "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4),
+                     # the distance to what ONE dependent launch that only streams these bytes costs on this part
+                     # (2.4 us + bytes / 7.5 TB/s, measured: profiles/r03_overlap_probe2.jsonl); floor_frac = floor / measured <= 1
+                     "floor_us": round(floor_us, 3), "floor_frac": round(floor_us / us, 4)})
         del packs, g
         torch.cuda.empty_cache()
     return rows
@@ -1131,7 +1138,8 @@ def run(args, rank: int, local_rank: int, world: int):
             try:
                 tab = per_shape_table("llama3-8b", dev, reps=300, shapes=NORTH_STAR_SHAPES, min_bytes=768 << 20)
                 result["extra"] = {"llama3_8b_per_shape": tab, "target_frac": 0.70,
-                                   "note": "batch-1 fused rotate + INT4 GEMV per operator call, HIP graph of 300 launches over >= 768 MiB of distinct weights"}
+                                   "note": "batch-1 fused rotate + INT4 GEMV per operator call, HIP graph of 300 launches over >= 768 MiB of distinct weights; "
+                                           "floor_frac = (2.4 us + bytes / 7.5 TB/s) / measured: the share of a launch that a kernel which only streamed its bytes would also take"}
             except Exception as e:
                 result["extra"] = {"llama3_8b_per_shape": {"error": f"{type(e).__name__}: {e}"}}
         if world == 1 and not tp_mode and args.rows == 1 and not args.no_extra:

@@ -410,7 +410,12 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.ar_rank = ar ? F->ar_rank : 0;
   a.ar_slot = ar ? ar_slot_b(F->ar_max_elems) : 0;
   a.ar_off = ar ? ar_region_b_off(F->ar_world, F->ar_max_elems) : 0;
-  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61) ? env_pd : 1;
+  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61 || env_pd == 71 || env_pd == 81) ? env_pd : 1;
+  // K-split reducer: its first poll goes out a few hundred cycles after its own partial sums are staged -- a poll that lands before the
+  // other slices' granules costs a whole extra round trip (profiles/r06_poll_delay_sweep.jsonl, us at 0 / 256 / 512 cycles: Qwen3-4B o
+  // 5.00 / 4.88 / 4.96, down 7.42 / 7.24 / 7.14; Llama-3-8B o 5.45 / 5.31 / 5.25, down 9.55 / 9.39 / 9.32).  PARO_POLL_DELAY overrides.
+  static const int env_poll = getenv("PARO_POLL_DELAY") ? atoi(getenv("PARO_POLL_DELAY")) : -1;
+  a.poll_delay = env_poll >= 0 ? env_poll : (gps >= 16 ? 8 : 4);
   auto repack_hot = [&]() {
     return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride, pout);
   };

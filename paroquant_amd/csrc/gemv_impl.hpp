@@ -96,6 +96,7 @@ struct GemvArgs {
   int attn_in;                   // x is a split attention launch's slots (paro_fusion_t.attn_in, v14): parts_in / x_out carry its two pointers
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
+  int poll_delay;                // 64-cycle sleeps in front of the K-split reducer's first poll (gemv.hip: 4, or 8 for deep K-slices)
 };
 static_assert(offsetof(GemvArgs, hot) == 0, "hot block at kernarg offset 0");
 
@@ -119,10 +120,11 @@ using GP = const __attribute__((address_space(1))) T*;
 
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
-// PD: 1 = the shipping kernel; 11 / 21 / 31 / 41 / 51 / 61 = diagnostic builds of the M = 1 kernel (make DIAG=1;
+// PD: 1 = the shipping kernel; 11 / 21 / 31 / 41 / 51 / 61 / 71 / 81 = diagnostic builds of the M = 1 kernel (make DIAG=1;
 // tools/ablate_gemv.py, tools/timeline_gemv.py): 11 skips schedule + stages, 21 also the unpack + MFMA (pure
 // stream), 41 fetches the schedule but does not run the stages, 51 runs the stages without the cross-lane
-// fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps.
+// fetch, 61 exchanges through LDS memory instead of ds_bpermute, 31 records s_memtime phase stamps, 71 / 81 fetch only 2 KiB / 1 KiB of
+// the group's 3 KiB schedule (what a smaller schedule format could save on the fetch side).
 // FUSED (1: RMSNorm prologue and / or residual epilogue, 2: SiLU*mul prologue (+ residual); | 4: + the all-reduce
 // epilogue of a row-parallel shard, one row): the decode-layer
 // fusions either side of the linear, in extra instantiations so that the plain kernel's code is
@@ -378,7 +380,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
       GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b.rc[q] = rp[q * 64];
+      for (int q = 0; q < 3; ++q) {
+        // DIAG 7 / 8 (timing only, wrong results): what a 2 KiB / 1 KiB schedule would cost to FETCH -- the third / second and third
+        // 1-KiB wave load of the group is not issued (profiles/r06_gemv_ablation.jsonl)
+        if constexpr (DIAG == 7) { b.rc[q] = q < 2 ? rp[q * 64] : b.rc[1]; }
+        else if constexpr (DIAG == 8) { b.rc[q] = q < 1 ? rp[q * 64] : b.rc[0]; }
+        else b.rc[q] = rp[q * 64];
+      }
       b.csv = *(GP<unsigned>)(h.cs + (unsigned)(p * h.K + g * 128 + 2 * lane));
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
       float o1 = sa[r], o2 = sb[r];
-      if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
+      if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6 || DIAG == 7 || DIAG == 8) {
         o1 = __builtin_fmaf(P, sa[r], Q * sb[r]);
         const float d = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
         o2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ flip);
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         float sa[MB], sb[MB];
         seed(pc, sa, sb);
         if constexpr (DIAG == 3) { if (ts[2] == 0) ts[2] = stamp_after(sa[0] + sb[0]); }
-        if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6) {
+        if constexpr (DIAG == 0 || DIAG == 3 || DIAG == 5 || DIAG == 6 || DIAG == 7 || DIAG == 8) {
           // (the universal krot = 8 without the per-stage compare + branch was tried twice: round 2 -- the 4-wave o_proj build 0.8 us
           // SLOWER -- and round 3 in the 8- / 16-wave builds only: down_proj -0.1 .. -0.3 us at one row, but the 16-wave build for
           // 2..4 rows came out of the compiler with nondeterministic results (tools/_stress-style loop: 136 mismatching runs of 150,
@@ -926,6 +934,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       // The first poll of EVERY split is issued before any of them is looked at (up to 4 per batch): a poll is a
       // ~0.6 us round trip to the coherence point, and one after the other they were most of the hand-off's cost.
       const int nsp = h.ksplit - 1;
+      for (int dly = 0; dly < a.poll_delay; ++dly) __builtin_amdgcn_s_sleep(1);
       for (int s0 = 0; s0 < nsp; s0 += 4) {
         unsigned long long gq[4];
 #pragma unroll
@@ -1112,6 +1121,8 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
     if (a.pd == 41) return launch_waves_pd<AT, TPW, MB, PREROT, 41>(a, waves, grid, st);
     if (a.pd == 51) return launch_waves_pd<AT, TPW, MB, PREROT, 51>(a, waves, grid, st);
     if (a.pd == 61) return launch_waves_pd<AT, TPW, MB, PREROT, 61>(a, waves, grid, st);
+    if (a.pd == 71) return launch_waves_pd<AT, TPW, MB, PREROT, 71>(a, waves, grid, st);
+    if (a.pd == 81) return launch_waves_pd<AT, TPW, MB, PREROT, 81>(a, waves, grid, st);
   }
 #endif
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);

@@ -5,11 +5,11 @@ variant is read once at library load).  Needs `make -C paroquant_amd/csrc clean 
     python tools/ablate_gemv.py [--model llama3-8b]
 
 PARO_GEMV_PD: 1 shipping kernel | 51 stages without the cross-lane fetch | 61 exchange through LDS memory
-| 41 schedule fetched, stages not run | 11 no schedule, no stages | 21 also no unpack / MFMA (pure stream)."""
+| 71 / 81 only 2 KiB / 1 KiB of the 3 KiB schedule fetched (stages run on garbage: timing only) | 41 schedule fetched, stages not run | 11 no schedule, no stages | 21 also no unpack / MFMA (pure stream)."""
 import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = {"o_proj": "0,0,0", "qkv_proj": "0,0,0", "gate_up_proj": "0,0,0", "down_proj": "0,0,0"}   # the automatic launch shapes (what ships)
-VARIANTS = [1, 41, 11, 21]
+VARIANTS = [1, 51, 71, 81, 41, 11, 21]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import numpy as np, torch
