@@ -1133,6 +1133,9 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 template <typename AT, int TPW, bool PREROT>
 int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   if (a.rows <= 1) return launch_waves<AT, TPW, 1, PREROT>(a, waves, grid, st);
+  // (two rows: their own instantiation since round 6 -- the rotation's VALU work is per row, a 4-row build run on 2 rows rotates two
+  // rows of zeros: Qwen3-4B step at 2 rows 1.329 -> see profiles/r06_rows_boundary.jsonl)
+  if (a.rows <= 2) return launch_waves<AT, TPW, 2, PREROT>(a, waves, grid, st);
   if (a.rows <= 4) return launch_waves<AT, TPW, 4, PREROT>(a, waves, grid, st);
   if constexpr (tpw_is_pow2(TPW)) {
     if (a.rows <= 8) return launch_waves<AT, TPW, 8, PREROT>(a, waves, grid, st);
