@@ -87,6 +87,11 @@ inline bool fill_part_table(PartTable& pt, int nparts, const int32_t* part_cols,
   return true;
 }
 
+// The AQL packet index of the running dispatch on its queue: the same in every workgroup of a launch, new for every launch and for every
+// replay of a captured graph (tools/probes/dispatch_id_probe.hip) -- a launch tag that costs no memory access.  clang has no builtin
+// for it; the LLVM intrinsic is reachable by name.
+extern "C" __device__ unsigned long long paro_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
+
 // ---- vector types ---------------------------------------------------------------
 typedef _Float16 f16;
 typedef __bf16 bf16;

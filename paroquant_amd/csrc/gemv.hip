@@ -36,6 +36,18 @@ int validate_linear(const paro_linear_t* L) {
 }
 
 constexpr int kMaxKsplit = 16;
+constexpr int kSharedRotRows = kShrTaskRows;   // rows per producer task of mode 3 (gemv_impl.hpp)
+inline int shared_rot_row_tasks(int64_t rows) { return rows <= kSharedRotRows ? 1 : (int)((rows + kSharedRotRows - 1) / kSharedRotRows); }
+// Producer workgroups of a mode-3 launch: one task per wave when the chip has room beside the consumers, up to four tasks per wave (run
+// one after the other: +0.3 .. 0.5 us on the hand-over) when it has not; -1 = the launch does not fit at all.
+inline int64_t shared_rot_cap(int64_t rows, int wv) { return 256 * (rows <= 8 ? 2 : 1) * (wv <= 4 ? 2 : 1); }   // resident at once: two 8-wave workgroups per CU up to 8 rows (113 VGPRs), one at 9..16 (145)
+inline int shared_rot_prod_wgs(int64_t units, int wv, int64_t consumers, int64_t cap) {
+  const int64_t want = (units + wv - 1) / wv, room = cap - consumers;
+  if (room >= want) return (int)want;
+  if (room >= 1 && room * 4 >= want) return (int)room;
+  return -1;
+}
+constexpr int kSharedRotMinRows = 5;    // automatic mode 3 from this many rows on (profiles/r06_shared_rot_ab.jsonl: ahead from the 8-row instantiation on; 17 = never)
 
 // Launch-shape heuristic (calibrated on MI355X with tools/sweep_gemv.py):
 // one workgroup covers all of K whenever that still yields >= ~1 workgroup per CU.
@@ -196,8 +208,8 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   if (ksp < 0 || ksp > kMaxKsplit) return fail(PARO_ERR_INVALID, "ksplit must be in 0..%d (got %d)", kMaxKsplit, ksp);
   const bool mode_auto = mode < 0;
   if (mode_auto) mode = 0;
-  if (mode != 0 && mode != 1 && mode != 2)
-    return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (fused), 1 (rotate pre-pass) or 2 (x is already rotated)");
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 3)
+    return fail(PARO_ERR_INVALID, "mode must be -1 (auto), 0 (rotation inside every workgroup), 1 (rotate pre-pass), 2 (x is already rotated) or 3 (rotation shared inside the launch)");
   if (mode != 2 && (L->krot > 8 || rows > 16)) mode = 1;  // the packed schedule holds 8 stages; 17..64 rows exist pre-rotated only
   // The fused rotation is replicated in every workgroup and its cost grows with the rows: beyond 8 rows,
   // and from 5 rows on for merged projections (one replicated rotation PER partition), rotating once up
@@ -217,7 +229,16 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   const bool narrow_single = L->n_parts == 1 && L->N / 16 <= 320 && L->K / 128 < 64;
   const bool few_groups = L->K / 128 <= 24 && L->N / 16 < 1024;
   if (mode_auto && rows > 8 && !narrow_single && !few_groups) mode = 1;
+  // Round 6: the rotation shared inside the launch (mode 3: every (partition, group, row quad) rotated ONCE per launch by one wave of the
+  // grid, handed over as {launch tag, two channels} granules) removes the replicated rotation without a second launch -- the GEMV on
+  // rotated activations is flat in the rows (Qwen3-4B layer at 8 rows 26.3 us against 25.5 at one row, profiles/r06_prerot_rows.jsonl),
+  // ALL of the batched-decode overhead is rotation.  PARO_SHARED_ROT_MIN_ROWS = first row count that takes it (plain calls; 17 = never).
+  static const int shr_min = getenv("PARO_SHARED_ROT_MIN_ROWS") ? atoi(getenv("PARO_SHARED_ROT_MIN_ROWS")) : kSharedRotMinRows;
+  const bool want_shared = mode_auto && !deferred && L->krot <= 8 && rows <= 16 && rows >= shr_min;
+  const int tpw_in = tpw;
   gemv_autotune(L, rows, tpw, ksp, wv, deferred);
+  // 9..16 rows: 4 tiles per wave (the accumulators of 16 rows x 8 tiles do not fit beside a replicated rotation); mode 3 runs 8 tiles
+  // there (no rotation state in a consumer) when that is what brings the grid onto the chip at once -- wide outputs: gate_up
   if (rows > 8 && rows <= 16 && tpw > 4) tpw = 4;
   (void)waves_in;
   if (tpw == 8 && wv == 16) wv = 8;   // 16 waves x 8 tiles does not fit the 128-VGPR budget
@@ -227,6 +248,18 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   const int G = (int)(L->K / 128);
   const int gps = (G + ksp - 1) / ksp;
   ksp = (G + gps - 1) / gps;           // empty splits are dropped
+  if (want_shared) {
+    // mode 3 only where producers + column blocks x K-slices fit the chip at once (the launcher checks the real occupancy and falls
+    // back to the replicated rotation): wide outputs at 9..16 rows run 8-tile blocks for it, or keep the pre-pass
+    const int64_t units = (int64_t)L->n_parts * G * shared_rot_row_tasks(rows);
+    auto fits = [&](int t) {
+      int64_t cbs = 0;
+      for (int i = 0; i < L->n_parts; ++i) cbs += (L->part_cols[i] / 16 + t - 1) / t;
+      return shared_rot_prod_wgs(units, wv, cbs * ksp, shared_rot_cap(rows, wv)) > 0;
+    };
+    if (fits(tpw)) mode = 3;
+    else if (tpw_in == 0 && rows > 8 && tpw == 4 && L->N / 16 >= 1024 && wv <= 8 && fits(8)) { tpw = 8; mode = 3; }
+  }
   return PARO_OK;
 }
 }  // namespace paro
@@ -246,7 +279,8 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (validate_linear(L) != PARO_OK) return -1;
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
-  const int64_t xrot = (int64_t)L->n_parts * r * L->K * 2;  // rotated activations (GEMM path / mode 1 / krot > 8)
+  const int64_t xrot = r <= 16 ? (int64_t)L->n_parts * L->K * ((r + 1) / 2) * 8   // <= 16 rows: as {two channels, tag} granules, 16 bytes per lane and row PAIR (mode 3)
+                               : (int64_t)L->n_parts * r * L->K * 2;               // rotated activations (GEMM path / mode 1 / krot > 8)
   // 8-byte {tag, partial} granules of the GEMV K-split: any split up to kMaxKsplit for <= 16 rows (the
   // launch-shape knobs are the caller's), the automatic one for 17..64 rows
   int64_t slabs = 0;
@@ -337,6 +371,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     const int64_t min_stride = (F->prologue >= PARO_PROLOGUE_SILU_MUL ? 2 : 1) * L->K;
     if (F->x_stride != 0 && F->x_stride < min_stride) return fail(PARO_ERR_INVALID, "x_stride %lld < %lld", (long long)F->x_stride, (long long)min_stride);
   }
+  if (mode == 3 && (fused || pout)) return fail(PARO_ERR_UNSUPPORTED, "mode 3 (shared rotation) runs the plain linear: no prologue / epilogue fusion, no partial sums");
   int tpw = tiles_per_wave, ksp = ksplit, wv = waves;
   if (E && tpw == 0 && wv == 0) {
     // expert slots: the grid is (column blocks) x (slots), so the slots fill the chip and fat column blocks cut the rotation every
@@ -410,7 +445,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.ar_rank = ar ? F->ar_rank : 0;
   a.ar_slot = ar ? ar_slot_b(F->ar_max_elems) : 0;
   a.ar_off = ar ? ar_region_b_off(F->ar_world, F->ar_max_elems) : 0;
-  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61 || env_pd == 71 || env_pd == 81) ? env_pd : 1;
+  a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61 || env_pd == 71 || env_pd == 81 || env_pd == 99) ? env_pd : 1;
   // K-split reducer: its first poll goes out a few hundred cycles after its own partial sums are staged -- a poll that lands before the
   // other slices' granules costs a whole extra round trip (profiles/r06_poll_delay_sweep.jsonl, us at 0 / 256 / 512 cycles: Qwen3-4B o
   // 5.00 / 4.88 / 4.96, down 7.42 / 7.24 / 7.14; Llama-3-8B o 5.45 / 5.31 / 5.25, down 9.55 / 9.39 / 9.32).  PARO_POLL_DELAY overrides.
@@ -422,7 +457,20 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 
   const int64_t slab_bytes = (a.ksplit > 1 && !pout) ? (int64_t)(a.ksplit - 1) * rows * L->N * 8 : 0;
-  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : 0;
+  const bool shared = mode == 3 && !fused;
+  if (mode == 3 && !shared) mode = 0;
+  const int64_t shr_bytes = (int64_t)L->n_parts * G * ((rows + 1) / 2) * 1024;   // granules: [partition][group][row pair][64 lanes] x 16 bytes
+  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : (shared ? shr_bytes : 0);
+  a.shared_rot = shared ? 1 : 0;
+  a.xg = nullptr;
+  a.shr_units = L->n_parts * G * shared_rot_row_tasks(rows);                  // tasks: (partition, group, quad of rows)
+  a.shr_prod_wgs = 0;                                                         // producer workgroups in front of every grid row
+  if (shared) {
+    const int pw = shared_rot_prod_wgs(a.shr_units, wv, (int64_t)pt.cbs * a.ksplit, shared_rot_cap(rows, wv));
+    a.shr_prod_wgs = pw > 0 ? pw : (a.shr_units + wv - 1) / wv;               // (explicit mode 3 on a grid that may not fit: the launcher decides)
+  }
+  a.shr_bytes = (int)shr_bytes;
+  if (shared && shr_bytes >= (1ll << 31)) return fail(PARO_ERR_UNSUPPORTED, "shared rotation: granule buffer too large");
   const int64_t need = PARO_WS_COUNTER_BYTES + slab_bytes + xrot_bytes;
   if (slab_bytes + xrot_bytes > 0) {
     if (!workspace || workspace_bytes < need)
@@ -431,6 +479,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     a.counters = (unsigned*)workspace;
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);
   }
+  if (shared) a.xg = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);   // [n_parts][G][rows][64] granules
   if (pout) a.slabs = (unsigned long long*)F->parts_out;        // float [N][4]
   if (a.pd == 31 && a.ksplit == 1 && workspace && workspace_bytes >= PARO_WS_COUNTER_BYTES + (int64_t)pt.cbs * 640)
     a.slabs = (unsigned long long*)((char*)workspace + PARO_WS_COUNTER_BYTES);   // per-workgroup phase timestamps (diagnostic build)
@@ -444,7 +493,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (rc != PARO_OK) return rc;
     a.hot.x = xrot;
   }
-  dim3 grid((unsigned)pt.cbs, (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
+  dim3 grid((unsigned)(pt.cbs + a.shr_prod_wgs), (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
   // [type][pre-rotated][tiles per wave - 1]: 1, 2, 4, 8 tiles per wave (the 3 / 5 / 6 / 7-tile builds of round 2 measured
   // within +-3 % of their neighbours on every shape and were dropped)
@@ -453,15 +502,25 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
        {launch_gemv_f16_1_t1, launch_gemv_f16_1_t2, nullptr, launch_gemv_f16_1_t4, nullptr, nullptr, nullptr, launch_gemv_f16_1_t8}},
       {{launch_gemv_bf16_0_t1, launch_gemv_bf16_0_t2, nullptr, launch_gemv_bf16_0_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_0_t8},
        {launch_gemv_bf16_1_t1, launch_gemv_bf16_1_t2, nullptr, launch_gemv_bf16_1_t4, nullptr, nullptr, nullptr, launch_gemv_bf16_1_t8}}};
-  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][mode >= 1 ? 1 : 0][tpw - 1] : nullptr;
+  const launch_fn fn = (tpw >= 1 && tpw <= 8) ? table[L->act_dtype == PARO_DTYPE_F16 ? 0 : 1][(mode == 1 || mode == 2) ? 1 : 0][tpw - 1] : nullptr;
   if (!fn) return fail(PARO_ERR_UNSUPPORTED, "tiles_per_wave = %d is not built for this mode", tpw);
   rc = fn(a, wv, grid, st);
+  if (rc == PARO_ERR_NOT_RESIDENT && shared && tpw == 8 && rows > 8)
+    // (8 tiles x 9..16 rows exist for the shared rotation only: the pre-pass route is what such a wide output takes otherwise)
+    return gemv_impl(L, x, y, rows, workspace, workspace_bytes, tiles_per_wave, ksplit, waves, 1, F, E, stream);
+  if (rc == PARO_ERR_NOT_RESIDENT && shared) {
+    // the grid does not fit the chip at once (nobody may wait for a producer that is not running): the replicated rotation is always legal
+    a.shared_rot = 0;
+    a.shr_prod_wgs = 0;
+    grid = dim3((unsigned)pt.cbs, (unsigned)a.ksplit, 1u);
+    rc = fn(a, wv, grid, st);
+  }
   if (rc == PARO_ERR_NOT_RESIDENT && ksplit == 0 && a.ksplit > 1 && !pout) {
     // the automatic K-split does not fit this instantiation's real occupancy: run unsplit (always legal)
     a.ksplit = 1;
     gps = G;
     repack_hot();
-    rc = fn(a, wv, dim3((unsigned)pt.cbs, 1), st);
+    rc = fn(a, wv, dim3((unsigned)(pt.cbs + a.shr_prod_wgs), 1), st);
   }
   if (rc == PARO_ERR_NOT_RESIDENT) rc = PARO_ERR_UNSUPPORTED;
   if (rc != PARO_OK) return rc;

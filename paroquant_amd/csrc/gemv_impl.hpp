@@ -81,6 +81,12 @@ struct GemvArgs {
   long long x_sstride, y_sstride;        // elements between slots of x (slot / x_div) and of y
   int x_div;
   int n_experts;                         // ids outside [0, n_experts) read expert 0 and give NaN outputs (checked on the device: graph replays too)
+  // shared rotation (FUSED | 32, mode 3): every (partition, group) of x is rotated ONCE per launch -- by one wave of the grid -- and
+  // handed to the workgroups that multiply by it as {launch tag, two rotated channels} granules: [n_parts][G][rows][64 lanes] x 8 bytes
+  unsigned long long* xg;
+  int shr_units;                         // producer tasks: n_parts * G * ceil(rows / 4) (rows <= 4: one per (partition, group))
+  int shr_prod_wgs;                      // producer workgroups in front of every grid row: ceil(shr_units / waves)
+  int shr_bytes;                         // size of the granule buffer (buffer descriptor bound)
   // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
   // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
   unsigned char* ar_peer[kArMaxWorld];   // every rank's buffer as mapped in this process, BY VALUE: a pointer fetched from device
@@ -94,6 +100,7 @@ struct GemvArgs {
   int rows, ksplit, prologue;
   int parts_out;                 // deferred K-split reduction (paro_fusion_t, v12): this launch leaves partial sums
   int attn_in;                   // x is a split attention launch's slots (paro_fusion_t.attn_in, v14): parts_in / x_out carry its two pointers
+  int shared_rot;                // mode 3: the rotation is shared inside the launch (FUSED | 32)
   int qs;                        // quantisation groups per 128-channel span: 1 (group_size 128) or 2 (group_size 64)
   int pd;                        // 1, or a diagnostic build of the M = 1 kernel (11 / 21 / 31 / 41 / 51 / 61)
   int poll_delay;                // 64-cycle sleeps in front of the K-split reducer's first poll (gemv.hip: 4, or 8 for deep K-slices)
@@ -118,6 +125,10 @@ inline bool pack_hot(GemvHot& h, const PartTable& pt, int G, int order, int rows
 template <typename T>
 using GP = const __attribute__((address_space(1))) T*;
 
+#ifndef PARO_SHR_TASK_ROWS
+#define PARO_SHR_TASK_ROWS 2
+#endif
+constexpr int kShrTaskRows = PARO_SHR_TASK_ROWS;   // rows of one producer task of the shared rotation (2 or 4: row pairs are the granule unit)
 constexpr int kXhStride = 136;  // halves per fragment row in LDS (128 + 8 pad: 16 rows' b128 reads spread over banks)
 
 // PD: 1 = the shipping kernel; 11 / 21 / 31 / 41 / 51 / 61 / 71 / 81 = diagnostic builds of the M = 1 kernel (make DIAG=1;
@@ -153,6 +164,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   constexpr bool ATTN_IN = (FUSED & 16) != 0;    // x = the merge of a split attention launch's slots, completed while seeding
   static_assert(!PARTS_IN || ((FMODE == 0 || FMODE == 1) && MB == 1 && !AREP && !PREROT), "partial sums feed the one-row RMSNorm / plain prologue");
   static_assert(!ATTN_IN || (FMODE == 0 && MB == 1 && !AREP && !PREROT && !PARTS_IN), "attention slots feed the plain one-row kernel");
+  // FUSED | 32 (FUSED & 31 == 0; 1..16 rows): SHARED ROTATION.  The in-kernel rotation above is replicated in every workgroup and its VALU cost grows
+  // with the rows (8 rows: 1.9x the one-row launch for identical bytes, profiles/r05_rows_boundary.jsonl).  Here every (partition, group)
+  // of x is rotated ONCE per launch: unit u = (p, g) belongs to wave u / n_wgs of workgroup u % n_wgs (one producer per CU first), which
+  // rotates it in registers exactly as below and publishes it as 8-byte {launch tag, channels 2l | 2l+1} granules with ONE write-through
+  // store per lane and row; every wave then GATHERS the groups it multiplies by (one 8-byte load per lane and row, checked against the
+  // tag, bounded re-poll) instead of rotating them.  The tag is the hardware's dispatch id of this launch (the AQL packet index: the same
+  // in every workgroup, new for every launch and every graph replay -- tools/probes/dispatch_id_probe.hip) mixed with the queue address:
+  // no epoch word, no re-arm, a stale or foreign granule is never consumed.  Same values, same rounding as the replicated form (the
+  // producer runs the same seed / stage / finish code): the outputs are bit-identical to mode 0.  Needs the whole grid resident (checked).
+  constexpr bool SHR = (FUSED & 32) != 0;
+  static_assert(!SHR || ((FUSED & 31) == 0 && !PREROT && MB <= 16), "the shared rotation feeds the plain kernel");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
   constexpr int DIAG = PD / 10;
@@ -180,7 +202,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = blockIdx.x, ks = blockIdx.y;
+  // (FUSED | 32: the first a.shr_prod_wgs workgroups of every grid row are the rotation's PRODUCERS -- dispatched first -- and the column
+  // blocks start behind them; see SHR below)
+  const int cb = ((FUSED & 32) != 0) ? (int)blockIdx.x - a.shr_prod_wgs : (int)blockIdx.x, ks = blockIdx.y;
   // The hot argument block (kernarg bytes 0..127) with two back-to-back scalar loads and ONE wait, and the partition
   // lookup of this column block, in one hand-written sequence:  p = #{q in 1..7 : cb >= cbs[q]} (seven compare +
   // add-with-carry pairs), then three indexed scalar reads (s_movrels) of cbs[p], ent[p], ent[p + 1].  The table half
@@ -266,6 +290,95 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.residual = (GP<unsigned short>)ptr(k0[13], k0[14]);
     h.xstride = (long long)k0[15];
   }
+  // ---- SHR: launch tag, granule buffer, and the PRODUCER workgroups (they never reach the GEMV below)
+  constexpr int kAuxSc1 = 16;                    // gfx940+ cache-policy immediate of the buffer intrinsics: bit 4 = sc1 (bit 0 sc0, bit 1 nt)
+  constexpr int PRR = MB < kShrTaskRows ? MB : kShrTaskRows;           // rows per producer task
+  const int shr_nrp = SHR ? (h.rows + 1) / 2 : 1;    // row pairs of the batch: granules are stored per (partition, group, row pair, lane)
+  unsigned xtag = 0;
+  __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(SHR ? a.xg : nullptr), 0, SHR ? a.shr_bytes : 0, 0x00020000);
+  if constexpr (SHR) {
+    // launch tag: the dispatch id (AQL packet index of this launch on its queue) + the queue's address, never zero
+    const unsigned long long did = paro_dispatch_id();
+    const unsigned long long qp = (unsigned long long)__builtin_amdgcn_queue_ptr();
+    xtag = ((unsigned)did + (unsigned)(qp >> 6) * 0x9E3779B1u) | 0x80000000u;
+    if (cb < 0) {
+      // producer workgroup: wave w rotates task u = blockIdx.x * WAVES + w = (partition, group, quad of rows) in registers -- the same
+      // seed / stage / finish arithmetic as the replicated form below, one rounding -- and publishes it: lane l stores channels 2l, 2l + 1
+      // of two rows as one 16-byte write-through store {x, tag, x, tag}
+      if (ks != 0) return;
+      const int nq = (h.rows + PRR - 1) / PRR;
+      unsigned short* xq = (unsigned short*)(lds + wave * (((PRR + 1) * kXhStride * 2 + 15) / 16 * 16));
+      const float fscale = __builtin_ldexpf(1.0f, 49 - 14 * h.krot);
+      for (int u = (int)blockIdx.x * WAVES + wave; u < a.shr_units; u += a.shr_prod_wgs * WAVES) {
+        const int pg = u / nq, r0 = (u - pg * nq) * PRR;
+        const int pu = pg / h.G, g = pg - pu * h.G;
+        GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)(pg * 192 + lane);
+        u32x4 rc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rc[q] = rp[q * 64];
+        const unsigned csv = *(GP<unsigned>)(h.cs + (unsigned)(pu * h.K + g * 128 + 2 * lane));
+        float sa[PRR], sb[PRR];
+        {
+          unsigned xv[PRR];
+#pragma unroll
+          for (int r = 0; r < PRR; ++r) {
+            const int rr = min(r0 + r, h.rows - 1);
+            xv[r] = *(GP<unsigned>)(h.x + (unsigned)(rr * h.K + g * 128 + 2 * lane));
+          }
+          const float c0 = f16_bits_to_f32(csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(csv >> 16) * 0x1p-63f;
+#pragma unroll
+          for (int r = 0; r < PRR; ++r) {
+            const unsigned v = (r0 + r < h.rows) ? xv[r] : 0u;
+            sa[r] = A::to_f32(v & 0xffffu) * c0;
+            sb[r] = A::to_f32(v >> 16) * c1;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < h.krot) {
+            const unsigned w = rc[t >> 2][t & 3];
+            const unsigned sw = rc[2][t >> 2];
+            const float P = (float)(int)(short)(w & 0xffffu), Q = (float)((int)w >> 16);
+            const int src = (int)((sw >> (8 * (t & 3))) & 0xffu);
+#pragma unroll
+            for (int r = 0; r < PRR; ++r) {
+              const float keep = __builtin_fmaf(P, sa[r], Q * sb[r]);
+              const float give = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+              sb[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, give)));
+              sa[r] = keep;
+            }
+          }
+        }
+        {
+          const unsigned w0 = rc[2][2], w1 = rc[2][3];
+          const float P = (float)(int)(short)(w0 & 0xffffu) * fscale, Q = (float)((int)w0 >> 16) * fscale;
+          const unsigned oa = w1 & 0xfeu, ob = (w1 >> 8) & 0xfeu;
+          const unsigned flip = w1 & 0x80000000u;
+#pragma unroll
+          for (int r = 0; r < PRR; ++r) {
+            const float o1 = __builtin_fmaf(P, sa[r], Q * sb[r]);
+            const float d = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+            const float o2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ flip);
+            *(unsigned short*)((unsigned char*)(xq + r * kXhStride) + oa) = A::from_f32(o1);
+            *(unsigned short*)((unsigned char*)(xq + r * kXhStride) + ob) = A::from_f32(o2);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rows r0 + 2 q, r0 + 2 q + 1 -> row pair (r0 >> 1) + q (r0 is a multiple of 4, or 0)
+#pragma unroll
+        for (int q = 0; q < (PRR + 1) / 2; ++q) {
+          if (r0 + 2 * q < h.rows) {
+            const unsigned v0 = *(const unsigned*)(xq + (2 * q) * kXhStride + 2 * lane);
+            const unsigned v1 = (2 * q + 1 < PRR) ? *(const unsigned*)(xq + (2 * q + 1 < PRR ? 2 * q + 1 : 0) * kXhStride + 2 * lane) : 0u;
+            const u32x4 gv = {v0, xtag, v1, xtag};
+            __builtin_amdgcn_raw_buffer_store_b128(gv, xg_rsrc, (unsigned)(((pg * shr_nrp + (r0 >> 1) + q) * 64 + lane) * 16), 0, kAuxSc1);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
   // PARTS_IN: where the completed x goes -- a buffer descriptor whose size is K halves in column block 0 (and when the caller
   // wants it) and ZERO elsewhere: out-of-range buffer stores are dropped by the hardware, no branch around the store
   __amdgpu_buffer_rsrc_t xout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pin_ptrs[1], 0, (PARTS_IN && cb == 0 && pin_ptrs[1] != 0) ? h.K * 2 : 0, 0x00020000);
@@ -336,6 +449,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     unsigned csv;
     u32x4 rc[3];                // exchange schedule of the group (paro_pack_rotation); unused when PREROT
     u32x4 xa[PREROT ? 4 * RT : 1];   // [row tile][k-step]
+    u32x4 gq[SHR ? (MB + 1) / 2 : 1];      // SHR: this lane's granules of every PAIR of rows: {channels 2l | 2l + 1, tag} x 2
+    unsigned goff;                         // SHR: where they came from (byte offset in the granule buffer: the re-poll)
   };
   struct TBuf {
     u32x4 q[TPW];
@@ -348,7 +463,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // per term, in a prologue every wave of the CU executes on the one shared scalar unit
   GP<unsigned short> xrot_p = x_p + (PREROT ? (unsigned)(p * h.rows * h.K) : 0u);
 
-  auto load_p = [&](PBuf& b, int g) {
+  // the rotation inputs of group g of partition pu: exchange schedule, channel scales, x (SHR: the producer's unit -- any partition)
+  auto load_rot = [&](PBuf& b, int pu, int g) {
     if constexpr (PREROT) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -378,7 +494,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         b.am[1] = ml[1];
       }
       // 3 KiB per group, three coalesced 1-KiB wave loads: [3][lane] x 16 bytes
-      GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((p * h.G + g) * 192 + lane);
+      GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)((pu * h.G + g) * 192 + lane);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         // DIAG 7 / 8 (timing only, wrong results): what a 2 KiB / 1 KiB schedule would cost to FETCH -- the third / second and third
@@ -387,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
         else if constexpr (DIAG == 8) { b.rc[q] = q < 1 ? rp[q * 64] : b.rc[0]; }
         else b.rc[q] = rp[q * 64];
       }
-      b.csv = *(GP<unsigned>)(h.cs + (unsigned)(p * h.K + g * 128 + 2 * lane));
+      b.csv = *(GP<unsigned>)(h.cs + (unsigned)(pu * h.K + g * 128 + 2 * lane));
 #pragma unroll
       for (int r = 0; r < MB; ++r) {
         const int rr = r < h.rows ? r : 0;  // clamp instead of branching: keeps the load count static
@@ -403,6 +519,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       }
     }
   };
+  // what a wave needs of group g before it can multiply: the rotation inputs -- or, with the shared rotation, the group's granules
+  // (write-through loads: they bypass this CU's L1, which another CU's stores never refresh)
+  auto load_p = [&](PBuf& b, int g) {
+    if constexpr (SHR) {
+      b.goff = (unsigned)((((p * h.G + g) * shr_nrp) * 64 + lane) * 16);
+#pragma unroll
+      for (int q = 0; q < (MB + 1) / 2; ++q) {
+        const int qq = q < shr_nrp ? q : 0;     // clamp instead of branching (static load count)
+        b.gq[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xg_rsrc, b.goff + (unsigned)(qq * 1024), 0, kAuxSc1));
+      }
+    } else {
+      load_rot(b, p, g);
+    }
+  };
   // ---- first unit's coefficient requests, at priority 3 (see the note at the driver loop), then the bookkeeping
   // K-split epoch word of this column block (see ks_tag below): the wave's OLDEST vector request -- unconditional (any
   // readable word when the launch is not split), so it is waited for with the first coefficients, costs no round trip of its
@@ -412,7 +542,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   const unsigned ep_raw = *(GP<unsigned>)((ks_handoff ? (GP<unsigned>)cnt_ptr : (GP<unsigned>)h.cs) + (ks_handoff ? (unsigned)cb : 0u));
   PBuf pc_first;
   if (h.prio) __builtin_amdgcn_s_setprio(3);
-  load_p(pc_first, gf_first);
+  if constexpr (!SHR) load_p(pc_first, gf_first);
   __builtin_amdgcn_sched_barrier(0);
   if (h.prio) __builtin_amdgcn_s_setprio(0);
 
@@ -684,6 +814,51 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     for (int i = 0; i < 4; ++i) af[i] = *(const vec8*)(afrag + 32 * i);
   };
 
+  // ---- SHR: the gather of this wave's first group.  The producers need about 2 us from the launch; until then the wave PROBES: one
+  // 16-byte request for the whole wave (lane 0's granule of the first row pair) per round, then the real gather -- which is checked
+  // in full below, so the probe is a heuristic, never a proof.  (A gather at kernel entry finds nothing, and 1500 waves re-polling
+  // whole groups is L2 traffic in front of the producers' own loads: the first cut of this mode, 8 rows 14.9 us against 8.4.)
+  if constexpr (SHR) {
+    const unsigned poff = (unsigned)((((p * h.G + gf_first) * shr_nrp) * 64) * 16);
+    for (int spin = 0; spin < (1 << 15); ++spin) {
+      const u32x4 pv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xg_rsrc, poff, 0, kAuxSc1));
+      if (__builtin_amdgcn_readfirstlane((int)pv[1]) == (int)xtag || a.pd == 99) break;
+      __builtin_amdgcn_s_sleep(3);
+    }
+    load_p(pc_first, gf_first);
+  }
+  // SHR: every lane's granules of the group must carry THIS launch's tag before they are used; a granule that does not yet is polled
+  // again (bounded; the re-poll is inline assembly with its own wait, so that the compiler's vmcnt bookkeeping of the pipelined loads
+  // around it stays exact -- the hardware counter is at zero when it leaves).  Give-up: NaN channels (they reach every output of the
+  // group through the matrix cores) and the workspace's sticky status word -- never a silently stale activation.
+  bool shr_gaveup = false;
+  auto shr_validate = [&](PBuf& b) {
+    auto any_bad = [&]() {
+      bool bad = false;
+#pragma unroll
+      for (int q = 0; q < (MB + 1) / 2; ++q)
+        bad = bad || (2 * q < h.rows && b.gq[q][1] != xtag) || (2 * q + 1 < h.rows && b.gq[q][3] != xtag);
+      return __builtin_amdgcn_ballot_w64(bad) != 0ull;
+    };
+    if (__builtin_expect(any_bad() && a.pd != 99, 0)) {
+      int spin = 0;
+      do {      // every row pair of the group again, ONE batch per round
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int q = 0; q < (MB + 1) / 2; ++q) {
+          const int qq = q < shr_nrp ? q : 0;
+          b.gq[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xg_rsrc, b.goff + (unsigned)(qq * 1024), 0, kAuxSc1));
+        }
+        ++spin;
+      } while (any_bad() && spin < (1 << 15));
+      if (any_bad()) {
+#pragma unroll
+        for (int q = 0; q < (MB + 1) / 2; ++q) b.gq[q] = (u32x4){0x7fc07fc0u, xtag, 0x7fc07fc0u, xtag};   // NaN in both activation types
+        shr_gaveup = true;
+      }
+    }
+  };
+
   bool has_work_any = true;
   {
     // One unit at a time, distance-1 software pipeline.
@@ -707,6 +882,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       if constexpr (PREROT) {
 #pragma unroll
         for (int i = 0; i < 4 * RT; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
+      } else if constexpr (SHR) {
+        shr_validate(pc);
+#pragma unroll
+        for (int r = 0; r < MB; ++r) *(unsigned*)(xh + r * kXhStride + 2 * lane) = pc.gq[r >> 1][2 * (r & 1)];
+        __builtin_amdgcn_wave_barrier();
+        frags_from_lds(xh, af);
       } else {
         float sa[MB], sb[MB];
         seed(pc, sa, sb);
@@ -986,6 +1167,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     }
   }
   if (ks_handoff && ks == h.ksplit - 1 && tid == 0) a.counters[cb] = ks_tag >> 12;
+  if constexpr (SHR) {
+    if (shr_gaveup) a.counters[PARO_WS_STATUS_OFFSET / 4] = PARO_WS_STATUS_GIVEUP;
+  }
   if constexpr (FMODE == 1) {
     // RMSNorm prologue on a launch that leaves partial sums: no workgroup sees all of K, so the norm's scalar travels with the partial
     // sums -- row N of the buffer gets this K-slice's sum of squares (same slot order, unused slots zero) and whoever completes the
@@ -1035,7 +1219,7 @@ constexpr int PARO_ERR_NOT_RESIDENT = -100;   // internal: mapped to PARO_ERR_UN
 int device_cu_count();
 template <auto Kern, int THREADS>
 int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
-  if (a.ksplit > 1 && !a.parts_out) {   // (partial sums left to the consumer: nobody waits inside the launch)
+  if ((a.ksplit > 1 && !a.parts_out) || a.shared_rot) {   // (partial sums left to the consumer: nobody waits inside the launch; shared rotation: every wave waits for the producers)
     static int per_cu = -1;
     if (per_cu < 0) {
       int v = 0;
@@ -1043,9 +1227,12 @@ int launch_checked(const GemvArgs& a, dim3 grid, hipStream_t st) {
       per_cu = v;
     }
     const long long cap = (long long)per_cu * device_cu_count();
-    if ((long long)grid.x * grid.y > cap)
-      return fail(PARO_ERR_NOT_RESIDENT, "K-split grid of %u x %u workgroups exceeds the %lld that are resident at once; "
-                  "use a smaller ksplit or more tiles per wave", grid.x, grid.y, cap);
+    // (shared rotation: the producer workgroups never wait and the workgroups in front of the other grid rows exit at once -- what must
+    // fit the chip together is the producers plus every column block x K-slice)
+    const long long waiting = a.shared_rot ? (long long)(grid.x - a.shr_prod_wgs) * grid.y + a.shr_prod_wgs : (long long)grid.x * grid.y;
+    if (waiting > cap)
+      return fail(PARO_ERR_NOT_RESIDENT, "%s grid of %u x %u workgroups exceeds the %lld that are resident at once; "
+                  "use a smaller ksplit or more tiles per wave", a.shared_rot ? "shared-rotation" : "K-split", grid.x, grid.y, cap);
   }
   hipLaunchKernelGGL(Kern, grid, dim3(THREADS), 0, st, a);
   return PARO_OK;
@@ -1111,6 +1298,24 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
   return fail(PARO_ERR_UNSUPPORTED, "waves per workgroup = %d not built for %d tiles per wave x %d batch rows", waves, TPW, MB);
 }
 
+// shared rotation (FUSED = 32): plain kernel, 1..16 rows, power-of-two tiles per wave, group_size 128 and 64
+template <typename AT, int TPW, int MB>
+int launch_waves_shared(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if constexpr (tpw_is_pow2(TPW)) {     // (8 tiles x 16 rows exists here only: nothing of the rotation is live in a consumer's registers)
+    if (a.qs == 2) {
+      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32, 2>, 512>(a, grid, st);
+      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32, 2>, 256>(a, grid, st);
+      return fail(PARO_ERR_UNSUPPORTED, "group_size 64: the shared rotation is built for 4 or 8 waves per workgroup (got %d)", waves);
+    }
+    if constexpr (TPW < 8 && MB <= 4) {
+      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, 32>, 1024>(a, grid, st);
+    }
+    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32>, 512>(a, grid, st);
+    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32>, 256>(a, grid, st);
+  }
+  return fail(PARO_ERR_UNSUPPORTED, "shared rotation: not built for %d tiles per wave x %d waves x %d rows", TPW, waves, MB);
+}
+
 template <typename AT, int TPW, int MB, bool PREROT>
 int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 #ifdef PARO_GEMV_DIAG   // make DIAG=1: diagnostic builds of the M = 1 kernel, selected with PARO_GEMV_PD = 11 / 21 / 31 / 41
@@ -1125,6 +1330,10 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
     if (a.pd == 81) return launch_waves_pd<AT, TPW, MB, PREROT, 81>(a, waves, grid, st);
   }
 #endif
+  if (a.shared_rot) {
+    if constexpr (!PREROT && MB <= 16) return launch_waves_shared<AT, TPW, MB>(a, waves, grid, st);
+    return fail(PARO_ERR_UNSUPPORTED, "the shared rotation runs on un-rotated activations, 1..16 rows");
+  }
   if (a.pd != 1) return fail(PARO_ERR_UNSUPPORTED, "PARO_GEMV_PD=%d needs a diagnostic build (make DIAG=1) and batch-1 fused mode", a.pd);
   if (a.prologue != PARO_PROLOGUE_NONE || (a.hot.residual_lo | a.hot.residual_hi) || a.expert_idx || a.ar_mine || a.parts_in || a.attn_in) return launch_waves_fused<AT, TPW, MB, PREROT>(a, waves, grid, st);
   return launch_waves_pd<AT, TPW, MB, PREROT, 1>(a, waves, grid, st);
@@ -1132,6 +1341,9 @@ int launch_waves(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 
 template <typename AT, int TPW, bool PREROT>
 int launch_rows(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if constexpr (TPW == 8 && !PREROT) {
+    if (a.shared_rot && a.rows > 8 && a.rows <= 16) return launch_waves_shared<AT, TPW, 16>(a, waves, grid, st);
+  }
   if (a.rows <= 1) return launch_waves<AT, TPW, 1, PREROT>(a, waves, grid, st);
   // (two rows: their own instantiation since round 6 -- the rotation's VALU work is per row, a 4-row build run on 2 rows rotates two
   // rows of zeros: Qwen3-4B step at 2 rows 1.329 -> see profiles/r06_rows_boundary.jsonl)

@@ -266,13 +266,18 @@ def test_round3_launch_shape_heuristics():
     # fused family, more than one row: o_proj keeps its one-row shape (4 tiles x 4 splits x 4 waves) up to 4 rows (round-4 re-sweep on the
     # build without packed-FP32 ops, profiles/r04_sweep_rows*.jsonl), 8 waves at 5..16 rows -- and stays FUSED up to 16 rows (a narrow
     # single-partition output replicates little rotation); mid-width qkv 4 tiles x 2 splits x 8 waves at 5..8 rows from K = 2048 on
+    # (round 6: from 5 rows on the launch shapes are the same and the MODE is 3 -- the rotation shared inside the launch -- wherever producers +
+    # column blocks x K-slices fit the chip at once; else the rules below: replicated rotation (0) or the pre-pass (1))
     for m in (l8, q4):
-        assert shape(*m["o_proj"], 2) == (4, 4, 4, 0) and shape(*m["o_proj"], 4) == (4, 4, 4, 0) and shape(*m["o_proj"], 8) == (4, 4, 8, 0)
+        assert shape(*m["o_proj"], 2) == (4, 4, 4, 0) and shape(*m["o_proj"], 4) == (4, 4, 4, 0) and shape(*m["o_proj"], 8)[:3] == (4, 4, 8)
         assert shape(*m["o_proj"], 1)[:3] == (4, 4, 4)
-        assert shape(*m["o_proj"], 16)[3] == 0 and shape(*m["down_proj"], 16)[3] == 1
-    # (round 6: at 9..16 rows a projection of at most 24 groups below 1024 tiles stays fused -- Qwen3-4B qkv, 20 groups; Llama-3-8B's, 32 groups, keeps the pre-pass)
-    assert shape(*l8["qkv_proj"], 16)[3] == 1 and shape(*q4["qkv_proj"], 16)[3] == 0
-    assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 0) and shape(*q4["qkv_proj"], 4) == (2, 1, 16, 0)
+    assert shape(*q4["o_proj"], 8)[3] == 3 and shape(*q4["o_proj"], 16)[3] == 3            # 40 blocks x 4 slices + producers: fits
+    assert shape(*l8["o_proj"], 8)[3] == 3 and shape(*l8["o_proj"], 16)[3] == 0            # 64 x 4 = 256: fits two per CU (<= 8 rows), not one (9..16: the fused form, narrow single partition)
+    assert shape(*l8["down_proj"], 16)[3] == 1 and shape(*q4["down_proj"], 16)[3] == 3
+    assert shape(*l8["qkv_proj"], 16)[3] == 3 and shape(*q4["qkv_proj"], 16)[3] == 3       # (Llama-3-8B: 96 x 2 + 64 producer workgroups looping over 96 tasks' worth of waves)
+    assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 3) and shape(*q4["qkv_proj"], 4) == (2, 1, 16, 0)
+    # wide outputs at 9..16 rows: 8-tile blocks for mode 3 (4-tile blocks do not fit the chip at once); past 16 rows the pre-pass
+    assert shape(*q4["gate_up_proj"], 16) == (8, 1, 8, 3) and shape(*l8["gate_up_proj"], 16) == (8, 1, 8, 3) and shape(*q4["gate_up_proj"], 17)[3] == 1
     # chain family (profiles/r03_chain_shape_sweep_rows.jsonl): deep K 8 slices at <= 8 rows, 5 at <= 16; the others 5 / 4; four groups per
     # slice instead of three (Qwen3-4B o_proj: 8 slices x 4 waves, not 11)
     assert chain(*q4["down_proj"], 8)[0] == 8 and chain(*q4["down_proj"], 16)[0] == 5
@@ -316,10 +321,13 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*l70["down_proj"], 1) == (8, 4, 8, 0)
     # small batches: fused up to 8 rows (round 6: the wide merged projections too -- profiles/r06_rot_modes_sweep.jsonl), rotate pre-pass
     # above unless a workgroup rotates few groups for few columns; 17..64 rows always pre-pass
-    assert shape(*l8["o_proj"], 8)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 0 and shape(*l8["down_proj"], 9)[3] == 1     # (o_proj: narrow, one partition: fused to 16 rows)
-    assert shape(*l8["qkv_proj"], 8)[3] == 0 and shape(*l8["qkv_proj"], 9)[3] == 1
-    assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 8)[3] == 0 and shape(*l8["gate_up_proj"], 9)[3] == 1
-    assert shape(*q4["qkv_proj"], 16)[3] == 0 and shape(*q4["gate_up_proj"], 8)[3] == 0 and shape(*q4["gate_up_proj"], 9)[3] == 1   # (20 groups: 384 tiles fused, 1216 not)
+    # (round 6, later: from 5 rows on mode 3 -- the rotation shared inside the launch -- where the grid fits the chip at once)
+    assert shape(*l8["o_proj"], 4)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 0 and shape(*l8["down_proj"], 9)[3] == 1     # (o_proj 9..16 rows: narrow, one partition: fused; down: no room for producers)
+    assert shape(*l8["qkv_proj"], 4)[3] == 0 and shape(*l8["qkv_proj"], 8)[3] == 3 and shape(*l8["qkv_proj"], 9)[3] == 3
+    assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 8)[3] == 3 and shape(*l8["gate_up_proj"], 9)[3] == 3
+    assert shape(*q4["qkv_proj"], 16)[3] == 3 and shape(*q4["gate_up_proj"], 8)[3] == 3 and shape(*q4["gate_up_proj"], 9)[3] == 3
+    # the rules behind mode 3 (PARO_SHARED_ROT_MIN_ROWS=17 in the environment restores them): explicit modes are taken as given
+    assert shape(*l8["gate_up_proj"], 8, mode=0)[3] == 0 and shape(*l8["gate_up_proj"], 8, mode=1)[3] == 1
     assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
     # a caller that fixes ksplit = 1 (the RMSNorm prologue) gets the best UNSPLIT shape of the sweeps, not a 2-tile default:
     # TP = 4 gate_up shard (8192 -> 2 x 7168) 4 tiles x 16 waves; narrow deep-K shards 1 tile x 16 waves
@@ -420,7 +428,9 @@ def test_allreduce_epilogue_host_checks(lib):
     t, k, w, m = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(2)
     assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == 0 and m.value == 2
     assert t.value in (1, 2, 4, 8)
-    m = ctypes.c_int(3)
+    m = ctypes.c_int(3)      # ABI v17: mode 3 = the rotation shared inside the launch
+    assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == 0 and m.value == 3
+    m = ctypes.c_int(4)
     assert lib.paro_gemv_launch_shape(ctypes.byref(d), 1, ctypes.byref(t), ctypes.byref(k), ctypes.byref(w), ctypes.byref(m)) == -1
     # region A: 2 sets x world x (max_elems / 2) granules, region B: 2 x world x max_elems granules, 8 bytes each, behind the 4 KiB header
     assert lib.paro_allreduce_buffer_bytes(8, 8192) == 4096 + 2 * 8 * 4096 * 8 + 2 * 8 * 8192 * 8
@@ -617,14 +627,20 @@ def test_no_kernel_reads_the_dispatch_packet():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     blob = open(lib, "rb").read()
-    n, bad = 0, []
+    n, bad, n_shared = 0, [], 0
     for triple, co in m.code_objects(blob):
         if "gfx950" in triple and co[:4] == b"\x7fELF":
             for name, props, priv in m.kernels(co):
                 n += 1
-                if props & 0b110:
+                # bit 1: dispatch-packet pointer -- never.  bit 2: queue pointer -- only the shared-rotation instantiations of the GEMV
+                # (gemv_kernel<..., FUSED = 32, ...>): they take the queue's ADDRESS (two preloaded SGPRs, no memory access) into
+                # their launch tag so that two queues' equal dispatch ids never match (gemv_impl.hpp, FUSED | 32)
+                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi32ELi[12]EEE", name) is not None
+                if props & 0b010 or (props & 0b100 and not shared_rot):
                     bad.append(name)
+                n_shared += int(shared_rot and bool(props & 0b100))
     assert n > 100 and not bad, bad[:5]
+    assert n_shared > 0
 
 
 def test_round4_launch_shape_heuristics():
