@@ -1,3 +1,4 @@
+"""GEMV on ALREADY-ROTATED activations (mode 2) against the rotation replicated in every workgroup (mode 0), per linear and row count:\nus per launch in a HIP graph of 100 launches over >= 1 GiB of weights.  Round 6: the pre-rotated GEMV is flat in the rows -- all of the\nbatched-decode overhead is rotation (profiles/r06_prerot_rows.jsonl; what mode 3 was built on).   python tools/bench_prerot_rows.py"""
 import sys, json, torch
 sys.path.insert(0, '.')
 import bench

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the GEMV's rotation modes per linear and row count (round 6): us per launch inside a HIP graph of `reps` launches cycling >= 1 GiB
-of distinct weights.  mode -1 = what `apply` picks, 0 = rotation replicated in every workgroup, 1 = stage-kernel pre-pass + the GEMV on rotated x.  (Mode 3 -- the
-rotation shared inside the launch: every (partition, group) rotated once by one wave of the grid and handed over as {launch tag, two
-channels} granules -- was built in round 6, bit-identical to mode 0, and lost on every shape and row count: profiles/r06_shared_rot_ab.jsonl,
-NOTES 6.2; its code is commit 5f02a04.  On a library that still has it the script also checks that mode 3 returns mode 0's bits.)
-    python tools/bench_shared_rot.py [--model qwen3-4b] [--rows 1,2,4,8,16] [--modes -1,0,3]"""
+of distinct weights.  mode -1 = what `apply` picks (PARO_SHARED_ROT_MIN_ROWS=17 in the environment: the rules before mode 3), 0 = rotation
+replicated in every workgroup, 1 = stage-kernel pre-pass + the GEMV on rotated x, 3 = the rotation shared inside the launch (producer
+workgroups in front of the grid, {two channels, launch tag} granules; automatic from 5 rows; an EXPLICIT mode 3 keeps the caller's /
+the rule tree's tiles per wave and falls back to mode 0 when that grid is not resident at once).  Also checks that mode 3 returns mode 0's
+bits.  Results of the final build of round 6: profiles/r06_shared_rot_ab.jsonl (first cut: r06_shared_rot_cut1.jsonl), NOTES 6.2.
+    python tools/bench_rot_modes.py [--model qwen3-4b] [--rows 1,2,4,8,16] [--modes=-1,0,1,3]"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3-4b")
     ap.add_argument("--rows", default="1,2,4,8,16")
-    ap.add_argument("--modes", default="-1,0,1")
+    ap.add_argument("--modes", default="-1,0,1,3")
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--knobs", default="0,0,0", help="tiles_per_wave,ksplit,waves (0 = auto)")
