@@ -189,8 +189,12 @@ int paro_workspace_status(const void* workspace, void* stream);
 /* Decode / small-batch path (rows <= 64; above 16 rows always with the rotate pre-pass): one launch; x is rotated per
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in {1, 2, 4, 8};
- * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = fused rotation, 1 = rotate pre-pass kernel into
- * the workspace then the same GEMV on rotated x, -1 = auto (fused up to 8 rows -- 4 for merged projections -- pre-pass above),
+ * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = rotation replicated in every workgroup, 1 = rotate
+ * pre-pass kernel into the workspace then the same GEMV on rotated x, 3 (v17) = rotation SHARED inside the launch -- producer workgroups in
+ * front of the grid rotate every (partition, group, pair of rows) once and hand it to the column blocks as {two channels, launch tag}
+ * granules in the workspace; plain calls of 1..16 rows, bit-identical to mode 0, falls back to mode 0 when the grid cannot be resident at
+ * once -- -1 = auto (mode 0 up to 4 rows, mode 3 from 5 rows where it fits the chip, else mode 0 up to 8 rows / for small projections and
+ * the pre-pass above; PARO_SHARED_ROT_MIN_ROWS moves the threshold),
  * 2 (v10) = x IS ALREADY ROTATED by the caller: [n_parts][rows][K] in the activation type, partition p rotated with
  * partition p's pairs / theta / channel_scales (rotation::rotate, or the epilogue of whatever kernel produced x) -- the
  * same pre-rotated kernels as mode 1 without the pre-pass launch. */
