@@ -498,6 +498,48 @@ def prefill_table(dev, rows: int = 65536, launches: int = 5):
     return out
 
 
+def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_counts=(1, 2, 4, 8, 16), steps: int = 20, warmup: int = 3):
+    """Batched decode THROUGH THE BOUNDARY (what a vLLM decode batch reaches: `ParoQuantLinearMethod.apply` is M-agnostic, vllm/plugin.py:281-311),
+    driver-visible: the bench step of the headline workload's first `n_layers` layers at several row counts on the
+    per-call route -- same weight bytes at every row count, so `x_one_row` is what the extra rows cost.  mode = what the library picked for the
+    layer's qkv projection at that row count (0 rotation replicated per workgroup, 1 pre-pass, 3 shared inside the launch)."""
+    import ctypes
+    from paroquant_amd import _native as nat, ops as _ops
+    lib = nat.load()
+    out, base = [], None
+    for rows in row_counts:
+        st = DecodeStack(model, dev, n_layers=n_layers, seed=37, rows=rows, route="fused")
+        st.step(st.x)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        ss = torch.cuda.Stream(dev)
+        ss.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(ss):
+            st.step(st.x)
+        torch.cuda.current_stream(dev).wait_stream(ss)
+        with torch.cuda.graph(g):
+            st.step(st.x)
+        _, ev = time_steps(g.replay, steps, warmup, 1, dev)
+        ms = ev / steps
+        base = ms if base is None else base
+        pk0 = st._flat[0] if hasattr(st, "_flat") else (st.layers[0][0] if getattr(st, "layers", None) else None)
+        mode = None
+        try:
+            if pk0 is not None:
+                d = _ops.pk_desc(pk0, torch.float16)
+                kn = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
+                if lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(k) for k in kn]) == 0:
+                    mode = kn[3].value
+        except Exception:
+            mode = None
+        out.append({"rows": rows, "ms_per_step_measured": round(ms, 4), "x_one_row": round(ms / base, 3),
+                    "tokens_per_s_full_depth": round(rows * 1e3 / (ms * n_layers_of(model) / st.n_layers), 1), "qkv_rotation_mode": mode})
+        del st, g
+        torch.cuda.empty_cache()
+    return {"workload": f"{model}-PARO decode, per-call route", "layers_measured": n_layers, "layers_of_model": n_layers_of(model), "rows": out,
+            "note": "same weight bytes at every row count; x_one_row = step time / the one-row step of the same stack (round 5, full depth: 1.42 / 1.90 / 2.60 at 2 / 8 / 16 rows)"}
+
+
 def config_steps(dev, models=(("qwen3-0.6b", 0), ("qwen3.5-4b-class", 8)), steps: int = 20, warmup: int = 3):
     """BASELINE configs 1 and 2's decode legs in the same line: the bench step (per-call route, one HIP graph) of the
     other single-GPU configurations; `layers` = 0 builds the full depth, otherwise the first n layers (stated in the row; the per-layer time
@@ -1154,6 +1196,10 @@ def run(args, rank: int, local_rank: int, world: int):
                 ex["configs"] = config_steps(dev)
             except Exception as e:
                 ex["configs"] = {"error": f"{type(e).__name__}: {e}"}
+            try:       # batched decode through the boundary: step time at 1 / 2 / 4 / 8 / 16 rows, same weights
+                ex["batched_decode"] = batched_decode_steps(dev)
+            except Exception as e:
+                ex["batched_decode"] = {"error": f"{type(e).__name__}: {e}"}
             try:       # the launch shapes of the headline workload's layers, MEASURED (paroquant_amd/autotune.py), plus three shapes no sweep saw
                 from paroquant_amd import autotune as _at
                 rows_at = []
