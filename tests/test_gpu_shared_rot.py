@@ -63,6 +63,47 @@ def test_shared_rotation_group_size_64(dev, gs, rows):
     assert po.rel_err(_np(y3), ref) < TIGHT_F16
 
 
+@pytest.mark.parametrize("krot", [1, 3])
+@pytest.mark.parametrize("rows", [6, 16])
+def test_shared_rotation_short_schedules_and_bias(dev, krot, rows):
+    """Checkpoints with fewer than eight rotation stages (identity-padded schedules: the producers skip the padded stages like the
+    replicated form does) and a bias (added once, by whoever writes y: transformers/modules.py:69-70)."""
+    from paroquant_amd import ops
+    K, sizes = 1024, [768, 256]
+    L = po.make_layer(500 + krot + rows, K, sizes, krot=krot, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    x = _t(np.random.default_rng(krot * 100 + rows).standard_normal((rows, K)).astype(np.float16), dev)
+    y3 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 3, bias=pk.bias)      # (the tuning entry takes the bias explicitly)
+    y0 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0, bias=pk.bias)
+    assert torch.equal(y3, y0)
+    assert po.rel_err(_np(y3), _ideal(L, _np(x))) < TIGHT_F16
+    ya = pk.apply(x)                     # the automatic route at these row counts
+    assert torch.equal(ya, y0)
+
+
+def test_shared_rotation_wide_output_at_16_rows_runs_eight_tile_blocks(dev):
+    """9..16 rows on a wide merged projection: the automatic route is mode 3 on 8-tile column blocks (4-tile blocks would not be resident
+    at once; 16 rows x 8 tiles is built for this mode only) and returns the replicated rotation's bits (which runs 4-tile blocks: the
+    column tiling does not enter the K summation order)."""
+    from paroquant_amd import _native as nat, ops
+    lib = nat.load()
+    K, sizes = 2560, [9728, 9728]
+    L = po.make_layer(77, K, sizes)
+    pk = _packed(L, dev)
+    d = ops.pk_desc(pk, torch.float16)
+    out = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
+    nat.check(lib.paro_gemv_launch_shape(ctypes.byref(d), 16, *[ctypes.byref(o) for o in out]))
+    assert (out[0].value, out[3].value) == (8, 3)
+    x = _t(np.random.default_rng(4).standard_normal((16, K)).astype(np.float16), dev)
+    y = pk.apply(x)
+    assert torch.equal(y, ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0))
+    rng = np.random.default_rng(8)
+    cols = rng.choice(sum(sizes), size=96, replace=False)
+    ref = _ideal(L, _np(x))[:, cols] if K * sum(sizes) <= (1 << 26) else None
+    if ref is not None:
+        assert po.rel_err(_np(y)[:, cols], ref) < TIGHT_F16
+
+
 def test_shared_rotation_is_what_apply_reaches_from_five_rows(dev):
     """The automatic route of the boundary: `PackedParoWeights.apply` (= RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply) takes
     mode 3 from 5 rows on for the BASELINE decode shapes, the replicated rotation below, and matches the oracle either way."""
