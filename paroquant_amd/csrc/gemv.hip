@@ -1,6 +1,8 @@
 // Host side of the fused GEMV: validation, launch-shape heuristic, ABI entry point.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemv_impl.hpp"
 
 namespace paro {
@@ -46,6 +48,22 @@ inline int shared_rot_prod_wgs(int64_t units, int wv, int64_t consumers, int64_t
   if (room >= want) return (int)want;
   if (room >= 1 && room * 4 >= want) return (int)room;
   return -1;
+}
+// Mode 3's HYBRID form (every wave rotates its own first group under the first tiles' latency, the producers the rest): where it beat both
+// the replicated rotation and the pure form (profiles/r06_shared_rot_hybrid.jsonl) -- 3..4 rows on mid-width / wide outputs (Qwen3-4B qkv
+// 7.1 -> 6.2 us, gate_up 9.4 -> 8.6; Llama-3-8B 7.8 -> 7.3, 14.7 -> 12.9; narrow K-split outputs stall on the hand-over there: o +1.1), and
+// 5..8 rows on narrow deep-K outputs (Qwen3-4B down 10.4 -> 9.2).  PARO_SHR_SELF = 0 / 1 overrides (experiments).
+inline int shared_rot_self(const paro_linear_t* L, int64_t rows, int ksp, int wv) {
+  static const int env_self = getenv("PARO_SHR_SELF") ? atoi(getenv("PARO_SHR_SELF")) : -1;
+  if (rows > 8) return 0;
+  if (env_self >= 0) return env_self ? 1 : 0;
+  const int G = (int)(L->K / 128), gps = (G + ksp - 1) / ksp;
+  const int64_t tiles = L->N / 16;
+  if (gps - wv <= 0) return 0;                       // nobody has a second group: nothing to share
+  if (rows <= 1) return 0;                           // one row: the replicated rotation, no hand-over of any kind (Llama-3-8B gate_up alone would gain 2.5 %)
+  if (rows == 2) return tiles >= 1024 ? 1 : 0;       // wide outputs: Qwen3-4B gate_up 8.66 -> 8.26 us, Llama-3-8B 13.29 -> 12.74
+  if (rows <= 4) return tiles >= 320 ? 1 : 0;
+  return ((tiles < 320 && G >= 64) || (tiles >= 1024 && gps >= 3 * wv)) ? 1 : 0;   // deep narrow outputs; wide ones with >= 3 groups per wave (Llama-3-8B gate_up 14.8 -> 14.0)
 }
 constexpr int kSharedRotMinRows = 5;    // automatic mode 3 from this many rows on (profiles/r06_shared_rot_ab.jsonl: ahead from the 8-row instantiation on; 17 = never)
 
@@ -234,7 +252,7 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // rotated activations is flat in the rows (Qwen3-4B layer at 8 rows 26.3 us against 25.5 at one row, profiles/r06_prerot_rows.jsonl),
   // ALL of the batched-decode overhead is rotation.  PARO_SHARED_ROT_MIN_ROWS = first row count that takes it (plain calls; 17 = never).
   static const int shr_min = getenv("PARO_SHARED_ROT_MIN_ROWS") ? atoi(getenv("PARO_SHARED_ROT_MIN_ROWS")) : kSharedRotMinRows;
-  const bool want_shared = mode_auto && !deferred && L->krot <= 8 && rows <= 16 && rows >= shr_min;
+  const bool want_shared = mode_auto && !deferred && L->krot <= 8 && rows <= 16 && (rows >= shr_min || (rows >= 2 && shr_min <= 16));   // (2..4 rows: only as the hybrid, below)
   const int tpw_in = tpw;
   gemv_autotune(L, rows, tpw, ksp, wv, deferred);
   // 9..16 rows: 4 tiles per wave (the accumulators of 16 rows x 8 tiles do not fit beside a replicated rotation); mode 3 runs 8 tiles
@@ -257,7 +275,9 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
       for (int i = 0; i < L->n_parts; ++i) cbs += (L->part_cols[i] / 16 + t - 1) / t;
       return shared_rot_prod_wgs(units, wv, cbs * ksp, shared_rot_cap(rows, wv)) > 0;
     };
-    if (fits(tpw)) mode = 3;
+    if (rows < shr_min) {
+      if (shared_rot_self(L, rows, ksp, wv) == 1 && fits(tpw)) mode = 3;
+    } else if (fits(tpw)) mode = 3;
     else if (tpw_in == 0 && rows > 8 && tpw == 4 && L->N / 16 >= 1024 && wv <= 8 && fits(8)) { tpw = 8; mode = 3; }
   }
   return PARO_OK;
@@ -463,7 +483,13 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : (shared ? shr_bytes : 0);
   a.shared_rot = shared ? 1 : 0;
   a.xg = nullptr;
-  a.shr_units = L->n_parts * G * shared_rot_row_tasks(rows);                  // tasks: (partition, group, quad of rows)
+  a.shr_self = shared ? shared_rot_self(L, rows, a.ksplit, wv) : 0;
+  {
+    // producer tasks: (partition, group that is no wave's own first group, chunk of rows); the pure form: every group
+    const int gps_ = (G + a.ksplit - 1) / a.ksplit;
+    const int l_full = std::max(0, gps_ - a.shr_self * wv), l_last = std::max(0, (G - (a.ksplit - 1) * gps_) - a.shr_self * wv);
+    a.shr_units = L->n_parts * ((a.ksplit - 1) * l_full + l_last) * shared_rot_row_tasks(rows);
+  }
   a.shr_prod_wgs = 0;                                                         // producer workgroups in front of every grid row
   if (shared) {
     const int pw = shared_rot_prod_wgs(a.shr_units, wv, (int64_t)pt.cbs * a.ksplit, shared_rot_cap(rows, wv));

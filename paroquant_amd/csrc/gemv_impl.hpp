@@ -87,6 +87,7 @@ struct GemvArgs {
   int shr_units;                         // producer tasks: n_parts * G * ceil(rows / 4) (rows <= 4: one per (partition, group))
   int shr_prod_wgs;                      // producer workgroups in front of every grid row: ceil(shr_units / waves)
   int shr_bytes;                         // size of the granule buffer (buffer descriptor bound)
+  int shr_self;                          // 1: the hybrid form (FUSED | 64) -- every wave rotates its own first group, the producers the rest
   // all-reduce epilogue (FUSED instantiations, one row; allreduce.hip describes the buffers): the row-parallel partial
   // outputs of the world's ranks are exchanged as {fp32 partial, epoch} granules straight from the output threads
   unsigned char* ar_peer[kArMaxWorld];   // every rank's buffer as mapped in this process, BY VALUE: a pointer fetched from device
@@ -174,6 +175,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // no epoch word, no re-arm, a stale or foreign granule is never consumed.  Same values, same rounding as the replicated form (the
   // producer runs the same seed / stage / finish code): the outputs are bit-identical to mode 0.  Needs the whole grid resident (checked).
   constexpr bool SHR = (FUSED & 32) != 0;
+  // FUSED | 64 (with 32): HYBRID -- every wave rotates its FIRST group itself, exactly as the replicated form does (that rotation runs
+  // under the first tiles' HBM latency and costs nothing), and takes the rest from the producers, which by then have published: no
+  // hand-over on the critical path at all.  The producers rotate only the groups that are nobody's first (local index >= WAVES in their
+  // K-slice).
+  constexpr bool SELF1 = (FUSED & 64) != 0;
+  constexpr int SELF = SELF1 ? 1 : 0;
+  static_assert(!SELF1 || SHR, "the hybrid is a form of the shared rotation");
   static_assert(!SHR || ((FUSED & 31) == 0 && !PREROT && MB <= 16), "the shared rotation feeds the plain kernel");
   typedef Act<AT> A;
   typedef typename A::vec8 vec8;
@@ -309,9 +317,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       const int nq = (h.rows + PRR - 1) / PRR;
       unsigned short* xq = (unsigned short*)(lds + wave * (((PRR + 1) * kXhStride * 2 + 15) / 16 * 16));
       const float fscale = __builtin_ldexpf(1.0f, 49 - 14 * h.krot);
+      // tasks: (partition, group that is not a wave's own first group, chunk of PRR rows).  A K-slice of n groups has n - SELF * WAVES of them
+      const int l_full = max(0, h.gps - SELF * WAVES), l_last = max(0, (h.G - (h.ksplit - 1) * h.gps) - SELF * WAVES);
+      const int l_sum = (h.ksplit - 1) * l_full + l_last;
       for (int u = (int)blockIdx.x * WAVES + wave; u < a.shr_units; u += a.shr_prod_wgs * WAVES) {
-        const int pg = u / nq, r0 = (u - pg * nq) * PRR;
-        const int pu = pg / h.G, g = pg - pu * h.G;
+        const int v = u / nq, r0 = (u - v * nq) * PRR;
+        const int pu = v / l_sum, w_ = v - pu * l_sum;
+        const int sl = l_full > 0 ? min(w_ / l_full, h.ksplit - 1) : h.ksplit - 1;
+        const int g = sl * h.gps + SELF * WAVES + (w_ - sl * l_full);
+        const int pg = pu * h.G + g;
         GP<u32x4> rp = (GP<u32x4>)h.rot + (unsigned)(pg * 192 + lane);
         u32x4 rc[3];
 #pragma unroll
@@ -543,6 +557,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   PBuf pc_first;
   if (h.prio) __builtin_amdgcn_s_setprio(3);
   if constexpr (!SHR) load_p(pc_first, gf_first);
+  else if constexpr (SELF1) load_rot(pc_first, p, gf_first);
   __builtin_amdgcn_sched_barrier(0);
   if (h.prio) __builtin_amdgcn_s_setprio(0);
 
@@ -818,7 +833,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // 16-byte request for the whole wave (lane 0's granule of the first row pair) per round, then the real gather -- which is checked
   // in full below, so the probe is a heuristic, never a proof.  (A gather at kernel entry finds nothing, and 1500 waves re-polling
   // whole groups is L2 traffic in front of the producers' own loads: the first cut of this mode, 8 rows 14.9 us against 8.4.)
-  if constexpr (SHR) {
+  if constexpr (SHR && !SELF1) {
     const unsigned poff = (unsigned)((((p * h.G + gf_first) * shr_nrp) * 64) * 16);
     for (int spin = 0; spin < (1 << 15); ++spin) {
       const u32x4 pv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xg_rsrc, poff, 0, kAuxSc1));
@@ -874,14 +889,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // PFP: request the NEXT unit's coefficients before this unit's rotation; PFT: request the next
     // unit's tiles before this unit's tiles are consumed.  Coefficients are always requested before
     // the tiles of the same unit.
-    auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt) {
+    auto step = [&](auto pfp_tag, auto pft_tag, int gp, int gt, auto self_tag) {
       constexpr bool PFP = decltype(pfp_tag)::value;
       constexpr bool PFT = decltype(pft_tag)::value;
-      if constexpr (PFP) load_p(pn, gp);
+      constexpr bool ROT_SELF = decltype(self_tag)::value;     // SHR hybrid: this unit is the wave's own first group
+      if constexpr (PFP && !ROT_SELF) load_p(pn, gp);
       vec8 af[4 * RT];
       if constexpr (PREROT) {
 #pragma unroll
         for (int i = 0; i < 4 * RT; ++i) af[i] = __builtin_bit_cast(vec8, pc.xa[i]);
+      } else if constexpr (SHR && ROT_SELF) {
+        float sa[MB], sb[MB];
+        seed(pc, sa, sb);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < h.krot) stage(pc, t, sa, sb);
+        }
+        finish(pc, xh, sa, sb);
+        __builtin_amdgcn_wave_barrier();
+        frags_from_lds(xh, af);
+        // the next group's granules are requested only now (~1.5 .. 2 us after the launch: the producers are publishing), not at entry
+        if constexpr (PFP) load_p(pn, gp);
       } else if constexpr (SHR) {
         shr_validate(pc);
 #pragma unroll
@@ -954,11 +982,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     // until its first coefficient requests were out and dropped to 0 before its tile requests (h.prio).
     pc = pc_first;
     tc = tc_first;
-    for (int i = 0; i + 1 < my_count; ++i) {
-      const int gn = unit_group(i + 1);
-      step(yes, yes, gn, gn);
+    if constexpr (SELF1) {
+      if (my_count > 1) {
+        const int g1 = unit_group(1);
+        step(yes, yes, g1, g1, yes);
+        for (int i = 1; i + 1 < my_count; ++i) {
+          const int gn = unit_group(i + 1);
+          step(yes, yes, gn, gn, no);
+        }
+        step(no, no, 0, 0, no);
+      } else {
+        step(no, no, 0, 0, yes);
+      }
+    } else {
+      for (int i = 0; i + 1 < my_count; ++i) {
+        const int gn = unit_group(i + 1);
+        step(yes, yes, gn, gn, no);
+      }
+      step(no, no, 0, 0, no);   // the last unit: nothing left to request
     }
-    step(no, no, 0, 0);   // the last unit: nothing left to request
     if (!has_work) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
@@ -1299,19 +1341,23 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 }
 
 // shared rotation (FUSED = 32): plain kernel, 1..16 rows, power-of-two tiles per wave, group_size 128 and 64
-template <typename AT, int TPW, int MB>
+template <typename AT, int TPW, int MB, int F = 32>
 int launch_waves_shared(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
+  if constexpr (F == 32 && MB <= 8) {   // the hybrid (every wave rotates its own first group): up to 8 rows
+    if (a.shr_self == 1) return launch_waves_shared<AT, TPW, MB, 96>(a, waves, grid, st);
+  }
+  if (a.shr_self != (F == 96 ? 1 : 0)) return fail(PARO_ERR_UNSUPPORTED, "shared rotation: the hybrid form is built for 1..8 rows");
   if constexpr (tpw_is_pow2(TPW)) {     // (8 tiles x 16 rows exists here only: nothing of the rotation is live in a consumer's registers)
     if (a.qs == 2) {
-      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32, 2>, 512>(a, grid, st);
-      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32, 2>, 256>(a, grid, st);
+      if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, F, 2>, 512>(a, grid, st);
+      if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, F, 2>, 256>(a, grid, st);
       return fail(PARO_ERR_UNSUPPORTED, "group_size 64: the shared rotation is built for 4 or 8 waves per workgroup (got %d)", waves);
     }
     if constexpr (TPW < 8 && MB <= 4) {
-      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, 32>, 1024>(a, grid, st);
+      if (waves == 16) return launch_checked<gemv_kernel<AT, TPW, MB, 16, false, 1, F>, 1024>(a, grid, st);
     }
-    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, 32>, 512>(a, grid, st);
-    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, 32>, 256>(a, grid, st);
+    if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, F>, 512>(a, grid, st);
+    if (waves == 4) return launch_checked<gemv_kernel<AT, TPW, MB, 4, false, 1, F>, 256>(a, grid, st);
   }
   return fail(PARO_ERR_UNSUPPORTED, "shared rotation: not built for %d tiles per wave x %d waves x %d rows", TPW, waves, MB);
 }

@@ -104,9 +104,47 @@ def test_shared_rotation_wide_output_at_16_rows_runs_eight_tile_blocks(dev):
         assert po.rel_err(_np(y)[:, cols], ref) < TIGHT_F16
 
 
+def test_shared_rotation_hybrid_forced_in_a_child_process(dev):
+    """PARO_SHR_SELF=1 (read once per process) forces the hybrid form wherever mode 3 runs with at most 8 rows: a child process sweeps shapes
+    x rows x types, comparing explicit mode 3 with mode 0 bit for bit and the status word; PARO_SHR_SELF=0 forces the pure form the same way."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json
+sys.path.insert(0, ".")
+import numpy as np, torch
+from oracle import paro_oracle as po
+from tests.test_gpu_parity import _packed, _t, _np
+from paroquant_amd import ops
+dev = torch.device("cuda:0")
+bad = []
+n = 0
+for K, sizes in [(2560, [4096, 1024, 1024]), (2560, [2432, 2432]), (9728, [640]), (4096, [2560]), (1536, [512]), (256, [48, 16]), (1024, [272])]:
+    L = po.make_layer(K + 3, K, sizes)
+    pk = _packed(L, dev)
+    for rows in (1, 2, 3, 4, 5, 7, 8):
+        for dt in (torch.float16, torch.bfloat16):
+            x = _t(np.random.default_rng(K + rows).standard_normal((rows, K)).astype(np.float32), dev, dt)
+            y3 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 3)
+            y0 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0)
+            n += 1
+            if not torch.equal(y3, y0):
+                bad.append((K, sizes, rows, str(dt)))
+    ops.check_workspace(pk.workspace)
+print(json.dumps({"cases": n, "bad": bad}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for force in ("1", "0"):
+        env = dict(os.environ, PARO_SHR_SELF=force)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["cases"] == 98 and not res["bad"], (force, res["bad"][:5])
+
+
 def test_shared_rotation_is_what_apply_reaches_from_five_rows(dev):
     """The automatic route of the boundary: `PackedParoWeights.apply` (= RotateQuantizedLinear.forward / ParoQuantLinearMethod.apply) takes
-    mode 3 from 5 rows on for the BASELINE decode shapes, the replicated rotation below, and matches the oracle either way."""
+    mode 3 from 5 rows on for the BASELINE decode shapes (from 3 rows in its hybrid form on mid-width / wide outputs), the replicated
+    rotation below, and matches the oracle either way."""
     from paroquant_amd import _native as nat
     lib = nat.load()
     K, sizes = 2560, [4096, 1024, 1024]
@@ -114,7 +152,8 @@ def test_shared_rotation_is_what_apply_reaches_from_five_rows(dev):
     pk = _packed(L, dev)
     from paroquant_amd import ops
     d = ops.pk_desc(pk, torch.float16)
-    for rows, want in ((1, 0), (4, 0), (5, 3), (8, 3), (16, 3)):
+    # (3..4 rows: mode 3 in its HYBRID form on this mid-width merged projection -- 384 tiles, 20 groups on 16 waves: four groups are nobody's first)
+    for rows, want in ((1, 0), (2, 0), (4, 3), (5, 3), (8, 3), (16, 3)):
         out = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
         nat.check(lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(o) for o in out]))
         assert out[3].value == want, (rows, out[3].value)

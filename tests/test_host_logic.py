@@ -275,7 +275,10 @@ def test_round3_launch_shape_heuristics():
     assert shape(*l8["o_proj"], 8)[3] == 3 and shape(*l8["o_proj"], 16)[3] == 0            # 64 x 4 = 256: fits two per CU (<= 8 rows), not one (9..16: the fused form, narrow single partition)
     assert shape(*l8["down_proj"], 16)[3] == 1 and shape(*q4["down_proj"], 16)[3] == 3
     assert shape(*l8["qkv_proj"], 16)[3] == 3 and shape(*q4["qkv_proj"], 16)[3] == 3       # (Llama-3-8B: 96 x 2 + 64 producer workgroups looping over 96 tasks' worth of waves)
-    assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 3) and shape(*q4["qkv_proj"], 4) == (2, 1, 16, 0)
+    assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 3) and shape(*q4["qkv_proj"], 2) == (2, 1, 16, 0)
+    # 3..4 rows: mode 3 in its hybrid form where the output is mid-width / wide and some group is nobody's first (20 groups on 16 waves);
+    # narrow K-split outputs keep the replicated rotation there
+    assert shape(*q4["qkv_proj"], 4) == (2, 1, 16, 3) and shape(*q4["gate_up_proj"], 3)[3] == 3 and shape(*q4["o_proj"], 4)[3] == 0 and shape(*q4["down_proj"], 4)[3] == 0
     # wide outputs at 9..16 rows: 8-tile blocks for mode 3 (4-tile blocks do not fit the chip at once); past 16 rows the pre-pass
     assert shape(*q4["gate_up_proj"], 16) == (8, 1, 8, 3) and shape(*l8["gate_up_proj"], 16) == (8, 1, 8, 3) and shape(*q4["gate_up_proj"], 17)[3] == 1
     # chain family (profiles/r03_chain_shape_sweep_rows.jsonl): deep K 8 slices at <= 8 rows, 5 at <= 16; the others 5 / 4; four groups per
@@ -323,8 +326,8 @@ def test_gemv_launch_shape_heuristics():
     # above unless a workgroup rotates few groups for few columns; 17..64 rows always pre-pass
     # (round 6, later: from 5 rows on mode 3 -- the rotation shared inside the launch -- where the grid fits the chip at once)
     assert shape(*l8["o_proj"], 4)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 0 and shape(*l8["down_proj"], 9)[3] == 1     # (o_proj 9..16 rows: narrow, one partition: fused; down: no room for producers)
-    assert shape(*l8["qkv_proj"], 4)[3] == 0 and shape(*l8["qkv_proj"], 8)[3] == 3 and shape(*l8["qkv_proj"], 9)[3] == 3
-    assert shape(*l8["gate_up_proj"], 4)[3] == 0 and shape(*l8["gate_up_proj"], 8)[3] == 3 and shape(*l8["gate_up_proj"], 9)[3] == 3
+    assert shape(*l8["qkv_proj"], 2)[3] == 0 and shape(*l8["qkv_proj"], 8)[3] == 3 and shape(*l8["qkv_proj"], 9)[3] == 3
+    assert shape(*l8["gate_up_proj"], 1)[3] == 0 and shape(*l8["gate_up_proj"], 2)[3] == 3 and shape(*l8["gate_up_proj"], 4)[3] == 3 and shape(*l8["gate_up_proj"], 8)[3] == 3 and shape(*l8["gate_up_proj"], 9)[3] == 3   # (2 rows: wide outputs only, hybrid form)
     assert shape(*q4["qkv_proj"], 16)[3] == 3 and shape(*q4["gate_up_proj"], 8)[3] == 3 and shape(*q4["gate_up_proj"], 9)[3] == 3
     # the rules behind mode 3 (PARO_SHARED_ROT_MIN_ROWS=17 in the environment restores them): explicit modes are taken as given
     assert shape(*l8["gate_up_proj"], 8, mode=0)[3] == 0 and shape(*l8["gate_up_proj"], 8, mode=1)[3] == 1
@@ -635,7 +638,7 @@ def test_no_kernel_reads_the_dispatch_packet():
                 # bit 1: dispatch-packet pointer -- never.  bit 2: queue pointer -- only the shared-rotation instantiations of the GEMV
                 # (gemv_kernel<..., FUSED = 32, ...>): they take the queue's ADDRESS (two preloaded SGPRs, no memory access) into
                 # their launch tag so that two queues' equal dispatch ids never match (gemv_impl.hpp, FUSED | 32)
-                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi32ELi[12]EEE", name) is not None
+                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi(32|96)ELi[12]EEE", name) is not None
                 if props & 0b010 or (props & 0b100 and not shared_rot):
                     bad.append(name)
                 n_shared += int(shared_rot and bool(props & 0b100))
