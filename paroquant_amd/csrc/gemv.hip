@@ -55,12 +55,12 @@ inline int shared_rot_prod_wgs(int64_t units, int wv, int64_t consumers, int64_t
 // 5..8 rows on narrow deep-K outputs (Qwen3-4B down 10.4 -> 9.2).  PARO_SHR_SELF = 0 / 1 overrides (experiments).
 inline int shared_rot_self(const paro_linear_t* L, int64_t rows, int ksp, int wv) {
   static const int env_self = getenv("PARO_SHR_SELF") ? atoi(getenv("PARO_SHR_SELF")) : -1;
-  if (rows > 8) return 0;
+  if (rows > 8 || rows <= 1) return 0;               // (one row: the replicated rotation, or -- explicit mode 3 -- the pure form)
   if (env_self >= 0) return env_self ? 1 : 0;
   const int G = (int)(L->K / 128), gps = (G + ksp - 1) / ksp;
   const int64_t tiles = L->N / 16;
   if (gps - wv <= 0) return 0;                       // nobody has a second group: nothing to share
-  if (rows <= 1) return 0;                           // one row: the replicated rotation, no hand-over of any kind (Llama-3-8B gate_up alone would gain 2.5 %)
+  // (one row: no hand-over of any kind on the batch-1 path; Llama-3-8B gate_up alone would gain 2.5 % from the hybrid)
   if (rows == 2) return tiles >= 1024 ? 1 : 0;       // wide outputs: Qwen3-4B gate_up 8.66 -> 8.26 us, Llama-3-8B 13.29 -> 12.74
   if (rows <= 4) return tiles >= 320 ? 1 : 0;
   return ((tiles < 320 && G >= 64) || (tiles >= 1024 && gps >= 3 * wv)) ? 1 : 0;   // deep narrow outputs; wide ones with >= 3 groups per wave (Llama-3-8B gate_up 14.8 -> 14.0)

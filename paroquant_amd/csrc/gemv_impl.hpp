@@ -1343,10 +1343,10 @@ int launch_waves_pd(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
 // shared rotation (FUSED = 32): plain kernel, 1..16 rows, power-of-two tiles per wave, group_size 128 and 64
 template <typename AT, int TPW, int MB, int F = 32>
 int launch_waves_shared(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) {
-  if constexpr (F == 32 && MB <= 8) {   // the hybrid (every wave rotates its own first group): up to 8 rows
+  if constexpr (F == 32 && MB >= 2 && MB <= 8) {   // the hybrid (every wave rotates its own first group): 2..8 rows (one row never shares its rotation)
     if (a.shr_self == 1) return launch_waves_shared<AT, TPW, MB, 96>(a, waves, grid, st);
   }
-  if (a.shr_self != (F == 96 ? 1 : 0)) return fail(PARO_ERR_UNSUPPORTED, "shared rotation: the hybrid form is built for 1..8 rows");
+  if (a.shr_self != (F == 96 ? 1 : 0)) return fail(PARO_ERR_UNSUPPORTED, "shared rotation: the hybrid form is built for 2..8 rows");
   if constexpr (tpw_is_pow2(TPW)) {     // (8 tiles x 16 rows exists here only: nothing of the rotation is live in a consumer's registers)
     if (a.qs == 2) {
       if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, MB, 8, false, 1, F, 2>, 512>(a, grid, st);
