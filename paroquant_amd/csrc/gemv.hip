@@ -253,7 +253,7 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
   // ALL of the batched-decode overhead is rotation.  PARO_SHARED_ROT_MIN_ROWS = first row count that takes it (plain calls; 17 = never).
   static const int shr_min = getenv("PARO_SHARED_ROT_MIN_ROWS") ? atoi(getenv("PARO_SHARED_ROT_MIN_ROWS")) : kSharedRotMinRows;
   const bool want_shared = mode_auto && !deferred && L->krot <= 8 && rows <= 16 && (rows >= shr_min || (rows >= 2 && shr_min <= 16));   // (2..4 rows: only as the hybrid, below)
-  const int tpw_in = tpw;
+  const int tpw_in = tpw, ksp_in = ksp;
   gemv_autotune(L, rows, tpw, ksp, wv, deferred);
   // 9..16 rows: 4 tiles per wave (the accumulators of 16 rows x 8 tiles do not fit beside a replicated rotation); mode 3 runs 8 tiles
   // there (no rotation state in a consumer) when that is what brings the grid onto the chip at once -- wide outputs: gate_up
@@ -270,15 +270,24 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
     // mode 3 only where producers + column blocks x K-slices fit the chip at once (the launcher checks the real occupancy and falls
     // back to the replicated rotation): wide outputs at 9..16 rows run 8-tile blocks for it, or keep the pre-pass
     const int64_t units = (int64_t)L->n_parts * G * shared_rot_row_tasks(rows);
-    auto fits = [&](int t) {
+    auto fits_ks = [&](int t, int ks) {
       int64_t cbs = 0;
       for (int i = 0; i < L->n_parts; ++i) cbs += (L->part_cols[i] / 16 + t - 1) / t;
-      return shared_rot_prod_wgs(units, wv, cbs * ksp, shared_rot_cap(rows, wv)) > 0;
+      return shared_rot_prod_wgs(units, wv, cbs * ks, shared_rot_cap(rows, wv)) > 0;
     };
+    auto fits = [&](int t) { return fits_ks(t, ksp); };
     if (rows < shr_min) {
       if (shared_rot_self(L, rows, ksp, wv) == 1 && fits(tpw)) mode = 3;
     } else if (fits(tpw)) mode = 3;
     else if (tpw_in == 0 && rows > 8 && tpw == 4 && L->N / 16 >= 1024 && wv <= 8 && fits(8)) { tpw = 8; mode = 3; }
+    else if (ksp_in == 0 && rows > 8 && ksp >= 3 && fits_ks(tpw, ksp - 1)) {
+      // 9..16 rows, one workgroup per CU: a K-split whose slices fill the chip leaves no room for the producers -- one slice fewer does
+      // (Llama-3-8B o_proj 64 x 4 -> 64 x 3 + 32, down_proj + 64)
+      ksp -= 1;
+      const int gps2 = (G + ksp - 1) / ksp;
+      ksp = (G + gps2 - 1) / gps2;
+      mode = 3;
+    }
   }
   return PARO_OK;
 }

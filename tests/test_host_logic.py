@@ -272,8 +272,9 @@ def test_round3_launch_shape_heuristics():
         assert shape(*m["o_proj"], 2) == (4, 4, 4, 0) and shape(*m["o_proj"], 4) == (4, 4, 4, 0) and shape(*m["o_proj"], 8)[:3] == (4, 4, 8)
         assert shape(*m["o_proj"], 1)[:3] == (4, 4, 4)
     assert shape(*q4["o_proj"], 8)[3] == 3 and shape(*q4["o_proj"], 16)[3] == 3            # 40 blocks x 4 slices + producers: fits
-    assert shape(*l8["o_proj"], 8)[3] == 3 and shape(*l8["o_proj"], 16)[3] == 0            # 64 x 4 = 256: fits two per CU (<= 8 rows), not one (9..16: the fused form, narrow single partition)
-    assert shape(*l8["down_proj"], 16)[3] == 1 and shape(*q4["down_proj"], 16)[3] == 3
+    # 64 blocks x 4 slices = 256: fits two per CU (<= 8 rows); at 9..16 rows (one workgroup per CU) ONE K-SLICE FEWER makes room for the producers
+    assert shape(*l8["o_proj"], 8) == (4, 4, 8, 3) and shape(*l8["o_proj"], 16) == (4, 3, 8, 3)
+    assert shape(*l8["down_proj"], 16) == (4, 3, 8, 3) and shape(*q4["down_proj"], 16)[3] == 3
     assert shape(*l8["qkv_proj"], 16)[3] == 3 and shape(*q4["qkv_proj"], 16)[3] == 3       # (Llama-3-8B: 96 x 2 + 64 producer workgroups looping over 96 tasks' worth of waves)
     assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 3) and shape(*q4["qkv_proj"], 2) == (2, 1, 16, 0)
     # 3..4 rows: mode 3 in its hybrid form where the output is mid-width / wide and some group is nobody's first (20 groups on 16 waves);
@@ -325,7 +326,8 @@ def test_gemv_launch_shape_heuristics():
     # small batches: fused up to 8 rows (round 6: the wide merged projections too -- profiles/r06_rot_modes_sweep.jsonl), rotate pre-pass
     # above unless a workgroup rotates few groups for few columns; 17..64 rows always pre-pass
     # (round 6, later: from 5 rows on mode 3 -- the rotation shared inside the launch -- where the grid fits the chip at once)
-    assert shape(*l8["o_proj"], 4)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 0 and shape(*l8["down_proj"], 9)[3] == 1     # (o_proj 9..16 rows: narrow, one partition: fused; down: no room for producers)
+    assert shape(*l8["o_proj"], 4)[3] == 0 and shape(*l8["o_proj"], 16)[3] == 3 and shape(*l8["down_proj"], 9)[3] == 3     # (9..16 rows: one K-slice fewer makes room for the producers)
+    assert shape(*l8["o_proj"], 16, ksplit=4)[3] == 0 and shape(*l8["down_proj"], 9, ksplit=4)[3] == 1                        # (a caller's K-split is kept: no room -> the rules before)
     assert shape(*l8["qkv_proj"], 2)[3] == 0 and shape(*l8["qkv_proj"], 8)[3] == 3 and shape(*l8["qkv_proj"], 9)[3] == 3
     assert shape(*l8["gate_up_proj"], 1)[3] == 0 and shape(*l8["gate_up_proj"], 2)[3] == 3 and shape(*l8["gate_up_proj"], 4)[3] == 3 and shape(*l8["gate_up_proj"], 8)[3] == 3 and shape(*l8["gate_up_proj"], 9)[3] == 3   # (2 rows: wide outputs only, hybrid form)
     assert shape(*q4["qkv_proj"], 16)[3] == 3 and shape(*q4["gate_up_proj"], 8)[3] == 3 and shape(*q4["gate_up_proj"], 9)[3] == 3
@@ -691,7 +693,7 @@ def test_round4_launch_shape_heuristics():
     assert shape(*dense("llama3-70b", 8)["qkv_proj"]) == (2, 4, 8, 0)
     # the un-merged k_proj / v_proj of an HF module tree; o_proj keeps its one-row shape at 2..4 rows and stays fused to 16 rows
     assert shape(4096, [1024]) == (1, 4, 4, 0)
-    assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 4, 8, 0)
+    assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 3, 8, 3)      # (round 6: mode 3 at 16 rows, one K-slice fewer to make room for its producers)
 
 
 @_needs_experimental
