@@ -330,10 +330,18 @@ class DecodeStack:
         h = x
         tp = self.tp
         if tp == 1:
-            # every linear consumes the first K columns of its predecessor's output (attention / SiLU*mul stand-ins: views)
+            # every linear consumes the first K columns of its predecessor's output (attention / SiLU*mul stand-ins: views).  With more than one
+            # row that slice is a STRIDED view and torch copies it in front of every linear whose predecessor is wider or narrower than its K
+            # (72 copy launches per Qwen3-4B step, 0.21 ms -- no decoder has them: attention and SiLU*mul write contiguous tensors).  The
+            # stand-in there is the first rows x K ELEMENTS of the predecessor's output: the same data dependency, a contiguous view, no
+            # launch.  PARO_BENCH_STRIDED_STANDIN=1 restores the column slice (what rounds 3..5 timed at --rows > 1).
+            strided = self.rows > 1 and os.environ.get("PARO_BENCH_STRIDED_STANDIN", "0") == "1"
             for lay in self.layers:
                 for pk in lay:
-                    h = pk.apply(h[:, : pk.K])
+                    if self.rows == 1 or strided:
+                        h = pk.apply(h[:, : pk.K])
+                    else:
+                        h = pk.apply(h.reshape(-1)[: self.rows * pk.K].view(self.rows, pk.K))
             return h
         for qkv, o, gu, down in self.layers:
             a = qkv.apply(h)[:, : o.K]                      # attention stand-in: a view, no kernel
@@ -537,7 +545,11 @@ def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_c
         del st, g
         torch.cuda.empty_cache()
     return {"workload": f"{model}-PARO decode, per-call route", "layers_measured": n_layers, "layers_of_model": n_layers_of(model), "rows": out,
-            "note": "same weight bytes at every row count; x_one_row = step time / the one-row step of the same stack (round 5, full depth: 1.42 / 1.90 / 2.60 at 2 / 8 / 16 rows)"}
+            "note": "same weight bytes at every row count; x_one_row = step time / the one-row step of the same stack.  Protocol (round 6): between two linears the "
+                    "stand-in for attention / SiLU*mul is a CONTIGUOUS view of the predecessor's output; rounds 3..5 sliced columns, which at > 1 row is a strided view "
+                    "that torch copies in front of 72 of a Qwen3-4B step's 144 linears (0.21 ms of copy launches no decoder has; PARO_BENCH_STRIDED_STANDIN=1 restores it). "
+                    "Round 5 with the strided stand-in, full depth: 1.42 / 1.90 / 2.60 at 2 / 8 / 16 rows; this build the same way 1.30 / 1.60 / 1.87, "
+                    "contiguous 1.06 / 1.36 / 1.63 (mode 3 off: 1.06 / 1.52 / 2.31): profiles/r06_rows_boundary_v2.jsonl"}
 
 
 def config_steps(dev, models=(("qwen3-0.6b", 0), ("qwen3.5-4b-class", 8)), steps: int = 20, warmup: int = 3):
