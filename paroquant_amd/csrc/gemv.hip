@@ -42,7 +42,8 @@ constexpr int kSharedRotRows = kShrTaskRows;   // rows per producer task of mode
 inline int shared_rot_row_tasks(int64_t rows) { return rows <= kSharedRotRows ? 1 : (int)((rows + kSharedRotRows - 1) / kSharedRotRows); }
 // Producer workgroups of a mode-3 launch: one task per wave when the chip has room beside the consumers, up to four tasks per wave (run
 // one after the other: +0.3 .. 0.5 us on the hand-over) when it has not; -1 = the launch does not fit at all.
-inline int64_t shared_rot_cap(int64_t rows, int wv) { return 256 * (rows <= 8 ? 2 : 1) * (wv <= 4 ? 2 : 1); }   // resident at once: two 8-wave workgroups per CU up to 8 rows (113 VGPRs), one at 9..16 (145)
+// resident at once: two 8-wave workgroups per CU up to 8 rows (113 VGPRs) and at 9..16 rows on <= 2-tile blocks (119); one on 4- / 8-tile blocks there (145 / 190)
+inline int64_t shared_rot_cap(int64_t rows, int wv, int tpw) { return 256 * ((rows <= 8 || tpw <= 2) ? 2 : 1) * (wv <= 4 ? 2 : 1); }
 inline int shared_rot_prod_wgs(int64_t units, int wv, int64_t consumers, int64_t cap) {
   const int64_t want = (units + wv - 1) / wv, room = cap - consumers;
   if (room >= want) return (int)want;
@@ -273,10 +274,24 @@ int resolve_launch_shape(const paro_linear_t* L, int64_t rows, int& tpw, int& ks
     auto fits_ks = [&](int t, int ks) {
       int64_t cbs = 0;
       for (int i = 0; i < L->n_parts; ++i) cbs += (L->part_cols[i] / 16 + t - 1) / t;
-      return shared_rot_prod_wgs(units, wv, cbs * ks, shared_rot_cap(rows, wv)) > 0;
+      return shared_rot_prod_wgs(units, wv, cbs * ks, shared_rot_cap(rows, wv, t)) > 0;
     };
     auto fits = [&](int t) { return fits_ks(t, ksp); };
-    if (rows < shr_min) {
+    // 9..16 rows, launch shapes re-swept UNDER mode 3 (profiles/r06_sweep_mode3.jsonl): with the rotation no longer replicated per workgroup,
+    // thin column blocks win on outputs below 1024 tiles that are not deep-K -- more workgroups in flight, and the 2-tile build fits two per
+    // CU -- and a mid-width merged projection of < 32 groups needs no K-split at all (Qwen3-4B qkv 9.3 -> 8.0 us at 16 rows, o 8.2 -> 7.7;
+    // Llama-3-8B o 9.2 -> 8.8, qkv 11.1 -> 10.7; deep K keeps 4-tile blocks: Llama-3-8B down 16.0 against 18.2)
+    bool thin = false;
+    if (rows > 8 && rows >= shr_min && tpw_in == 0 && ksp_in == 0 && tpw == 4 && G < 64 && L->N / 16 < 1024) {
+      int ks2 = (L->n_parts > 1 && G < 32) ? 1 : ksp;
+      if (!fits_ks(2, ks2) && ks2 >= 3) ks2 -= 1;                      // (Llama-3-8B o_proj: 128 blocks x 4 slices do not fit, x 3 do)
+      if (fits_ks(2, ks2)) {
+        const int gps2 = (G + ks2 - 1) / ks2;
+        tpw = 2; ksp = (G + gps2 - 1) / gps2; mode = 3; thin = true;
+      }
+    }
+    if (thin) {
+    } else if (rows < shr_min) {
       if (shared_rot_self(L, rows, ksp, wv) == 1 && fits(tpw)) mode = 3;
     } else if (fits(tpw)) mode = 3;
     else if (tpw_in == 0 && rows > 8 && tpw == 4 && L->N / 16 >= 1024 && wv <= 8 && fits(8)) { tpw = 8; mode = 3; }
@@ -501,7 +516,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   }
   a.shr_prod_wgs = 0;                                                         // producer workgroups in front of every grid row
   if (shared) {
-    const int pw = shared_rot_prod_wgs(a.shr_units, wv, (int64_t)pt.cbs * a.ksplit, shared_rot_cap(rows, wv));
+    const int pw = shared_rot_prod_wgs(a.shr_units, wv, (int64_t)pt.cbs * a.ksplit, shared_rot_cap(rows, wv, tpw));
     a.shr_prod_wgs = pw > 0 ? pw : (a.shr_units + wv - 1) / wv;               // (explicit mode 3 on a grid that may not fit: the launcher decides)
   }
   a.shr_bytes = (int)shr_bytes;

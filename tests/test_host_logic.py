@@ -273,8 +273,11 @@ def test_round3_launch_shape_heuristics():
         assert shape(*m["o_proj"], 1)[:3] == (4, 4, 4)
     assert shape(*q4["o_proj"], 8)[3] == 3 and shape(*q4["o_proj"], 16)[3] == 3            # 40 blocks x 4 slices + producers: fits
     # 64 blocks x 4 slices = 256: fits two per CU (<= 8 rows); at 9..16 rows (one workgroup per CU) ONE K-SLICE FEWER makes room for the producers
-    assert shape(*l8["o_proj"], 8) == (4, 4, 8, 3) and shape(*l8["o_proj"], 16) == (4, 3, 8, 3)
-    assert shape(*l8["down_proj"], 16) == (4, 3, 8, 3) and shape(*q4["down_proj"], 16)[3] == 3
+    # ... and outputs below 1024 tiles that are not deep-K run THIN (2-tile) blocks there: the rotation is no longer replicated per workgroup
+    # and the 2-tile build fits two per CU (profiles/r06_sweep_mode3.jsonl); deep K keeps 4-tile blocks
+    assert shape(*l8["o_proj"], 8) == (4, 4, 8, 3) and shape(*l8["o_proj"], 16) == (2, 3, 8, 3) and shape(*q4["o_proj"], 16) == (2, 4, 8, 3)
+    assert shape(*q4["qkv_proj"], 16) == (2, 1, 8, 3) and shape(*l8["qkv_proj"], 16) == (2, 2, 8, 3)
+    assert shape(*l8["down_proj"], 16) == (4, 3, 8, 3) and shape(*q4["down_proj"], 16) == (4, 4, 8, 3)
     assert shape(*l8["qkv_proj"], 16)[3] == 3 and shape(*q4["qkv_proj"], 16)[3] == 3       # (Llama-3-8B: 96 x 2 + 64 producer workgroups looping over 96 tasks' worth of waves)
     assert shape(*q4["qkv_proj"], 8) == (4, 2, 8, 3) and shape(*q4["qkv_proj"], 2) == (2, 1, 16, 0)
     # 3..4 rows: mode 3 in its hybrid form where the output is mid-width / wide and some group is nobody's first (20 groups on 16 waves);
@@ -693,7 +696,7 @@ def test_round4_launch_shape_heuristics():
     assert shape(*dense("llama3-70b", 8)["qkv_proj"]) == (2, 4, 8, 0)
     # the un-merged k_proj / v_proj of an HF module tree; o_proj keeps its one-row shape at 2..4 rows and stays fused to 16 rows
     assert shape(4096, [1024]) == (1, 4, 4, 0)
-    assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (4, 3, 8, 3)      # (round 6: mode 3 at 16 rows, one K-slice fewer to make room for its producers)
+    assert shape(4096, [2560], 2) == (4, 4, 4, 0) and shape(4096, [4096], 16) == (2, 3, 8, 3)      # (round 6: mode 3 at 16 rows on thin blocks, one K-slice fewer to make room for its producers)
 
 
 @_needs_experimental

@@ -16,6 +16,15 @@ from paroquant_amd import ops
 
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev); gen.manual_seed(17)
+def auto_shape(pk, rows):
+    import ctypes
+    from paroquant_amd import _native as nat
+    d = ops.pk_desc(pk, torch.float16)
+    kn = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
+    nat.check(nat.load().paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(k) for k in kn]))
+    return kn[0].value, kn[1].value, kn[2].value
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "--load":
     res = []
     # a competing stream that keeps most CUs busy with matmuls of uneven length
@@ -28,7 +37,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--load":
         bad = nan = 0
         for it in range(300):
             x = torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen)
-            ref = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0)
+            ref = ops.w4a16_gemv_tuned(x, pk, *auto_shape(pk, rows), 0)
             torch.cuda.synchronize()
             with torch.cuda.stream(s2):
                 for _ in range(1 + it % 3):
@@ -48,17 +57,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "--load":
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cases = [(2560, [4096, 1024, 1024], 8), (4096, [2560], 5), (2560, [9728, 9728], 16), (9728, [2560], 12), (4096, [14336, 14336], 8),
          (14336, [4096], 8), (4096, [4096, 1024, 1024], 16), (1024, [2048, 1024, 1024], 16), (1536, [528], 7)]
+
+
 out = []
 t0 = time.time()
 for K, sizes, rows in cases:
     pk = bench.synth_packed(K, sizes, dev, gen)
     x = torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen)
     bad = 0
-    ref = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0).clone()
+    shape = auto_shape(pk, rows)          # mode 3 may run another launch shape than mode 0's rule tree: compare at ITS shape (same K-split = same bits)
+    ref = ops.w4a16_gemv_tuned(x, pk, *shape, 0).clone()
     for it in range(N):
         if it % 25 == 24:
             x = torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen)
-            ref = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 0).clone()
+            ref = ops.w4a16_gemv_tuned(x, pk, *shape, 0).clone()
         y = pk.apply(x)                                   # the boundary's automatic route: mode 3 from 5 rows
         if not torch.equal(y, ref):
             bad += 1
@@ -75,7 +87,7 @@ for K, sizes, rows in cases:
     for rep in range(max(1, N // 50)):
         xs.copy_(torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen))
         g.replay(); torch.cuda.synchronize()
-        r = ops.w4a16_gemv_tuned(xs, pk, 0, 0, 0, 0)
+        r = ops.w4a16_gemv_tuned(xs, pk, *shape, 0)
         gbad += sum(0 if torch.equal(y, r) else 1 for y in ys)
     try:
         ops.check_workspace(pk.workspace); status = "clean"
