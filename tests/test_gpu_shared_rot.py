@@ -115,12 +115,15 @@ import numpy as np, torch
 from oracle import paro_oracle as po
 from tests.test_gpu_parity import _packed, _t, _np
 from paroquant_amd import ops
+from paroquant_amd.linear import PackedParoWeights
 dev = torch.device("cuda:0")
 bad = []
 n = 0
 for K, sizes in [(2560, [4096, 1024, 1024]), (2560, [2432, 2432]), (9728, [640]), (4096, [2560]), (1536, [512]), (256, [48, 16]), (1024, [272])]:
-    L = po.make_layer(K + 3, K, sizes)
-    pk = _packed(L, dev)
+    gs = 64 if K == 1024 else 128           # (one group_size-64 layer: two quantisation groups per rotation span)
+    L = po.make_layer(K + 3, K, sizes, group_size=gs)
+    pk = _packed(L, dev) if gs == 128 else PackedParoWeights(_t(L["qweight"], dev), _t(L["qzeros"], dev), _t(L["scales"], dev), _t(L["theta"], dev),
+                                                             _t(L["pairs"], dev), _t(L["channel_scales"], dev), sizes, None, gs)
     for rows in (1, 2, 3, 4, 5, 7, 8):
         for dt in (torch.float16, torch.bfloat16):
             x = _t(np.random.default_rng(K + rows).standard_normal((rows, K)).astype(np.float32), dev, dt)
