@@ -849,7 +849,7 @@ def parse_args(argv=None):
                          "default: qwen3-4b at --gpus 1, llama3-70b-tp above")
     ap.add_argument("--model-config", default="", help="HF config.json to register as a workload (use with --workload <dir name>)")
     ap.add_argument("--layers", type=int, default=0, help="decoder layers to instantiate (0 = all)")
-    ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16)")
+    ap.add_argument("--rows", type=int, default=1, help="sequences decoded per step (batched decode; 1..16, with --route fused 1..512)")
     ap.add_argument("--route", default="auto", choices=["auto", "fused", "parts", "chain", "engine", "engine2"],
                     help="fused = rotation inside every consuming GEMV; chain = activations handed over rotated by the producing "
                          "launch (decode-chain family); parts = fused with the deferred K-split reduction of o / down (one row, one GPU); "
@@ -914,8 +914,8 @@ def run(args, rank: int, local_rank: int, world: int):
     model = workload[:-3] if tp_mode else workload
     if model not in MODELS and model not in HYBRID:
         raise SystemExit(f"unknown workload {workload!r}; known models: {known_models()} (the dense ones also as <model>-tp)")
-    if not 1 <= args.rows <= 16:
-        raise SystemExit("--rows must be in 1..16")
+    if not 1 <= args.rows <= (512 if args.route == "fused" else 16):
+        raise SystemExit("--rows must be in 1..16 (--route fused, the per-call route: 1..512)")
     tp = world if tp_mode else 1
 
     if args.dry_run:
