@@ -33,7 +33,45 @@ the reference root).
 """
 from __future__ import annotations
 
+import hashlib
+import os
+from collections import OrderedDict
+
 import numpy as np
+
+# ---------------------------------------------------------------------------
+# Memo of the two expensive pure functions of the test suite (dequantising a whole weight matrix, generating a synthetic layer): the
+# parity tests call both again and again with the same arguments (one layer, several row counts / launch shapes / repetitions).  Keyed
+# by CONTENT (a digest of the packed arrays) resp. by the argument tuple; bounded (PARO_ORACLE_CACHE_MB, default 1536; 0 disables);
+# cached arrays are read-only.  Results are exactly what the uncached functions return.
+# ---------------------------------------------------------------------------
+_CACHE_BUDGET = int(os.environ.get("PARO_ORACLE_CACHE_MB", "1536")) << 20
+_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()      # key -> (value, bytes)
+_cache_bytes = 0
+
+
+def _digest(a) -> tuple:
+    a = np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=16).digest())
+
+
+def _cache_get(key):
+    hit = _CACHE.get(key)
+    if hit is not None:
+        _CACHE.move_to_end(key)
+        return hit[0]
+    return None
+
+
+def _cache_put(key, value, nbytes: int):
+    global _cache_bytes
+    if nbytes > _CACHE_BUDGET // 2:
+        return
+    _CACHE[key] = (value, nbytes)
+    _cache_bytes += nbytes
+    while _cache_bytes > _CACHE_BUDGET:
+        _, (_, b) = _CACHE.popitem(last=False)
+        _cache_bytes -= b
 
 # ---------------------------------------------------------------------------
 # AWQ packing (paroquant/cli/convert.py:19,149-155; inverse at
@@ -77,6 +115,12 @@ def dequant_awq(qweight, qzeros, scales, group_size: int = 128, out_dtype=np.flo
     The subtraction is exact in integers; the product is rounded once to
     ``out_dtype`` (fp16 = what an fp16 ``(q - z) * s`` dequant kernel produces).
     """
+    key = None
+    if _CACHE_BUDGET:
+        key = ("deq", _digest(qweight), _digest(qzeros), _digest(scales), int(group_size), np.dtype(out_dtype).str)
+        hit = _cache_get(key)
+        if hit is not None:
+            return hit
     q = unpack_awq(qweight).astype(np.float32)          # [K, N]
     z = unpack_awq(qzeros).astype(np.float32)           # [K/gs, N]
     s = np.asarray(scales).astype(np.float32)           # [K/gs, N]
@@ -84,8 +128,11 @@ def dequant_awq(qweight, qzeros, scales, group_size: int = 128, out_dtype=np.flo
     assert K % group_size == 0 and z.shape[0] == K // group_size == s.shape[0]
     zf = np.repeat(z, group_size, axis=0)
     sf = np.repeat(s, group_size, axis=0)
-    w = (q - zf) * sf
-    return w.astype(out_dtype)
+    w = ((q - zf) * sf).astype(out_dtype)
+    if key is not None:
+        w.flags.writeable = False
+        _cache_put(key, w, w.nbytes)
+    return w
 
 
 # ---------------------------------------------------------------------------
@@ -359,8 +406,17 @@ def paro_linear(x, qweight, qzeros, scales, theta, pairs, channel_scales, bias=N
         return y.reshape(*x.shape[:-1], w.shape[1])
     mode = rotate_mode or act
     xr = rotate(x, pairs, theta, channel_scales, 128, mode=mode)   # group_size NOT forwarded: modules.py:60
-    w = dequant_awq(qweight, qzeros, scales, group_size, out_dtype=np.float32)
-    w = round_to(w, act).astype(np.float64)
+    key = None
+    w = None
+    if _CACHE_BUDGET:
+        key = ("deq-rounded", _digest(qweight), _digest(qzeros), _digest(scales), int(group_size), act)
+        w = _cache_get(key)
+    if w is None:
+        w = dequant_awq(qweight, qzeros, scales, group_size, out_dtype=np.float32)
+        w = round_to(w, act).astype(np.float64)
+        if key is not None:
+            w.flags.writeable = False
+            _cache_put(key, w, w.nbytes)
     y = xr.reshape(-1, K).astype(np.float64) @ w
     if bias is not None:
         y = y + round_to(np.asarray(bias, dtype=np.float32), act).astype(np.float64)[None, :]
@@ -427,8 +483,13 @@ def make_layer(seed: int, K: int, sizes, krot: int = 8, group_size: int = 128, b
     scales ``f16[K/gs, N]`` and per-partition theta ``f16[P, krot, K/2]``, pairs
     ``int16[P, krot, K]``, channel_scales ``f16[P, 1, K]``.
     """
-    rng = np.random.default_rng(seed)
     sizes = list(sizes)
+    key = ("layer", int(seed), int(K), tuple(int(v) for v in sizes), int(krot), int(group_size), bool(bias))
+    if _CACHE_BUDGET:
+        hit = _cache_get(key)
+        if hit is not None:
+            return dict(hit, sizes=list(sizes))      # a fresh dict over the same (never modified in place) arrays
+    rng = np.random.default_rng(seed)
     N = int(sum(sizes))
     G = K // group_size
     q = rng.integers(0, 16, size=(K, N), dtype=np.int64)
@@ -442,6 +503,8 @@ def make_layer(seed: int, K: int, sizes, krot: int = 8, group_size: int = 128, b
                channel_scales=cs, sizes=sizes, K=K, N=N)
     if bias:
         out["bias"] = (rng.standard_normal(N) * 0.1).astype(np.float16)
+    if _CACHE_BUDGET:
+        _cache_put(key, dict(out), sum(v.nbytes for v in out.values() if isinstance(v, np.ndarray)))
     return out
 
 
