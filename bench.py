@@ -798,8 +798,10 @@ def end_to_end(model: str, dev, prompt: int = 128, new: int = 128, runs: int = 5
             "ttft_ms": round(float(np.median([s_["ttft_s"] for s_ in stats])) * 1e3, 2),
             "protocol": f"{warmup} warm-up + {runs} runs, prompt {prompt}, {new} new tokens, greedy, HIP graph per token",
             "launches_per_token": (sum(5 if L.full else 6 for L in lm.layers) + 3) if hybrid else
-                                  ((5 if tp_world == 1 or lm.fused_allreduce else 7) * lm.cfg.n_layers + 3 + (1 if lm.deferred else 0)),
+                                  (((5 if tp_world == 1 or lm.fused_allreduce else 7) - (1 if getattr(lm, "fuse_qkv_attn", False) else 0)) * lm.cfg.n_layers
+                                   + 3 + (1 if lm.deferred else 0)),
             "deferred_ksplit_reduction": bool(lm.deferred),   # o / down leave partial sums, gate_up / the next qkv complete them (decoder.py)
+            "attention_in_qkv_launch": bool(getattr(lm, "fuse_qkv_attn", False)),   # ABI v18 attn_tail: 4 launches per layer
             "parallelism": f"tp{tp_world}" + (" (bytes_per_token and GBps are per rank)" if tp_world > 1 else ""),
             "bytes_per_token": int(lm.bytes_per_token + lm_head_bytes),
             "GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 17
+#define PARO_ABI_VERSION 18
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -249,6 +249,30 @@ int paro_w4a16_gemv(const paro_linear_t* L, const void* x, void* y, int64_t rows
 #define PARO_PROLOGUE_SILU_MUL 2
 #define PARO_PROLOGUE_GELU_TANH_MUL 3   /* v11: x_k = gelu_tanh(gate_k) * up_k -- the Gemma families' MLP activation (the reference lists
                                            gemma-4 checkpoints, README.md:89-93); same input layout as SILU_MUL */
+/* v18 -- ATTENTION TAIL of the qkv projection (decode harness): the batch-1 decode attention that consumes this
+ * projection's q / k / v (paro_attn_decode_split on partial sums) runs in the SAME launch.  The grid gets one more row, dispatched behind
+ * every projection workgroup, whose workgroups are the attention's (KV head, 64 / 128-position chunk): they request their K / V cache
+ * lines at once (nothing of that depends on this token) while the projection streams its weights, then poll q / k / v, which the
+ * projection's K-slices leave as 8-byte {fp32 partial sum, launch tag} granules (write-through; tag = the hardware dispatch id of the
+ * launch, as in GEMV mode 3) -- one in-launch hand-over instead of a launch boundary plus the attention's cold start.  Same arithmetic,
+ * same bits as paro_w4a16_gemv_fused(parts_out) followed by paro_attn_decode_split(qkv_parts).
+ * Needs: one row, PARO_PROLOGUE_RMSNORM, parts_out (whose buffer is then [(N + 1)][PARO_MAX_PARTIALS] 8-BYTE granules, i.e. twice the
+ * floats, 16-byte aligned, and is NOT readable as plain partial sums afterwards), N == (n_heads + 2 n_kv_heads) * head_dim, head_dim
+ * 128, at most 4 query heads per KV head, group_size 128, a launch shape of 4 or 8 waves that K-splits (paro_attn_tail_supported;
+ * otherwise PARO_ERR_UNSUPPORTED: use the two launches).  The remaining fields are paro_attn_decode_split's arguments of the same names. */
+typedef struct paro_attn_tail {
+  void* kcache;
+  void* vcache;
+  float* attn_parts;
+  const int32_t* pos;
+  const float* rope;
+  const void* q_norm_w;
+  const void* k_norm_w;
+  float eps, scale;
+  int32_t n_heads, n_kv_heads, head_dim, max_positions;
+  void* workspace;
+  int64_t workspace_bytes;
+} paro_attn_tail_t;
 typedef struct paro_fusion {
   int32_t prologue;
   float eps;             /* RMSNorm epsilon */
@@ -271,8 +295,12 @@ typedef struct paro_fusion {
                                   completes out = sum_c 2^(m_c - M) o_c / sum_c 2^(m_c - M) l_c per element while it seeds its rotation --
                                   the same bits as paro_attn_finish followed by the plain launch.  One row, no prologue, no residual;
                                   parts_out allowed (o_proj of a decoder layer: attention slots in, K-split partial sums out). */
+  const paro_attn_tail_t* attn_tail;   /* v18: run the consuming decode attention in this launch (above), or NULL */
 } paro_fusion_t;
 int paro_gemv_parts_count(const paro_linear_t* L);
+/* v18: 1 when paro_fusion_t.attn_tail can run this qkv projection with its decode attention in one launch (the conditions above), 0 when
+ * the two launches are the route, < 0 on a bad descriptor. */
+int paro_attn_tail_supported(const paro_linear_t* L, int n_heads, int n_kv_heads, int head_dim, int max_positions);
 int paro_parts_finish(const void* x, const float* parts, int64_t K, void* out, int act_dtype, void* stream);
 int paro_w4a16_gemv_fused(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                           int64_t workspace_bytes, const paro_fusion_t* fusion, void* stream);

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 17
+PARO_ABI_VERSION = 18
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -58,6 +58,7 @@ EXPORTS = (
     "paro_w4a16_gemv_chain",
     "paro_rotate_parts",
     "paro_gemv_parts_count",
+    "paro_attn_tail_supported",
     "paro_parts_finish",
     "paro_allreduce_buffer_bytes",
     "paro_allreduce_buffer_create",
@@ -115,13 +116,22 @@ class ParoLinearDesc(Structure):
     ]
 
 
+class ParoAttnTail(Structure):
+    """``paro_attn_tail_t`` (include/paro_abi.h, v18)."""
+
+    _fields_ = [("kcache", c_void_p), ("vcache", c_void_p), ("attn_parts", c_void_p), ("pos", c_void_p), ("rope", c_void_p),
+                ("q_norm_w", c_void_p), ("k_norm_w", c_void_p), ("eps", ctypes.c_float), ("scale", ctypes.c_float),
+                ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32), ("max_positions", c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+
+
 class ParoFusion(Structure):
     """``paro_fusion_t`` (include/paro_abi.h)."""
 
     _fields_ = [("prologue", c_int32), ("eps", ctypes.c_float), ("x_stride", c_int64), ("residual", c_void_p),
                 ("ar_peers", c_void_p), ("ar_own", c_void_p), ("ar_state", c_void_p), ("ar_world", c_int32), ("ar_rank", c_int32), ("ar_max_elems", c_int64),
                 ("parts_out", c_void_p), ("parts_in", c_void_p), ("x_out", c_void_p), ("parts_out_n", c_int32), ("attn_head_dim", c_int32),
-                ("attn_in", c_void_p)]
+                ("attn_in", c_void_p), ("attn_tail", POINTER(ParoAttnTail))]
 
 
 class ParoExperts(Structure):
@@ -253,6 +263,8 @@ def load() -> ctypes.CDLL:
     lib.paro_rotate_parts.argtypes = [POINTER(ParoLinearDesc), c_void_p, c_void_p, c_int64, c_void_p]
     lib.paro_gemv_parts_count.restype = c_int
     lib.paro_gemv_parts_count.argtypes = [POINTER(ParoLinearDesc)]
+    lib.paro_attn_tail_supported.restype = c_int
+    lib.paro_attn_tail_supported.argtypes = [POINTER(ParoLinearDesc), c_int, c_int, c_int, c_int]
     lib.paro_parts_finish.restype = c_int
     lib.paro_parts_finish.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]
     lib.paro_allreduce_buffer_bytes.restype = c_int64

@@ -356,7 +356,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if ((!x && !ain) || (!y && !pout)) return fail(PARO_ERR_INVALID, "null pointer");
   const bool ar = F && F->ar_peers && F->ar_world >= 1;
   const bool fused = (F && (F->prologue != PARO_PROLOGUE_NONE || F->residual)) || E || ar || pin || ain;
-  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr};
+  static const paro_fusion_t no_fusion = {PARO_PROLOGUE_NONE, 0.f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   int attn_shift = 0;
   if (ain) {
     if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "attn_in is a batch-1 decode path (got %lld rows)", (long long)rows);
@@ -366,6 +366,22 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     attn_shift = F->attn_head_dim == 64 ? 6 : (F->attn_head_dim == 128 ? 7 : (F->attn_head_dim == 256 ? 8 : 0));
     if (!attn_shift || L->K % F->attn_head_dim != 0) return fail(PARO_ERR_INVALID, "attn_head_dim must be 64, 128 or 256 and divide K (got %d, K = %lld)", F->attn_head_dim, (long long)L->K);
     if (((uintptr_t)F->attn_in & 15) != 0) return fail(PARO_ERR_INVALID, "attn_in must be 16-byte aligned");
+  }
+  const paro_attn_tail_t* T = F ? F->attn_tail : nullptr;   // v18: the consuming decode attention runs in this launch
+  if (T) {
+    if (rows != 1 || !pout || F->prologue != PARO_PROLOGUE_RMSNORM || E || ar || ain)
+      return fail(PARO_ERR_UNSUPPORTED, "attn_tail rides the one-row RMSNorm-prologue projection that leaves partial sums (no expert slots, all-reduce, attn_in)");
+    if (!T->kcache || !T->vcache || !T->attn_parts || !T->pos || !T->rope || !T->workspace) return fail(PARO_ERR_INVALID, "attn_tail: null pointer");
+    if (T->head_dim != 128) return fail(PARO_ERR_UNSUPPORTED, "attn_tail: head_dim must be 128 (got %d)", T->head_dim);
+    if (T->n_heads < 1 || T->n_kv_heads < 1 || T->n_kv_heads > 64 || T->n_heads % T->n_kv_heads != 0 || T->n_heads / T->n_kv_heads > 4)
+      return fail(PARO_ERR_UNSUPPORTED, "attn_tail: n_heads must be 1..4 x n_kv_heads (got %d / %d)", T->n_heads, T->n_kv_heads);
+    if ((int64_t)(T->n_heads + 2 * T->n_kv_heads) * T->head_dim != L->N) return fail(PARO_ERR_INVALID, "attn_tail: N = %lld is not (n_heads + 2 n_kv_heads) * head_dim", (long long)L->N);
+    if ((T->q_norm_w == nullptr) != (T->k_norm_w == nullptr)) return fail(PARO_ERR_INVALID, "attn_tail: q / k norm weights come together");
+    if (T->max_positions < 8 || T->max_positions % 8 != 0) return fail(PARO_ERR_INVALID, "attn_tail: max_positions must be a multiple of 8 (got %d)", T->max_positions);
+    if (T->workspace_bytes < paro_attn_decode_workspace_bytes(T->n_heads, T->n_kv_heads, T->head_dim, T->max_positions))
+      return fail(PARO_ERR_INVALID, "attn_tail: attention workspace too small");
+    if (quant_group(L->group_size) != 128) return fail(PARO_ERR_UNSUPPORTED, "attn_tail: group_size 128 only");
+    if (((uintptr_t)F->parts_out & 15) != 0) return fail(PARO_ERR_INVALID, "attn_tail: parts_out must be 16-byte aligned");
   }
   if (pout || pin) {
     if (rows != 1) return fail(PARO_ERR_UNSUPPORTED, "partial sums (parts_out / parts_in) are a batch-1 decode path (got %lld rows)", (long long)rows);
@@ -489,6 +505,39 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   a.ar_rank = ar ? F->ar_rank : 0;
   a.ar_slot = ar ? ar_slot_b(F->ar_max_elems) : 0;
   a.ar_off = ar ? ar_region_b_off(F->ar_world, F->ar_max_elems) : 0;
+  a.attn_wgs = 0;
+  a.attn_cbs = 1;
+  if (T) {
+    // the attention row: (KV head, 64-position chunk) workgroups -- the split launch's grid (attn.hip), flattened
+    AttnArgs& t = a.attn;
+    t.qkv = nullptr;
+    t.qkv_parts = (const f32x4*)F->parts_out;       // (as granules: attn_impl.hpp, TAGGED)
+    t.norm_dim = (float)L->K;
+    t.norm_eps = F->eps;
+    t.kcache = (unsigned short*)T->kcache;
+    t.vcache = (unsigned short*)T->vcache;
+    t.out = nullptr;
+    t.pos = T->pos;
+    t.rope = T->rope;
+    t.qnw = (const unsigned short*)T->q_norm_w;
+    t.knw = (const unsigned short*)T->k_norm_w;
+    t.part = (float*)((char*)T->workspace + kAttnWsHeader);
+    t.ticket = (unsigned*)T->workspace;
+    t.split_o = T->attn_parts;
+    t.split_ml = T->attn_parts + (int64_t)T->n_heads * T->head_dim * 4;
+    t.eps = T->eps;
+    t.scale = T->scale;
+    t.Hq = T->n_heads;
+    t.Hkv = T->n_kv_heads;
+    t.hd = T->head_dim;
+    t.T_max = T->max_positions;
+    t.chunks = (T->max_positions + 63) / 64;
+    t.dbg = 0;
+    a.attn_wgs = t.Hkv * t.chunks;
+    a.attn_cbs = (int)pt.cbs;
+    if ((a.attn_wgs + a.attn_cbs - 1) / a.attn_cbs + a.ksplit > 65535) return fail(PARO_ERR_UNSUPPORTED, "attn_tail: too many attention workgroups for the grid");
+    if (wv != 4 && wv != 8) return fail(PARO_ERR_UNSUPPORTED, "attn_tail: built for launch shapes of 4 or 8 waves (this one: %d)", wv);
+  }
   a.pd = (env_pd == 11 || env_pd == 21 || env_pd == 31 || env_pd == 41 || env_pd == 51 || env_pd == 61 || env_pd == 71 || env_pd == 81 || env_pd == 99) ? env_pd : 1;
   // K-split reducer: its first poll goes out a few hundred cycles after its own partial sums are staged -- a poll that lands before the
   // other slices' granules costs a whole extra round trip (profiles/r06_poll_delay_sweep.jsonl, us at 0 / 256 / 512 cycles: Qwen3-4B o
@@ -543,7 +592,7 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
     if (rc != PARO_OK) return rc;
     a.hot.x = xrot;
   }
-  dim3 grid((unsigned)(pt.cbs + a.shr_prod_wgs), (unsigned)a.ksplit, E ? (unsigned)E->n_slots : 1u);
+  dim3 grid((unsigned)(pt.cbs + a.shr_prod_wgs), (unsigned)(a.ksplit + (a.attn_wgs ? (a.attn_wgs + a.attn_cbs - 1) / a.attn_cbs : 0)), E ? (unsigned)E->n_slots : 1u);   // (+ the attention rows)
   typedef int (*launch_fn)(const GemvArgs&, int, dim3, hipStream_t);
   // [type][pre-rotated][tiles per wave - 1]: 1, 2, 4, 8 tiles per wave (the 3 / 5 / 6 / 7-tile builds of round 2 measured
   // within +-3 % of their neighbours on every shape and were dropped)
@@ -618,6 +667,19 @@ extern "C" int paro_gemv_parts_count(const paro_linear_t* L) {
   int tpw = 0, ks = 0, wv = 0, mode = 0;
   if (resolve_launch_shape(L, 1, tpw, ks, wv, mode, true) != PARO_OK) return -1;
   return (ks >= 2 && ks <= PARO_MAX_PARTIALS) ? ks : 0;
+}
+
+extern "C" int paro_attn_tail_supported(const paro_linear_t* L, int n_heads, int n_kv_heads, int head_dim, int max_positions) {
+  using namespace paro;
+  if (validate_linear(L) != PARO_OK) return -1;
+  if (L->krot > 8 || L->bias || quant_group(L->group_size) != 128) return 0;
+  if (head_dim != 128 || n_heads < 1 || n_kv_heads < 1 || n_kv_heads > 64 || n_heads % n_kv_heads != 0 || n_heads / n_kv_heads > 4) return 0;
+  if ((int64_t)(n_heads + 2 * n_kv_heads) * head_dim != L->N || max_positions < 8 || max_positions % 8 != 0) return 0;
+  int tpw = 0, ks = 0, wv = 0, mode = 0;
+  if (resolve_launch_shape(L, 1, tpw, ks, wv, mode, true) != PARO_OK) return -1;
+  if (ks < 2 || ks > PARO_MAX_PARTIALS || (wv != 4 && wv != 8) || !(tpw == 1 || tpw == 2 || tpw == 4 || tpw == 8)) return 0;
+  if (tpw == 8 && wv == 16) return 0;
+  return 1;
 }
 
 extern "C" int paro_parts_finish(const void* x, const float* parts, int64_t K, void* out, int act_dtype, void* stream) {

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "attn_impl.hpp"
 
 namespace paro {
 
@@ -97,6 +98,11 @@ struct GemvArgs {
   int ar_world, ar_rank;
   long long ar_slot;                // granules per (set, rank) slot of the fp32 region
   long long ar_off;                 // byte offset of that region inside a buffer
+  // attention tail (FUSED | 128, paro_fusion_t.attn_tail): the grid has more rows (blockIdx.y >= ksplit) whose first attn_wgs
+  // workgroups run the decode attention of this token (attn_impl.hpp) on the q / k / v this launch's K-slices leave as tagged granules
+  AttnArgs attn;
+  int attn_wgs;                     // KV heads x position chunks; 0 = no attention tail
+  int attn_cbs;                     // column blocks (= gridDim.x): the attention workgroups fill ceil(attn_wgs / attn_cbs) more grid rows
   // ---- host side only (instantiation choice; the kernel never reads these)
   int rows, ksplit, prologue;
   int parts_out;                 // deferred K-split reduction (paro_fusion_t, v12): this launch leaves partial sums
@@ -181,6 +187,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   // K-slice).
   constexpr bool SELF1 = (FUSED & 64) != 0;
   constexpr int SELF = SELF1 ? 1 : 0;
+  // FUSED | 128 (with FUSED & 127 == 1 or 9: the qkv projection of the decode harness, one row, partial sums left to the consumer): ATTENTION
+  // TAIL.  The decode attention that consumes q / k / v runs in THIS launch: the grid's last rows (blockIdx.y >= ksplit, dispatched behind
+  // every projection workgroup) hold the attention's (KV head, position chunk) workgroups.  They request their K / V cache lines at once
+  // -- nothing of that depends on this token's q / k / v -- while the projection streams; the K-slices leave their partial sums as
+  // 8-byte {fp32, launch tag} granules (write-through, the data is the flag) and the attention polls them: one in-launch hand-over
+  // (~1 us) instead of a launch boundary (2.4 us) plus the attention's own cold start.  Same arithmetic as the two launches.
+  constexpr bool ATAIL = (FUSED & 128) != 0;
+  static_assert(!ATAIL || (((FUSED & 127) == 1 || (FUSED & 127) == 9) && MB == 1 && !PREROT && QS == 1 && (WAVES == 4 || WAVES == 8)),
+                "the attention tail rides the one-row RMSNorm-prologue projection");
   static_assert(!SELF1 || SHR, "the hybrid is a form of the shared rotation");
   static_assert(!SHR || ((FUSED & 31) == 0 && !PREROT && MB <= 16), "the shared rotation feeds the plain kernel");
   typedef Act<AT> A;
@@ -297,6 +312,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.gstride = order ? T : 1;
     h.residual = (GP<unsigned short>)ptr(k0[13], k0[14]);
     h.xstride = (long long)k0[15];
+  }
+  // ---- ATAIL: launch tag (as for SHR below), and the attention row
+  unsigned atag = 0;
+  if constexpr (ATAIL) {
+    const unsigned long long did = paro_dispatch_id();
+    const unsigned long long qp = (unsigned long long)__builtin_amdgcn_queue_ptr();
+    atag = ((unsigned)did + (unsigned)(qp >> 6) * 0x9E3779B1u) | 0x80000000u;
+    if (ks >= h.ksplit) {                             // the attention rows: workgroup (ks - ksplit) * column blocks + cb
+      const int aw = (ks - h.ksplit) * a.attn_cbs + cb;
+      if (wave >= 4 || aw >= a.attn_wgs) return;      // (the attention body is a 256-thread workgroup)
+      const int as = aw / a.attn.Hkv, ah = aw - as * a.attn.Hkv;
+      if (a.attn.Hq > 2 * a.attn.Hkv) attn_decode_body<AT, 128, 4, 0, true, true, true>(a.attn, ah, as, atag);
+      else attn_decode_body<AT, 128, 2, 0, true, true, true>(a.attn, ah, as, atag);
+      return;
+    }
   }
   // ---- SHR: launch tag, granule buffer, and the PRODUCER workgroups (they never reach the GEMV below)
   constexpr int kAuxSc1 = 16;                    // gfx940+ cache-policy immediate of the buffer intrinsics: bit 4 = sc1 (bit 0 sc0, bit 1 nt)
@@ -1138,7 +1168,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       // the CONSUMER launch adds the partials while it seeds its rotation (FUSED | 8 above)
       // Layout [N][4]: slot 0 = the last split, slot q = split q - 1 (the order in which the in-launch reducer adds them), the
       // last split also zeroes the slots beyond the split count -- the consumer adds four slots, no count, no mask.
-      if constexpr (!AREP) {
+      if constexpr (ATAIL) {
+        // (attention tail: the consumer runs in THIS launch -- {fp32, launch tag} granules, written through; the unused slots too, so
+        // that it can check four tags without knowing the split count)
+        unsigned long long* pc = a.slabs + (int64_t)col * 4;
+        const bool last = ks == h.ksplit - 1;
+        const unsigned long long tg = (unsigned long long)atag << 32;
+        __hip_atomic_store(pc + (last ? 0 : ks + 1), tg | (unsigned long long)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) for (int q = h.ksplit; q < 4; ++q) __hip_atomic_store(pc + q, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if constexpr (!AREP) {
         float* pc = (float*)a.slabs + (int64_t)col * 4;
         const bool last = ks == h.ksplit - 1;
         pc[last ? 0 : ks + 1] = v;
@@ -1220,10 +1258,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
       float ss = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) ss += ssl[w * MB];
-      float* pr = (float*)a.slabs + (int64_t)h.N * 4;
       const bool last = ks == h.ksplit - 1;
-      pr[last ? 0 : ks + 1] = ss;
-      if (last) for (int q = h.ksplit; q < 4; ++q) pr[q] = 0.f;
+      if constexpr (ATAIL) {
+        unsigned long long* pr = a.slabs + (int64_t)h.N * 4;
+        const unsigned long long tg = (unsigned long long)atag << 32;
+        __hip_atomic_store(pr + (last ? 0 : ks + 1), tg | (unsigned long long)__builtin_bit_cast(unsigned, ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) for (int q = h.ksplit; q < 4; ++q) __hip_atomic_store(pr + q, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        float* pr = (float*)a.slabs + (int64_t)h.N * 4;
+        pr[last ? 0 : ks + 1] = ss;
+        if (last) for (int q = h.ksplit; q < 4; ++q) pr[q] = 0.f;
+      }
     }
   }
   if constexpr (DIAG == 3) {
@@ -1309,6 +1354,19 @@ int launch_waves_fused(const GemvArgs& a, int waves, dim3 grid, hipStream_t st) 
   if (a.attn_in) {   // x = the merge of a split attention launch's slots (FUSED | 16): one row, no prologue
     if constexpr (MB == 1 && !PREROT) return launch_waves_fused_mode<AT, TPW, MB, PREROT, 16>(a, waves, grid, st);
     return fail(PARO_ERR_UNSUPPORTED, "attention slots as input are built for one row, in-kernel rotation");
+  }
+  if (a.attn_wgs) {   // + attention tail (FUSED | 128): the one-row RMSNorm-prologue projection that leaves partial sums
+    if constexpr (MB == 1 && !PREROT && tpw_is_pow2(TPW)) {
+      if (a.qs == 1 && (waves == 4 || waves == 8) && a.parts_out && a.prologue == PARO_PROLOGUE_RMSNORM) {
+        if (a.parts_in) {
+          if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, 1, 8, false, 1, 137>, 512>(a, grid, st);
+          return launch_checked<gemv_kernel<AT, TPW, 1, 4, false, 1, 137>, 256>(a, grid, st);
+        }
+        if (waves == 8) return launch_checked<gemv_kernel<AT, TPW, 1, 8, false, 1, 129>, 512>(a, grid, st);
+        return launch_checked<gemv_kernel<AT, TPW, 1, 4, false, 1, 129>, 256>(a, grid, st);
+      }
+    }
+    return fail(PARO_ERR_UNSUPPORTED, "the attention tail is built for one row, RMSNorm prologue, partial sums out, group_size 128, 4 or 8 waves, 1 / 2 / 4 / 8 tiles per wave");
   }
   if (a.parts_in) {   // x = base + the producer's partial sums (FUSED | 8): one row, RMSNorm or no prologue
     if constexpr (MB == 1 && !PREROT) {

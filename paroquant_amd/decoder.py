@@ -333,11 +333,19 @@ class ParoDecoderLM:
             and os.environ.get("PARO_DEFERRED_QKV", "1") != "0"
         if self.deferred_qkv:
             self.parts_q = torch.zeros(qkv_w + 1, nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)
+        self.fuse_qkv_attn = False      # (decided below, once the attention's buffers exist)
         # ... and the attention's merge over position chunks (ABI v14): the chunks of a head run on different CUs and leave their slots'
         # (max, sum, un-normalised output); o_proj completes the merge while it seeds its rotation.  PARO_SPLIT_ATTN=0: off
         self.split_attn = self.deferred and c.head_dim in (64, 128) and os.environ.get("PARO_SPLIT_ATTN", "1") != "0"
         if self.split_attn:
             self.attn_parts = torch.zeros(ops.attn_parts_floats(self.nh, c.head_dim), dtype=torch.float32, device=dev)
+        # ... and the attention itself inside the qkv launch (ABI v18, paro_attn_tail_t): its workgroups ride in the projection's grid,
+        # request their K / V lines while the projection streams and take q / k / v as {partial sum, launch tag} granules -- one
+        # in-launch hand-over instead of a launch boundary.  PARO_FUSE_QKV_ATTN=0: off
+        self.fuse_qkv_attn = self.deferred_qkv and self.split_attn and os.environ.get("PARO_FUSE_QKV_ATTN", "1") != "0" \
+            and all(ops.attn_tail_supported(L.qkv, self.nh, self.nkv, c.head_dim, c.max_positions, dt) for L in self.layers)
+        if self.fuse_qkv_attn:
+            self.parts_q = torch.zeros(qkv_w + 1, 2 * nat.PARO_MAX_PARTIALS, dtype=torch.float32, device=dev)      # 8-byte granules
         self.logits = torch.zeros(1, c.vocab, dtype=dt, device=dev)
         self.out_tokens = torch.zeros(c.max_positions, dtype=torch.long, device=dev)
         # per-instance scratch (arrival tickets of the attention chunks): two decoders of the same geometry may run on
@@ -400,14 +408,19 @@ class ParoDecoderLM:
         pend = None
         qkv_to = dict(parts_out=self.parts_q) if self.deferred_qkv else dict(out=self.qkv_buf)
         for L in self.layers:
+            if self.fuse_qkv_attn:      # the attention rides in the qkv launch
+                qkv_to = dict(parts_out=self.parts_q, attn_tail=dict(
+                    kcache=L.kcache, vcache=L.vcache, pos=self.pos, rope=self.rope, n_heads=self.nh, n_kv_heads=self.nkv, head_dim=c.head_dim,
+                    q_norm_w=L.q_norm, k_norm_w=L.k_norm, eps=c.rms_eps, split_out=self.attn_parts, workspace=self.attn_ws))
             if pend is None:
                 ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, **qkv_to)
             else:
                 ops.w4a16_gemv_fused(cur, L.qkv, R, c.rms_eps, parts_in=pend, x_out=other.view(-1), **qkv_to)
                 cur, other = other, cur
-            ops.attn_decode(self.parts_q if self.deferred_qkv else self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv,
-                            c.head_dim, L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws, norm_dim=c.hidden,
-                            norm_eps=c.rms_eps, split_out=self.attn_parts if self.split_attn else None)
+            if not self.fuse_qkv_attn:
+                ops.attn_decode(self.parts_q if self.deferred_qkv else self.qkv_buf, L.kcache, L.vcache, self.pos, self.rope, self.nh, self.nkv,
+                                c.head_dim, L.q_norm, L.k_norm, c.rms_eps, out=self.attn_buf, workspace=self.attn_ws, norm_dim=c.hidden,
+                                norm_eps=c.rms_eps, split_out=self.attn_parts if self.split_attn else None)
             if self.split_attn:
                 ops.w4a16_gemv_fused(None, L.o, 0, parts_out=self.parts_o, attn_in=self.attn_parts, attn_head_dim=c.head_dim, dtype=self.dtype)
             else:

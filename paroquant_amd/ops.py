@@ -320,7 +320,7 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
                      out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, allreduce=None,
                      parts_out: Optional[torch.Tensor] = None, parts_in: Optional[torch.Tensor] = None,
                      x_out: Optional[torch.Tensor] = None, parts_n: int = 0, attn_in: Optional[torch.Tensor] = None,
-                     attn_head_dim: int = 0, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                     attn_head_dim: int = 0, dtype: Optional[torch.dtype] = None, attn_tail: Optional[dict] = None) -> torch.Tensor:
     """Decode-layer fusions around one fused linear (``paro_w4a16_gemv_fused``; rows <= 4):
     ``prologue`` = nat.PROLOGUE_RMSNORM  -> ``y = linear(x) * rsqrt(mean(x^2) + eps)`` (norm weight pre-folded into
     ``pk.channel_scales``, see ``PackedParoWeights.fold_norm_weight``), nat.PROLOGUE_SILU_MUL -> x is the merged
@@ -341,7 +341,12 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     ``attn_in`` (float32 ``[attn_parts_floats(K // attn_head_dim, attn_head_dim)]``, v14): the linear's input is the attention output
     handed over un-merged by :func:`attn_decode` ``(..., split_out=)``; ``x`` is ignored (pass ``None``), the activation type comes from
     ``dtype`` (or ``out``).  The launch completes the merge over the slots while it seeds its rotation -- the same bits as
-    :func:`attn_finish` followed by the plain launch.  One row, no prologue, no residual; ``parts_out`` allowed."""
+    :func:`attn_finish` followed by the plain launch.  One row, no prologue, no residual; ``parts_out`` allowed.
+
+    ``attn_tail`` (v18; a dict of :func:`attn_decode`'s arguments: kcache, vcache, pos, rope, n_heads, n_kv_heads, head_dim, q_norm_w,
+    k_norm_w, eps, split_out, workspace): this is the qkv projection (one row, RMSNorm prologue, ``parts_out``) and the decode attention
+    that consumes it runs in the SAME launch (include/paro_abi.h, ``paro_attn_tail_t``; :func:`attn_tail_supported` says when).
+    ``parts_out`` is then float32 ``[N + 1, 8]`` -- 8-byte {partial sum, launch tag} granules -- and the result is ``split_out``."""
     lib = nat.load()
     K, N = pk.K, pk.N
     if attn_in is not None:
@@ -360,10 +365,11 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
     if x.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"expected float16 or bfloat16 activations, got {x.dtype}")
     # (with the RMSNorm prologue a producer also leaves its K-slices' sums of squares: one more row)
-    for name, t, width_t in (("parts_out", parts_out, N + (1 if prologue == nat.PROLOGUE_RMSNORM else 0)), ("parts_in", parts_in, K)):
-        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (width_t, nat.PARO_MAX_PARTIALS) or not t.is_contiguous()
+    for name, t, width_t, slots in (("parts_out", parts_out, N + (1 if prologue == nat.PROLOGUE_RMSNORM else 0), nat.PARO_MAX_PARTIALS * (2 if attn_tail else 1)),
+                                    ("parts_in", parts_in, K, nat.PARO_MAX_PARTIALS)):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (width_t, slots) or not t.is_contiguous()
                               or t.device != x.device):
-            raise ValueError(f"{name} must be a contiguous float32 [{width_t}, {nat.PARO_MAX_PARTIALS}] tensor on {x.device}")
+            raise ValueError(f"{name} must be a contiguous float32 [{width_t}, {slots}] tensor on {x.device}")
     if x_out is not None and (parts_in is None or x_out.numel() != K or x_out.dtype != x.dtype or not x_out.is_contiguous() or x_out.device != x.device):
         raise ValueError(f"x_out (with parts_in) must be a contiguous [{K}] tensor of {x.dtype} on {x.device}")
     if parts_out is not None:
@@ -392,11 +398,41 @@ def w4a16_gemv_fused(x: torch.Tensor, pk, prologue: int = 0, eps: float = 1e-6, 
         f.x_out = x_out.data_ptr() if x_out is not None else None
     if attn_in is not None:
         f.attn_in, f.attn_head_dim = attn_in.data_ptr(), int(attn_head_dim)
+    tail = None
+    if attn_tail is not None:
+        t = attn_tail
+        if parts_out is None or prologue != nat.PROLOGUE_RMSNORM or rows != 1:
+            raise ValueError("attn_tail rides the one-row RMSNorm-prologue projection with parts_out")
+        nh, nkv, hd = int(t["n_heads"]), int(t["n_kv_heads"]), int(t["head_dim"])
+        so, aws, kc = t["split_out"], t["workspace"], t["kcache"]
+        if so.dtype != torch.float32 or not so.is_contiguous() or so.numel() != attn_parts_floats(nh, hd):
+            raise ValueError(f"attn_tail.split_out must be a contiguous float32 tensor of attn_parts_floats({nh}, {hd}) elements")
+        tail = nat.ParoAttnTail()
+        tail.kcache, tail.vcache, tail.attn_parts = kc.data_ptr(), t["vcache"].data_ptr(), so.data_ptr()
+        tail.pos, tail.rope = t["pos"].data_ptr(), t["rope"].data_ptr()
+        tail.q_norm_w = t["q_norm_w"].data_ptr() if t.get("q_norm_w") is not None else None
+        tail.k_norm_w = t["k_norm_w"].data_ptr() if t.get("k_norm_w") is not None else None
+        tail.eps, tail.scale = float(t.get("eps", 1e-6)), float(t.get("scale") or hd ** -0.5)
+        tail.n_heads, tail.n_kv_heads, tail.head_dim, tail.max_positions = nh, nkv, hd, int(kc.size(1))
+        tail.workspace, tail.workspace_bytes = aws.data_ptr(), aws.numel() * aws.element_size()
+        f.attn_tail = ctypes.pointer(tail)
     ws = pk.workspace
     with torch.cuda.device(x.device):
         nat.check(lib.paro_w4a16_gemv_fused(ctypes.byref(d), x2.data_ptr(), y.data_ptr() if y is not None else None, rows, ws.data_ptr(),
                                             ws.numel() * ws.element_size(), ctypes.byref(f), nat.current_stream_ptr(x.device)))
+    if tail is not None:
+        return attn_tail["split_out"]
     return y if y is not None else parts_out
+
+
+def attn_tail_supported(pk, n_heads: int, n_kv_heads: int, head_dim: int, max_positions: int, act_dtype: torch.dtype = torch.float16) -> bool:
+    """Whether ``w4a16_gemv_fused(..., attn_tail=)`` can run this qkv projection with its decode attention in one launch
+    (``paro_attn_tail_supported``: head_dim 128, at most 4 query heads per KV head, group_size 128, a deferred launch shape of 4 or 8
+    waves that K-splits)."""
+    n = nat.load().paro_attn_tail_supported(ctypes.byref(pk_desc(pk, act_dtype)), int(n_heads), int(n_kv_heads), int(head_dim), int(max_positions))
+    if n < 0:
+        nat.check(n)
+    return n == 1
 
 
 def gemv_parts_count(pk, act_dtype: torch.dtype = torch.float16) -> int:

@@ -643,7 +643,8 @@ def test_no_kernel_reads_the_dispatch_packet():
                 # bit 1: dispatch-packet pointer -- never.  bit 2: queue pointer -- only the shared-rotation instantiations of the GEMV
                 # (gemv_kernel<..., FUSED = 32, ...>): they take the queue's ADDRESS (two preloaded SGPRs, no memory access) into
                 # their launch tag so that two queues' equal dispatch ids never match (gemv_impl.hpp, FUSED | 32)
-                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi(32|96)ELi[12]EEE", name) is not None
+                # (and the attention-tail instantiations, FUSED = 129 / 137: the same launch tag)
+                shared_rot = "gemv_kernel" in name and re.search(r"Li1ELi(32|96|129|137)ELi[12]EEE", name) is not None
                 if props & 0b010 or (props & 0b100 and not shared_rot):
                     bad.append(name)
                 n_shared += int(shared_rot and bool(props & 0b100))

@@ -41,13 +41,14 @@ def main():
     ms = float(np.median([s["ms_per_token"] for s in stats]))
     lm_head_bytes = c.vocab * c.hidden * 2
     print(json.dumps({
-        "metric": "end-to-end batch-1 greedy decode tokens/s (fused harness: 5 launches per layer + lm_head, HIP graph)",
+        "metric": "end-to-end batch-1 greedy decode tokens/s (fused harness: %d launches per layer + lm_head, HIP graph)" % (4 if getattr(lm, "fuse_qkv_attn", False) else 5),
         "model": args.model, "layers": c.n_layers, "prompt_tokens": args.prompt, "new_tokens": args.new, "runs": args.runs,
         "decode_tokens_per_s": round(tps, 1), "ms_per_token": round(ms, 4),
         "ttft_ms": round(float(np.median([s["ttft_s"] for s in stats])) * 1e3, 2),
         "packed_weight_bytes_per_token": lm.bytes_per_token, "lm_head_bytes_per_token": lm_head_bytes,
         "effective_GBps": round((lm.bytes_per_token + lm_head_bytes) / ms / 1e6, 1),
-        "hip_graph": not args.no_graph, "deferred_ksplit_reduction": bool(lm.deferred), "split_attention": bool(getattr(lm, "split_attn", False)), "data": "synthetic"}), flush=True)
+        "hip_graph": not args.no_graph, "deferred_ksplit_reduction": bool(lm.deferred), "split_attention": bool(getattr(lm, "split_attn", False)),
+        "attention_in_qkv_launch": bool(getattr(lm, "fuse_qkv_attn", False)), "data": "synthetic"}), flush=True)
 
 
 if __name__ == "__main__":
