@@ -242,36 +242,49 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
   {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned m0_save;
-    // (PARTS_IN: one more request in front of the batch below, whose wait covers it; its own statement so that the other
-    // instantiations' prologue is byte for byte what it was)
-    if constexpr (PARTS_IN || ATTN_IN) asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(pin_ptrs) : "s"(kp), "i"(offsetof(GemvArgs, parts_in)) : "memory");
-    asm volatile(
-        "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"
-        "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"
-        "s_load_dwordx2 %[cnt], %[kp], %[cntoff]\n\t"
-        "s_mov_b32 %[m0s], m0\n\t"
-        "s_mov_b32 %[p], 0\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_cmp_ge_i32 %[cb], s84\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s85\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s86\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s87\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s88\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s89\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_cmp_ge_i32 %[cb], s90\n\ts_addc_u32 %[p], %[p], 0\n\t"
-        "s_mov_b32 m0, %[p]\n\t"
-        "s_nop 0\n\t"                       // hazard: a scalar write of m0 needs one wait state before s_movrel (no compiler in here to insert it)
-        "s_movrels_b32 %[cb0], s83\n\t"     // cbs[p - 1] = first column block of partition p (p = 0: junk, fixed below)
-        "s_movrels_b32 %[e0], s91\n\t"      // ent[p]
-        "s_movrels_b32 %[e1], s92\n\t"      // ent[p + 1]
-        "s_cmp_eq_u32 %[p], 0\n\t"
-        "s_cselect_b32 %[cb0], 0, %[cb0]\n\t"
-        "s_mov_b32 m0, %[m0s]\n\t"
+    // (PARTS_IN / ATTN_IN: one more request in front of the batch, whose wait covers it -- INSIDE the same statement: as a statement of
+    // its own, the compiler took its output registers for valid at once, and under register pressure copied / spilled them between the
+    // two statements, i.e. before the load had written them -- a garbage pointer in the bf16 attention-tail build, found in round 6;
+    // the other instantiations' prologue is byte for byte what it was)
+#define PARO_GEMV_PROLOGUE_ASM \
+        "s_load_dwordx16 %[k0], %[kp], 0x0\n\t"                                                                                   \
+        "s_load_dwordx16 s[84:99], %[kp], 0x40\n\t"                                                                               \
+        "s_load_dwordx2 %[cnt], %[kp], %[cntoff]\n\t"                                                                             \
+        "s_mov_b32 %[m0s], m0\n\t"                                                                                                \
+        "s_mov_b32 %[p], 0\n\t"                                                                                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                \
+        "s_cmp_ge_i32 %[cb], s84\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s85\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s86\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s87\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s88\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s89\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_cmp_ge_i32 %[cb], s90\n\ts_addc_u32 %[p], %[p], 0\n\t"                                                                \
+        "s_mov_b32 m0, %[p]\n\t"                                                                                                  \
+        "s_nop 0\n\t" /* hazard: a scalar write of m0 needs one wait state before s_movrel (no compiler in here to insert it) */   \
+        "s_movrels_b32 %[cb0], s83\n\t" /* cbs[p - 1] = first column block of partition p (p = 0: junk, fixed below) */           \
+        "s_movrels_b32 %[e0], s91\n\t"  /* ent[p] */                                                                              \
+        "s_movrels_b32 %[e1], s92\n\t"  /* ent[p + 1] */                                                                          \
+        "s_cmp_eq_u32 %[p], 0\n\t"                                                                                                \
+        "s_cselect_b32 %[cb0], 0, %[cb0]\n\t"                                                                                     \
+        "s_mov_b32 m0, %[m0s]\n\t"                                                                                                \
         "s_nop 0"
-        : [k0] "=&s"(k0), [p] "=&s"(p), [cb0] "=&s"(p_cb0_u), [e0] "=&s"(ent0), [e1] "=&s"(ent1), [m0s] "=&s"(m0_save), [cnt] "=&s"(cnt_ptr)
-        : [kp] "s"(kp), [cb] "s"(cb), [cntoff] "i"(offsetof(GemvArgs, counters))
-        : "memory", "scc", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
-          "s98", "s99");
+#define PARO_GEMV_PROLOGUE_OUT [k0] "=&s"(k0), [p] "=&s"(p), [cb0] "=&s"(p_cb0_u), [e0] "=&s"(ent0), [e1] "=&s"(ent1), [m0s] "=&s"(m0_save), [cnt] "=&s"(cnt_ptr)
+#define PARO_GEMV_PROLOGUE_CLOBBER "memory", "scc", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+    if constexpr (PARTS_IN || ATTN_IN) {
+      asm volatile("s_load_dwordx4 %[pin], %[kp], %[pinoff]\n\t" PARO_GEMV_PROLOGUE_ASM
+                   : PARO_GEMV_PROLOGUE_OUT, [pin] "=&s"(pin_ptrs)
+                   : [kp] "s"(kp), [cb] "s"(cb), [cntoff] "i"(offsetof(GemvArgs, counters)), [pinoff] "i"(offsetof(GemvArgs, parts_in))
+                   : PARO_GEMV_PROLOGUE_CLOBBER);
+    } else {
+      asm volatile(PARO_GEMV_PROLOGUE_ASM
+                   : PARO_GEMV_PROLOGUE_OUT
+                   : [kp] "s"(kp), [cb] "s"(cb), [cntoff] "i"(offsetof(GemvArgs, counters))
+                   : PARO_GEMV_PROLOGUE_CLOBBER);
+    }
+#undef PARO_GEMV_PROLOGUE_ASM
+#undef PARO_GEMV_PROLOGUE_OUT
+#undef PARO_GEMV_PROLOGUE_CLOBBER
   }
   // pointers rebuilt from argument dwords carry no address space: name it (global), or every access through them
   // becomes a flat load that also counts against lgkmcnt
