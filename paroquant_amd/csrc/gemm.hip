@@ -23,6 +23,8 @@ namespace paro {
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
                   int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
 int validate_linear(const paro_linear_t* L);
+int launch_prerot_sched(const void* x, void* out, const void* rot, const void* cs, int64_t rows, int64_t K, int krot, int nparts,
+                        int dt, int frag_row_tiles, hipStream_t st);   // rotate.hip
 int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows, int64_t K, int nparts, int dt,
                        hipStream_t st);
 
@@ -477,8 +479,11 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   // (Merged projections: rotating partition p + 1 on a side stream while the GEMM of partition p runs was built in round 5 and does not
   // overlap -- a GEMM workgroup holds 128 KB of LDS, a pre-pass workgroup 68 KB, a CU has 160 KB: profiles/r05_prefill_overlap.txt, NOTES 5.4;
   // the host branch was removed in round 6.)
+  static const int env_sched = getenv("PARO_PREROT_SCHED") ? atoi(getenv("PARO_PREROT_SCHED")) : 1;   // 0: the stage kernel, as up to round 5 (A/B)
   if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
     rc = launch_rotate_mfma(x, xrot, L->rmat, rows, L->K, L->n_parts, L->act_dtype, st);
+  else if (L->rot && L->krot <= 8 && env_sched != 0)   // short prefill / batched decode: the schedule pre-pass (rotate.hip), plain rows
+    rc = launch_prerot_sched(x, xrot, L->rot, L->channel_scales, rows, L->K, L->krot, L->n_parts, L->act_dtype, 0, st);
   else
     rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
                        PARO_DTYPE_F16, st, L->n_parts);  // one launch, blockIdx.z = merged partition

@@ -11,6 +11,8 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows);   // gemm.hip
 int gemm4_ksplit(const paro_linear_t* L, int64_t rows);  // gemm.hip
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales,
                   int64_t rows, int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);
+int launch_prerot_sched(const void* x, void* out, const void* rot, const void* cs, int64_t rows, int64_t K, int krot, int nparts,
+                        int dt, int frag_row_tiles, hipStream_t st);   // rotate.hip
 
 int validate_linear(const paro_linear_t* L) {
   if (!L) return fail(PARO_ERR_INVALID, "null layer descriptor");
@@ -323,8 +325,10 @@ extern "C" int64_t paro_linear_workspace_bytes(const paro_linear_t* L, int64_t r
   if (validate_linear(L) != PARO_OK) return -1;
   if (rows < 0) return -1;
   const int64_t r = rows < 1 ? 1 : rows;
-  const int64_t xrot = r <= 16 ? (int64_t)L->n_parts * L->K * ((r + 1) / 2) * 8   // <= 16 rows: as {two channels, tag} granules, 16 bytes per lane and row PAIR (mode 3)
-                               : (int64_t)L->n_parts * r * L->K * 2;               // rotated activations (GEMM path / mode 1 / krot > 8)
+  // <= 16 rows: as {two channels, tag} granules, 16 bytes per lane and row PAIR (mode 3), or one 16-row tile in fragment order (mode 1);
+  // 17..64 rows: fragment order pads to 32 / 64 rows (mode 1); above: plain rotated rows (GEMM path)
+  const int64_t xrot = r <= 16 ? (int64_t)L->n_parts * L->K * std::max<int64_t>(((r + 1) / 2) * 8, 32)
+                               : (int64_t)L->n_parts * (r <= 32 ? 32 : (r <= 64 ? 64 : r)) * L->K * 2;
   // 8-byte {tag, partial} granules of the GEMV K-split: any split up to kMaxKsplit for <= 16 rows (the
   // launch-shape knobs are the caller's), the automatic one for 17..64 rows
   int64_t slabs = 0;
@@ -544,8 +548,15 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   // 5.00 / 4.88 / 4.96, down 7.42 / 7.24 / 7.14; Llama-3-8B o 5.45 / 5.31 / 5.25, down 9.55 / 9.39 / 9.32).  PARO_POLL_DELAY overrides.
   static const int env_poll = getenv("PARO_POLL_DELAY") ? atoi(getenv("PARO_POLL_DELAY")) : -1;
   a.poll_delay = env_poll >= 0 ? env_poll : (gps >= 16 ? 8 : 4);
+  // mode 1 on the packed schedule (krot <= 8): the schedule pre-pass (rotate.hip) -- one wave per (partition, group, 4 rows), the in-kernel
+  // rotation's arithmetic (bit-identical to modes 0 / 3), x handed over in MFMA-fragment order.  PARO_PREROT_SCHED=0: the stage kernel and
+  // plain rows, as up to round 5 (A/B; krot > 8 always).
+  static const int env_sched = getenv("PARO_PREROT_SCHED") ? atoi(getenv("PARO_PREROT_SCHED")) : 1;
+  const bool sched_prepass = mode == 1 && L->krot <= 8 && L->rot && env_sched != 0;
   auto repack_hot = [&]() {
-    return pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride, pout);
+    if (!pack_hot(a.hot, pt, G, L->wq_order, a.rows, L->krot, a.ksplit, gps, env_skew, env_prio, a.prologue, E != nullptr, xstride, pout)) return false;
+    if (sched_prepass) a.hot.meta |= 1u << 30;   // x arrives in fragment order
+    return true;
   };
   if (!repack_hot()) return fail(PARO_ERR_UNSUPPORTED, "layer too large for the 16-bit partition tables of the GEMV (N / 16 must stay below 65535)");
 
@@ -553,7 +564,8 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   const bool shared = mode == 3 && !fused;
   if (mode == 3 && !shared) mode = 0;
   const int64_t shr_bytes = (int64_t)L->n_parts * G * ((rows + 1) / 2) * 1024;   // granules: [partition][group][row pair][64 lanes] x 16 bytes
-  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * rows * L->K * 2 : (shared ? shr_bytes : 0);
+  // (fragment order pads the rows to whole 16-row tiles: [n_parts][G][row tiles][4][64] x 16 bytes)
+  const int64_t xrot_bytes = mode == 1 ? (int64_t)L->n_parts * (sched_prepass ? (rows <= 16 ? 16 : (rows <= 32 ? 32 : 64)) : rows) * L->K * 2 : (shared ? shr_bytes : 0);
   a.shared_rot = shared ? 1 : 0;
   a.xg = nullptr;
   a.shr_self = shared ? shared_rot_self(L, rows, a.ksplit, wv) : 0;
@@ -587,8 +599,11 @@ static int gemv_impl(const paro_linear_t* L, const void* x, void* y, int64_t row
   if (mode == 1) {
     unsigned short* xrot = (unsigned short*)((char*)workspace + PARO_WS_COUNTER_BYTES + slab_bytes);
     // ONE launch rotates x with every merged partition's parameters (blockIdx.z = partition)
-    rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
-                       PARO_DTYPE_F16, st, L->n_parts);
+    if (sched_prepass)
+      rc = launch_prerot_sched(x, xrot, L->rot, L->channel_scales, rows, L->K, L->krot, L->n_parts, L->act_dtype, rows <= 16 ? 1 : (rows <= 32 ? 2 : 4), st);
+    else
+      rc = launch_rotate(x, xrot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype,
+                         PARO_DTYPE_F16, st, L->n_parts);
     if (rc != PARO_OK) return rc;
     a.hot.x = xrot;
   }

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     GP<unsigned short> cs;
     GP<unsigned short> x;
     GP<unsigned short> residual;
-    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts, parts_out;
+    int K, N, G, rows, krot, ksplit, gps, tsz, tstride, gstride, skew, prio, prologue, experts, parts_out, xfrag;
     long long xstride;
   } h;
   {
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
     h.prio = (int)((meta >> 25) & 1u);
     h.prologue = (int)((meta >> 26) & 3u);
     h.experts = (int)((meta >> 28) & 1u);
+    h.xfrag = (int)((meta >> 30) & 1u);   // pre-rotated x in MFMA-fragment order (the schedule pre-pass of mode 1, rotate.hip)
     h.gps = (int)(k0[12] & 0xffffu);
     h.tsz = (int)(k0[12] >> 16);
     const bool order = (meta >> 29) & 1u;
@@ -518,7 +519,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
 
   // element / chunk offsets are 32-bit (host-checked ranges): 64-bit scalar index arithmetic is several instructions
   // per term, in a prologue every wave of the CU executes on the one shared scalar unit
-  GP<unsigned short> xrot_p = x_p + (PREROT ? (unsigned)(p * h.rows * h.K) : 0u);
+  // pre-rotated x: plain rows [p][row][K] (mode 2: the caller's layout), or -- behind the schedule pre-pass of mode 1 (rotate.hip) --
+  // MFMA-fragment order [p][g][row tile][k-step][16 mq + row % 16] x 16 bytes: one contiguous 1-KiB wave load per (row tile, k-step)
+  // instead of sixteen 64-byte row pieces.  Element offset = lane part + uniform part (group, row tile, k-step strides).
+  const unsigned xl_base = !PREROT ? 0u : (h.xfrag ? (unsigned)(p * h.G * RT * 2048 + (mq * 16 + brow) * 8) : (unsigned)(p * h.rows * h.K + brow * h.K + 8 * mq));
+  const unsigned xg_stride = h.xfrag ? (unsigned)(RT * 2048) : 128u, xrt_stride = h.xfrag ? 2048u : (unsigned)(16 * h.K), xi_stride = h.xfrag ? 512u : 32u;
 
   // the rotation inputs of group g of partition pu: exchange schedule, channel scales, x (SHR: the producer's unit -- any partition)
   auto load_rot = [&](PBuf& b, int pu, int g) {
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const GemvArgs a) {
           const int row = rt * 16 + brow;
           b.xa[rt * 4 + i] = (u32x4){0u, 0u, 0u, 0u};
           if (((mrow & 3) < MR) && row < h.rows)
-            b.xa[rt * 4 + i] = *(GP<u32x4>)(xrot_p + (unsigned)(row * h.K + g * 128 + 32 * i + 8 * mq));
+            b.xa[rt * 4 + i] = *(GP<u32x4>)(x_p + ((unsigned)g * xg_stride + (unsigned)rt * xrt_stride + (unsigned)i * xi_stride) + xl_base);
         }
     } else {
       if constexpr (PARTS_IN) {

@@ -134,6 +134,132 @@ extern "C" int paro_rotate(const void* x, void* out, const int16_t* idx_ij, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pre-pass for 9..255 rows on the PACKED exchange schedule (paro_pack_rotation: 3 KiB per group, the words the fused GEMV
+// consumes).  The stage kernel above derives cos / sin from theta per stage and keeps its state in LDS: 6.5 .. 7 us per call
+// at 17..32 rows (profiles/r06_rows_17_64.jsonl), a launch boundary plus ~4 us of its own.  Here one WAVE rotates one
+// (partition, group, 4 rows) task in REGISTERS -- the seed / stage / finish arithmetic of the GEMV's in-kernel rotation
+// (gemv_impl.hpp, the producer of mode 3), so the rotated halves are BIT-IDENTICAL to what modes 0 and 3 multiply by -- and
+// stores either plain rows out[p][row][K] (the MFMA GEMM's LDS-DMA source, mode 2's layout) or, for the GEMV on 17..64 rows,
+// MFMA-FRAGMENT order: [p][g][row tile][k-step][lane = 16 mq + (row & 15)] x 16 bytes, so that a wave's A operand of one
+// (row tile, k-step) is ONE contiguous 1-KiB load instead of sixteen 64-byte row pieces (every column block re-reads the
+// rows: Qwen3-4B qkv at 32 rows pulls 30 MB of x through L2 beside 8.4 MB of weights).
+// Same semantics as rotate<T,4,128,8> per partition (rotation.cu:10-43; plugin.py:288-306 for the merged partitions).
+// ---------------------------------------------------------------------------------------------
+namespace paro {
+
+constexpr int kPrerotRows = 4;       // rows per task
+constexpr int kPrerotStride = 136;   // halves per staged row (128 + 8 pad)
+
+template <typename AT, bool FRAG>
+__global__ __launch_bounds__(256) void prerot_sched_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
+                                                          const unsigned* __restrict__ rot, const unsigned short* __restrict__ cs,
+                                                          int rows, int K, int krot, int units, int row_tiles) {
+  typedef Act<AT> A;
+  constexpr int PRR = kPrerotRows;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[4 * PRR * kPrerotStride];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = blockIdx.x * 4 + wave;
+  if (u >= units) return;
+  const int G = K >> 7;
+  const int nq = (rows + PRR - 1) / PRR;
+  const int pg = u / nq, r0 = (u - pg * nq) * PRR;     // the four waves of a workgroup share (partition, group) when nq >= 4
+  const int pu = pg / G, g = pg - pu * G;
+  unsigned short* xq = lds + wave * (PRR * kPrerotStride);
+  const u32x4* rp = (const u32x4*)rot + (int64_t)pg * 192 + lane;
+  u32x4 rc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rc[q] = rp[q * 64];
+  const unsigned csv = *(const unsigned*)(cs + (int64_t)pu * K + g * 128 + 2 * lane);
+  unsigned xv[PRR];
+#pragma unroll
+  for (int r = 0; r < PRR; ++r) {
+    const int rr = min(r0 + r, rows - 1);
+    xv[r] = *(const unsigned*)(x + (int64_t)rr * K + g * 128 + 2 * lane);
+  }
+  const float fscale = __builtin_ldexpf(1.0f, 49 - 14 * krot);
+  const float c0 = f16_bits_to_f32(csv & 0xffffu) * 0x1p-63f, c1 = f16_bits_to_f32(csv >> 16) * 0x1p-63f;
+  float sa[PRR], sb[PRR];
+#pragma unroll
+  for (int r = 0; r < PRR; ++r) {
+    const unsigned v = (r0 + r < rows) ? xv[r] : 0u;
+    sa[r] = A::to_f32(v & 0xffffu) * c0;
+    sb[r] = A::to_f32(v >> 16) * c1;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < krot) {
+      const unsigned w = rc[t >> 2][t & 3];
+      const unsigned sw = rc[2][t >> 2];
+      const float P = (float)(int)(short)(w & 0xffffu), Q = (float)((int)w >> 16);
+      const int src = (int)((sw >> (8 * (t & 3))) & 0xffu);
+#pragma unroll
+      for (int r = 0; r < PRR; ++r) {
+        const float keep = __builtin_fmaf(P, sa[r], Q * sb[r]);
+        const float give = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+        sb[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, give)));
+        sa[r] = keep;
+      }
+    }
+  }
+  {
+    const unsigned w0 = rc[2][2], w1 = rc[2][3];
+    const float P = (float)(int)(short)(w0 & 0xffffu) * fscale, Q = (float)((int)w0 >> 16) * fscale;
+    const unsigned oa = w1 & 0xfeu, ob = (w1 >> 8) & 0xfeu;
+    const unsigned flip = w1 & 0x80000000u;
+#pragma unroll
+    for (int r = 0; r < PRR; ++r) {
+      const float o1 = __builtin_fmaf(P, sa[r], Q * sb[r]);
+      const float d = __builtin_fmaf(P, sb[r], -(Q * sa[r]));
+      const float o2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) ^ flip);
+      *(unsigned short*)((unsigned char*)(xq + r * kPrerotStride) + oa) = A::from_f32(o1);
+      *(unsigned short*)((unsigned char*)(xq + r * kPrerotStride) + ob) = A::from_f32(o2);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if constexpr (FRAG) {
+    // lane -> (row r0 + (lane & 3), 16-byte chunk c = lane >> 2 = 4 i + mq): four lanes write 64 contiguous bytes
+    const int r = lane & 3, c = lane >> 2;
+    const int row = r0 + r;
+    if (row < rows) {
+      const u32x4 v = *(const u32x4*)(xq + r * kPrerotStride + 8 * c);
+      const int64_t frag = ((int64_t)pg * row_tiles + (row >> 4)) * 4 + (c >> 2);
+      *(u32x4*)(out + (frag * 64 + (c & 3) * 16 + (row & 15)) * 8) = v;
+    }
+  } else {
+    // lane -> (row r0 + (lane >> 4), chunk lane & 15): 256 contiguous bytes per row
+    const int r = lane >> 4, c = lane & 15;
+    const int row = r0 + r;
+    if (row < rows) {
+      const u32x4 v = *(const u32x4*)(xq + r * kPrerotStride + 8 * c);
+      *(u32x4*)(out + ((int64_t)pu * rows + row) * K + g * 128 + 8 * c) = v;
+    }
+  }
+}
+
+// frag_row_tiles = 0: plain rows out[p][row][K]; > 0: fragment order for a GEMV instantiation of that many 16-row tiles
+int launch_prerot_sched(const void* x, void* out, const void* rot, const void* cs, int64_t rows, int64_t K, int krot, int nparts,
+                        int dt, int frag_row_tiles, hipStream_t st) {
+  if (rows == 0) return PARO_OK;
+  if (krot < 1 || krot > 8 || !rot || !cs) return fail(PARO_ERR_INVALID, "schedule pre-pass: needs the packed schedule (krot <= 8)");
+  const int64_t units = (int64_t)nparts * (K / 128) * ((rows + kPrerotRows - 1) / kPrerotRows);
+  if (units > 0x7fffffff / 4) return fail(PARO_ERR_UNSUPPORTED, "schedule pre-pass: too many tasks");
+  const dim3 grid((unsigned)((units + 3) / 4));
+  const bool h = dt == PARO_DTYPE_F16;
+#define PARO_PREROT_LAUNCH(AT, FR)                                                                                                    \
+  hipLaunchKernelGGL((prerot_sched_kernel<AT, FR>), grid, dim3(256), 0, st, (const unsigned short*)x, (unsigned short*)out,           \
+                     (const unsigned*)rot, (const unsigned short*)cs, (int)rows, (int)K, krot, (int)units, frag_row_tiles)
+  if (frag_row_tiles > 0) { if (h) PARO_PREROT_LAUNCH(f16, true); else PARO_PREROT_LAUNCH(bf16, true); }
+  else { if (h) PARO_PREROT_LAUNCH(f16, false); else PARO_PREROT_LAUNCH(bf16, false); }
+#undef PARO_PREROT_LAUNCH
+  return check_launch("paro_rotate (schedule pre-pass)");
+}
+
+}  // namespace paro
+
+// ---------------------------------------------------------------------------------------------
 // Prefill pre-pass on the matrix cores.  For many rows the 8 sparse Givens stages are cheaper as ONE
 // dense product per 128-channel group:  x_rot[:, g] = x[:, g] @ R'_g,  R'_g = diag(cs_g) * G_1 ... G_8
 // (128 x 128, built once at load time by running the stage kernel above on the scaled identity and

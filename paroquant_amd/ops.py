@@ -709,7 +709,7 @@ def check_workspace(ws: torch.Tensor) -> None:
 
 def decode_workspace_bytes(K: int, N: int, n_parts: int, rows: int = 16) -> int:
     """Mirror of ``paro_linear_workspace_bytes`` for rows <= 16."""
-    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 8 + n_parts * K * ((rows + 1) // 2) * 8
+    return nat.PARO_WS_COUNTER_BYTES + 16 * rows * N * 8 + n_parts * K * max(((rows + 1) // 2) * 8, 32)
 
 
 # --------------------------------------------------------------------------------------

@@ -282,8 +282,11 @@ def test_gemv_matches_oracle(dev, K, sizes, rows):
 @pytest.mark.parametrize("K,sizes", [(1536, [400, 112]), (2560, [4096, 1024, 1024]), (1024, [256])])
 def test_gemv_on_caller_rotated_activations(dev, dtype, K, sizes):
     """mode 2 (ABI v10): x arrives already rotated, [n_parts][rows][K] -- here by rotation::rotate with each partition's
-    parameters, as a producer kernel's epilogue would -- and the GEMV runs the pre-rotated kernels without a pre-pass:
-    bit-identical to the library's own pre-pass route (mode 1), and within tolerance of the float64 oracle."""
+    parameters, as a producer kernel's epilogue would -- and the GEMV runs the pre-rotated kernels without a pre-pass: within
+    tolerance of the float64 oracle.  The library's own pre-pass route (mode 1) rotates on the packed schedule since round 6
+    (rotate.hip `prerot_sched_kernel`: the in-kernel rotation's arithmetic, x handed over in MFMA-fragment order), so on the same
+    launch shape it returns the BITS of mode 0 (rotation inside every workgroup) -- and differs from the stage kernel's rotation
+    (fp32 state, cos / sin from theta) only in the rotation's last-place rounding."""
     from paroquant_amd import ops
     L = po.make_layer(K + len(sizes), K, sizes, bias=True)
     pk = _packed(L, dev)
@@ -295,7 +298,11 @@ def test_gemv_on_caller_rotated_activations(dev, dtype, K, sizes):
                           for p in range(len(sizes))])
         y2 = ops.w4a16_gemv_tuned(xr, pk, 0, 0, 0, 2, bias)
         y1 = ops.w4a16_gemv_tuned(x, pk, 0, 0, 0, 1, bias)
-        assert y2.shape == (rows, sum(sizes)) and torch.equal(y2, y1)
+        assert y2.shape == (rows, sum(sizes)) and y1.shape == y2.shape
+        assert (y2.float() - y1.float()).abs().max().item() <= (4e-3 if dtype == torch.float16 else 3e-2) * y1.float().abs().max().item()
+        for knobs in ((2, 1, 8), (4, 2, 4)):
+            y0 = ops.w4a16_gemv_tuned(x, pk, *knobs, 0, bias)
+            assert torch.equal(ops.w4a16_gemv_tuned(x, pk, *knobs, 1, bias), y0), (rows, knobs)
         ideal = po.paro_linear_merged(_np(x), L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"],
                                       L["channel_scales"], sizes, _np(bias), ideal=True)
         assert po.rel_err(_np(y2), ideal) < (TIGHT_F16 if dtype == torch.float16 else TIGHT_BF16)
