@@ -54,7 +54,14 @@ extern "C" int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y,
   // rows on the GEMM's 64- / 128-row blocks with a K-split are ahead on every shape (48 rows: gate_up 33 vs 70, down 29
   // vs 36, qkv 27 vs 27).  PARO_SKINNY=0 routes everything above 16 rows to the GEMM (A/B runs).
   static const int skinny = getenv("PARO_SKINNY") ? atoi(getenv("PARO_SKINNY")) : 1;
-  if (skinny && rows <= 32 && L)   // fp16 and bf16 alike
+  // Round 6: behind the schedule pre-pass (rotate.hip; x in MFMA-fragment order) the GEMV with 4 row tiles is ahead of the GEMM up to
+  // 64 rows on every output below 1024 tiles (profiles/r06_skinny_routes.jsonl, us GEMV / GEMM at 48 rows: Qwen3-4B qkv 12.8 / 18.3,
+  // o 13.2 / 15.9, down 18.8 / 22.3; Llama-3-8B qkv 17.0 / 21.5, o 14.6 / 18.2, down 26.6 / 27.1); wide merged projections keep the GEMM
+  // from 33 rows on (gate_up 26.9 / 24.6, 48.5 / 33.6: 2-tile blocks re-read 64 rows of x per 32 columns).  PARO_SKINNY_MAX overrides.
+  static const int skinny_env = getenv("PARO_SKINNY_MAX") ? atoi(getenv("PARO_SKINNY_MAX")) : -1;
+  static const int sched_env = getenv("PARO_PREROT_SCHED") ? atoi(getenv("PARO_PREROT_SCHED")) : 1;
+  const int skinny_max = skinny_env >= 0 ? skinny_env : ((L && L->rot && L->krot <= 8 && sched_env != 0 && L->N / 16 < 1024) ? 64 : 32);
+  if (skinny && rows <= skinny_max && rows <= 64 && L)   // fp16 and bf16 alike
     return paro_w4a16_gemv(L, x, y, rows, workspace, workspace_bytes, 0, 0, 0, 1, stream);
   return paro_w4a16_gemm(L, x, y, rows, workspace, workspace_bytes, PARO_GEMM_AUTO, stream);
 }

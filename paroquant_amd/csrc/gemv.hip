@@ -86,7 +86,17 @@ void gemv_autotune(const paro_linear_t* L, int64_t rows, int& tpw, int& ksplit, 
     // 17..64 rows (pre-rotated activations, 2 / 4 MFMA row tiles per weight fragment): every workgroup reads
     // all of x_rot, so few, fat column blocks -- as many tiles per wave as the accumulators allow -- and a
     // K-split only to reach ~256 workgroups on narrow outputs
+    // (round 6, behind the schedule pre-pass -- x in MFMA-fragment order, one 1-KiB wave load per row tile and k-step: re-reading x is
+    // cheap now, and at 17..32 rows outputs below 1024 tiles want 2-tile blocks -- more workgroups in flight -- with the K-split that
+    // brings them to <= 256; wide merged projections keep 4-tile blocks, on four waves.  profiles/r06_sweep_rows32_frag.jsonl, us rule
+    // before / after: Qwen3-4B qkv 12.6 -> 9.7, o 12.3 -> 10.3, gate_up 19.5 -> 17.8, down 15.0 -> 13.5; Llama-3-8B qkv 14.5 -> 12.6,
+    // o 12.9 -> 11.1, gate_up 27.0 -> 25.6, down 20.2 -> 19.9.  At 33..64 rows the rule below is within 2 % of the best of 20 shapes.)
     const int cap = rows <= 32 ? 4 : 2;
+    const bool auto_all = tpw <= 0 && waves <= 0 && ksplit <= 0;
+    if (auto_all && rows <= 32) {
+      tpw = tiles < 1024 ? 2 : 4;
+      waves = tiles < 1024 ? 8 : 4;
+    }
     if (tpw <= 0 || tpw > cap) tpw = cap;
     if (waves <= 0 || waves > 8) waves = 8;
     if (ksplit <= 0) {

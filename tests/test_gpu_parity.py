@@ -595,7 +595,14 @@ def test_gemm_row_tile_blocks(dev, gs, K, sizes, rows):
                                   L["bias"], group_size=gs, ideal=True)
     y_auto = pk.apply(_t(x, dev))
     y_v4 = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, variant=4)
-    assert np.isfinite(_np(y_auto)).all() and torch.equal(y_auto, y_v4)          # the automatic route IS variant 4 here
+    assert np.isfinite(_np(y_auto)).all()
+    if rows > 64 or sum(sizes) // 16 >= 1024:
+        assert torch.equal(y_auto, y_v4)          # the automatic route IS variant 4 here
+    else:
+        # round 6: up to 64 rows, outputs below 1024 tiles take the 4-row-tile GEMV behind the schedule pre-pass (abi.hip) -- the bits of
+        # the in-kernel rotation, not the GEMM's; both against the oracle
+        assert torch.equal(y_auto, ops.w4a16_gemv_tuned(_t(x, dev), pk, 0, 0, 0, 1, pk.bias))
+        assert po.rel_err(_np(y_v4), ideal) < TIGHT_F16
     assert po.rel_err(_np(y_auto), ideal) < TIGHT_F16
     yb = pk.apply(_t(x, dev).to(torch.bfloat16), pk.bias.to(torch.bfloat16))
     assert po.rel_err(_np(yb), ideal) < 2e-2
