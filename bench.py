@@ -500,17 +500,19 @@ def prefill_table(dev, rows: int = 65536, launches: int = 5):
         flops = 2.0 * rows * K * sum(sizes)
         out.append({"linear": name, "M": rows, "K": K, "N": sum(sizes), "P": len(sizes), "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1),
                     "mfma_util": round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4), "prepass_ms": round(ms_pre, 4),
-                    "prepass_share": round(ms_pre / ms, 4), "launches": launches})
+                    "prepass_share": round(ms_pre / ms, 4), "timed_calls": launches, "kernel_launches_per_call": 2})
         del pk, x, xr
         torch.cuda.empty_cache()
     return out
 
 
-def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_counts=(1, 2, 4, 8, 16), steps: int = 20, warmup: int = 3):
+def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_counts=(1, 2, 4, 8, 16, 32, 64), steps: int = 20, warmup: int = 3):
     """Batched decode THROUGH THE BOUNDARY (what a vLLM decode batch reaches: `ParoQuantLinearMethod.apply` is M-agnostic, vllm/plugin.py:281-311),
     driver-visible: the bench step of the headline workload's first `n_layers` layers at several row counts on the
     per-call route -- same weight bytes at every row count, so `x_one_row` is what the extra rows cost.  mode = what the library picked for the
-    layer's qkv projection at that row count (0 rotation replicated per workgroup, 1 pre-pass, 3 shared inside the launch)."""
+    layer's qkv projection at that row count (0 rotation replicated per workgroup, 1 pre-pass, 3 shared inside the launch).  32 / 64 rows
+    (added in round 6, session 3): the GEMV with 2 / 4 MFMA row tiles behind the schedule pre-pass (rotate.hip), wide merged projections
+    on the MFMA GEMM from 33 rows on (abi.hip paro_w4a16_linear)."""
     import ctypes
     from paroquant_amd import _native as nat, ops as _ops
     lib = nat.load()
@@ -536,7 +538,9 @@ def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_c
             if pk0 is not None:
                 d = _ops.pk_desc(pk0, torch.float16)
                 kn = [ctypes.c_int(v) for v in (0, 0, 0, -1)]
-                if lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(k) for k in kn]) == 0:
+                if rows > 16:
+                    mode = 1
+                elif lib.paro_gemv_launch_shape(ctypes.byref(d), rows, *[ctypes.byref(k) for k in kn]) == 0:
                     mode = kn[3].value
         except Exception:
             mode = None
@@ -549,7 +553,8 @@ def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_c
                     "stand-in for attention / SiLU*mul is a CONTIGUOUS view of the predecessor's output; rounds 3..5 sliced columns, which at > 1 row is a strided view "
                     "that torch copies in front of 72 of a Qwen3-4B step's 144 linears (0.21 ms of copy launches no decoder has; PARO_BENCH_STRIDED_STANDIN=1 restores it). "
                     "Round 5 with the strided stand-in, full depth: 1.42 / 1.90 / 2.60 at 2 / 8 / 16 rows; this build the same way 1.30 / 1.60 / 1.87, "
-                    "contiguous 1.06 / 1.36 / 1.63 (mode 3 off: 1.06 / 1.52 / 2.31): profiles/r06_rows_boundary_v2.jsonl"}
+                    "contiguous 1.06 / 1.36 / 1.63 (mode 3 off: 1.06 / 1.52 / 2.31): profiles/r06_rows_boundary_v2.jsonl.  32 / 64 rows, full depth: 2.95 / 3.75 ms "
+                    "with the stage-kernel pre-pass (rounds 1..5) -> 1.84 / 2.71 ms behind the schedule pre-pass: profiles/r06_rows_17_64_v2.jsonl"}
 
 
 def config_steps(dev, models=(("qwen3-0.6b", 0), ("qwen3.5-4b-class", 8)), steps: int = 20, warmup: int = 3):

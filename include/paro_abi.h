@@ -190,7 +190,9 @@ int paro_workspace_status(const void* workspace, void* stream);
  * 128-channel group inside the workgroup that streams that group's INT4 tiles.
  * Launch-shape knobs (0 = auto): tiles_per_wave in {1, 2, 4, 8};
  * ksplit >= 1; waves per workgroup in {4,8,16} (16: <= 4 rows and <= 4 tiles).  mode: 0 = rotation replicated in every workgroup, 1 = rotate
- * pre-pass kernel into the workspace then the same GEMV on rotated x, 3 (v17) = rotation SHARED inside the launch -- producer workgroups in
+ * pre-pass kernel into the workspace then the same GEMV on rotated x (krot <= 8: the schedule pre-pass -- the in-kernel rotation's
+ * arithmetic, so the same bits as mode 0 on the same launch shape -- handing x over in MFMA-fragment order; krot > 8: the stage kernel,
+ * plain rows), 3 (v17) = rotation SHARED inside the launch -- producer workgroups in
  * front of the grid rotate every (partition, group, pair of rows) once and hand it to the column blocks as {two channels, launch tag}
  * granules in the workspace; plain calls of 1..16 rows, bit-identical to mode 0, falls back to mode 0 when the grid cannot be resident at
  * once -- -1 = auto (mode 0 up to 4 rows, mode 3 from 5 rows where it fits the chip, else mode 0 up to 8 rows / for small projections and
@@ -356,7 +358,11 @@ int paro_w4a16_gemm_grouped(const paro_linear_t* L, const void* x_rot, void* y, 
                             const int32_t* block_expert, int64_t wq_stride_bytes, int64_t sz_stride_bytes, int32_t n_experts,
                             void* stream);
 
-/* Dispatcher used by the Python operator: gemv for rows <= 16, gemm otherwise. */
+/* Dispatcher used by the Python operator (RotateQuantizedLinear.forward, transformers/modules.py:57-71; ParoQuantLinearMethod.apply,
+ * vllm/plugin.py:281-311): rows <= 16 the fused GEMV (mode auto); 17..32 rows -- and up to 64 rows on outputs below 1024 column tiles --
+ * the schedule pre-pass + the GEMV on 2 / 4 MFMA row tiles (mode 1); everything else pre-pass + MFMA GEMM.  Environment (A/B runs):
+ * PARO_SKINNY=0 (GEMM above 16 rows), PARO_SKINNY_MAX=<rows> (last row count of the GEMV route), PARO_PREROT_SCHED=0 (the stage-kernel
+ * pre-pass of rounds 1..5 instead of the schedule pre-pass). */
 int paro_w4a16_linear(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                       int64_t workspace_bytes, void* stream);
 

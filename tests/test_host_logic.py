@@ -336,7 +336,12 @@ def test_gemv_launch_shape_heuristics():
     assert shape(*q4["qkv_proj"], 16)[3] == 3 and shape(*q4["gate_up_proj"], 8)[3] == 3 and shape(*q4["gate_up_proj"], 9)[3] == 3
     # the rules behind mode 3 (PARO_SHARED_ROT_MIN_ROWS=17 in the environment restores them): explicit modes are taken as given
     assert shape(*l8["gate_up_proj"], 8, mode=0)[3] == 0 and shape(*l8["gate_up_proj"], 8, mode=1)[3] == 1
-    assert shape(*l8["o_proj"], 32) == (4, 4, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
+    # 17..32 rows behind the schedule pre-pass (x in fragment order, round 6): 2-tile blocks below 1024 tiles with the K-split that
+    # brings them to <= 256 workgroups, 4-tile blocks on four waves for wide merged projections (profiles/r06_sweep_rows32_frag.jsonl)
+    assert shape(*l8["o_proj"], 32) == (2, 2, 8, 1) and shape(*l8["o_proj"], 64)[0] == 2
+    assert shape(*q4["qkv_proj"], 32) == (2, 1, 8, 1) and shape(*q4["o_proj"], 24) == (2, 3, 8, 1) and shape(*q4["down_proj"], 17) == (2, 3, 8, 1)
+    assert shape(*l8["gate_up_proj"], 32) == (4, 1, 4, 1) and shape(*q4["gate_up_proj"], 32) == (4, 1, 4, 1)
+    assert shape(*l8["o_proj"], 32, tpw=4)[0] == 4         # a caller's knob is kept
     # a caller that fixes ksplit = 1 (the RMSNorm prologue) gets the best UNSPLIT shape of the sweeps, not a 2-tile default:
     # TP = 4 gate_up shard (8192 -> 2 x 7168) 4 tiles x 16 waves; narrow deep-K shards 1 tile x 16 waves
     assert shape(8192, [7168, 7168], 1, ksplit=1) == (4, 1, 16, 0) == shape(8192, [7168, 7168], 1)

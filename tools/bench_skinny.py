@@ -34,7 +34,7 @@ def main():
             x = torch.randn(rows, K, device=dev, dtype=torch.float16, generator=gen)
             out = {"model": a.model, "linear": name, "K": K, "N": N, "rows": rows}
             fns = {"gemv": lambda i: ops.w4a16_gemv_tuned(x, packs[i % copies], tpw, ksp, wv, 1),
-                   "gemm": lambda i: ops.w4a16_gemm_forced(x, packs[i % copies]),
+                   "gemm": lambda i: ops.w4a16_gemm_forced(x, packs[i % copies], None, False),
                    "apply": lambda i: packs[i % copies].apply(x)}
             graphs, ys = {}, {}
             for k, fn in fns.items():
