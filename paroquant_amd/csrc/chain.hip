@@ -9,6 +9,8 @@ int validate_linear(const paro_linear_t* L);   // gemv.hip
 int launch_rotate(const void* x, void* out, const int16_t* idx, const void* theta, const void* scales, int64_t rows,
                   int64_t hidden, int krot, int gs, int x_dt, int p_dt, hipStream_t st, int nparts);   // rotate.hip
 int launch_rotate_mfma(const void* x, void* out, const void* rmat, int64_t rows, int64_t K, int nparts, int dt, hipStream_t st);   // rotate.hip
+int launch_prerot_sched(const void* x, void* out, const void* rot, const void* cs, int64_t rows, int64_t K, int krot, int nparts,
+                        int dt, int frag_row_tiles, hipStream_t st);   // rotate.hip
 
 // Launch shape: one 128-column block (PAIR: one gate + one up block) per workgroup, K cut so that the grid fills the
 // chip once (~1 workgroup per CU); 4 waves when a K-slice has <= 4 groups per block, else 8.
@@ -57,8 +59,11 @@ extern "C" int paro_rotate_parts(const paro_linear_t* L, const void* x, void* x_
   if (rc != PARO_OK) return rc;
   if (rows == 0) return PARO_OK;
   if (!x || !x_rot || rows < 0) return fail(PARO_ERR_INVALID, "null pointer / bad row count");
+  static const int env_sched = getenv("PARO_PREROT_SCHED") ? atoi(getenv("PARO_PREROT_SCHED")) : 1;   // 0: the stage kernel (A/B)
   if (L->rmat && rows >= 256)     // many rows: the dense per-group product on the matrix cores -- the pre-pass paro_w4a16_gemm runs (gemm.hip)
     rc = launch_rotate_mfma(x, x_rot, L->rmat, rows, L->K, L->n_parts, L->act_dtype, (hipStream_t)stream);
+  else if (L->rot && L->krot <= 8 && env_sched != 0)   // the schedule pre-pass (rotate.hip): the in-kernel rotation's bits, plain rows
+    rc = launch_prerot_sched(x, x_rot, L->rot, L->channel_scales, rows, L->K, L->krot, L->n_parts, L->act_dtype, 0, (hipStream_t)stream);
   else
     rc = launch_rotate(x, x_rot, L->pairs, L->theta, L->channel_scales, rows, L->K, L->krot, 128, L->act_dtype, PARO_DTYPE_F16,
                        (hipStream_t)stream, L->n_parts);

@@ -80,6 +80,35 @@ def test_rotate_matches_oracle(dev, dtype, mode, tol, ftol, rows, hidden, gs, kr
         assert po.rel_err(got, ideal) <= po.rel_err(faithful, ideal) * 1.5 + 1e-4
 
 
+@pytest.mark.parametrize("dtype,mode,tol,ftol", [(torch.float16, "f16", 4e-3, 8e-3), (torch.bfloat16, "bf16", 1e-2, 6e-2)])
+@pytest.mark.parametrize("rows,K,sizes,krot", [(1, 128, [16], 8), (5, 1024, [256, 64], 8), (17, 2560, [512, 128, 128], 8), (32, 512, [64], 3),
+                                                (33, 1536, [400, 112], 1), (100, 256, [32, 32], 8), (255, 384, [48], 8)])
+def test_schedule_prepass_matches_oracle(dev, dtype, mode, tol, ftol, rows, K, sizes, krot):
+    """The rotation as a launch of its own below 256 rows (rotate.hip `prerot_sched_kernel`, round 6: one wave per (partition, group, 4 rows)
+    on the PACKED schedule, the in-kernel rotation's arithmetic) through `paro_rotate_parts` -- plain rows [P][rows][K] -- against the
+    oracle's rotate per merged partition (rotation.cuh:91-173; one rotation per partition: plugin.py:288-306): the float64 ideal and the
+    reference-faithful mode, the tolerances of `test_rotate_matches_oracle`.  Ragged row counts (not multiples of 4), 1..3 partitions,
+    short schedules (krot 1 / 3)."""
+    from paroquant_amd import ops
+    L = po.make_layer(rows * 31 + K + krot, K, sizes, krot=krot)
+    pk = _packed(L, dev)
+    x = np.random.default_rng(rows + K).standard_normal((rows, K)).astype(np.float32)
+    xt = _t(x, dev, dtype)
+    xr = ops.rotate_parts(xt, pk)
+    assert xr.shape == (len(sizes), rows, K) and xr.dtype == dtype and torch.isfinite(xr.float()).all()
+    xin = _np(xt)
+    for p in range(len(sizes)):
+        cs = L["channel_scales"][p].reshape(-1)
+        ideal = po.rotate(xin, L["pairs"][p], L["theta"][p].astype(np.float64), cs.astype(np.float64), 128, "ideal")
+        faithful = po.rotate(xin, L["pairs"][p], L["theta"][p], cs, 128, mode)
+        got = _np(xr[p])
+        assert po.rel_err(got, ideal) < tol, p
+        assert po.rel_err(got, faithful) < ftol, p
+    # and the stage kernel behind rotation::rotate agrees with it to the rotation's last-place rounding
+    ref = torch.ops.rotation.rotate(xt, pk.pairs[0], pk.theta[0], pk.channel_scales.reshape(len(sizes), 1, K)[0])
+    assert po.rel_err(_np(xr[0]), _np(ref).astype(np.float64)) < tol
+
+
 def test_rotate_kats_and_errors(dev):
     # K1 quarter turn (rotation.cuh:55-56), K2 zero theta
     x = torch.arange(1, 129, device=dev, dtype=torch.float32)[None, :] / 16
