@@ -413,19 +413,83 @@ int gemm_ksplit(const paro_linear_t* L, int64_t rows) {
   if (ks > G / 2) ks = G / 2;
   return ks < 1 ? 1 : ks;
 }
-// Variant 4 below 256 rows (batched decode / short prefill): row tiles of the block, and a K-split that brings the grid
-// of 256-column blocks up to about one workgroup per CU.
-int gemm4_row_tiles(int64_t rows) { return rows <= 64 ? 2 : (rows >= 225 ? 8 : (int)((rows + 31) / 32)); }
-int gemm4_ksplit(const paro_linear_t* L, int64_t rows) {
-  if (rows <= 16 || rows >= 4096) return 1;
-  const int rt = gemm4_row_tiles(rows);
-  const int64_t wgs = ((L->N + 255) / 256) * ((rows + 32 * rt - 1) / (32 * rt));
-  if (wgs > 128) return 1;
+// Variant 4's block shape between 33 and 4095 rows (batched decode, short and medium prefill): row tiles per block and K-split.
+// Round 6 (tools/sweep_gemm4.py, profiles/r06_sweep_gemm4_*.jsonl -- 18 shapes per linear and row count): what matters is ONE round of
+// ~192..256 workgroups over the 256 CUs; small row blocks reach it with few K-splits (the fp32 partial tiles of a split go through memory
+// twice: Llama-3-8B qkv at 256 rows on one 256-row block x 8 splits wrote and re-read 50 MB beside 12.6 MB of weights), the weights a
+// second row block re-reads come from L2.  So: of 2 / 4 / 8 row tiles, those whose grid of (row blocks x 256-column blocks)
+// fit one round, whichever fills it best with its K-split (g4_shape below).  us rule before /
+// after, Llama-3-8B: qkv 256 rows 51 -> 42, 512 rows 71 -> 55, 1024 rows 100 -> 77; o 1024 rows 68 -> 52; down 1024 rows 165 -> 145.
+// (PARO_GEMM4_TUNE set: PARO_GEMM4_RT / PARO_GEMM4_KS are read at EVERY call and override both -- tools/sweep_gemm4.py, one process)
+static const bool g4_tune = getenv("PARO_GEMM4_TUNE") != nullptr;
+static int g4_env(const char* n) { const char* v = getenv(n); return v ? atoi(v) : 0; }
+// K-splits of a grid of `wgs` blocks: fill ONE round, at most clamp(groups / 8, 4, 8) splits of at least two groups (deep K takes more:
+// Qwen3-4B down 128 rows x 8 = 25 us against x 4 = 30), and no more than K / (4 rows) -- a split's fp32 partial tile is written and read
+// back, 8 bytes per element and split against the weights' K / 2 per column: beyond ~4x the weight bytes the splits cost more than they
+// fill (Qwen3-4B down 384 rows: x 8 = 49 us, x 6 = 42)
+static int g4_splits(const paro_linear_t* L, int64_t rows, int64_t wgs) {
+  if (rows <= 16 || rows >= 4096 || wgs > 128) return 1;
   const int G = (int)(L->K / 128);
   int ks = (int)(256 / wgs);
-  if (ks > 8) ks = 8;
+  const int cap = G / 8 > 4 ? (G / 8 > 8 ? 8 : G / 8) : 4;
+  if (ks > cap) ks = cap;
   if (ks > G / 2) ks = G / 2;
+  if (rows > 64 && ks > L->K / (4 * rows)) ks = (int)(L->K / (4 * rows));
   return ks < 1 ? 1 : ks;
+}
+static void g4_shape(const paro_linear_t* L, int64_t rows, int& rt_out, int& ks_out) {
+  const int64_t cbs = (L->N + 255) / 256;
+  const int G = (int)(L->K / 128);
+  auto wgs = [&](int rt) { return ((rows + 32 * rt - 1) / (32 * rt)) * cbs; };
+  if (rows <= 64 || rows >= 4096) {
+    rt_out = rows <= 64 ? 2 : 8;
+    ks_out = g4_splits(L, rows, wgs(rt_out));
+    return;
+  }
+  // deep K above 256 rows: 128-row blocks with more K-splits beat 64-row blocks with fewer (Llama-3-8B down 384 rows 4 x 4 = 67 us
+  // against 2 x 2 = 76; Qwen3-4B down 1024 rows 4 x 3 = 80 against 2 x 1 = 92)
+  const int rt_min = (G >= 64 && rows > 256) ? 4 : 2;
+  // one round: the smallest block whose grid covers more than half of the CUs UNSPLIT (a K-split costs its partial tiles and the reduce
+  // launch: Qwen3-4B gate_up 128 rows 152 blocks unsplit 29 us, 76 x 3 splits 35), else the smallest whose blocks x splits fill three
+  // quarters of the round, else the fullest
+  int best = 0, best_ks = 1;
+  int64_t best_fill = 0;
+  for (int rt = rt_min; rt <= 8; rt *= 2) {
+    if (wgs(rt) > 256) continue;
+    const int ks = g4_splits(L, rows, wgs(rt));
+    const int64_t fill = wgs(rt) * ks;
+    if (wgs(rt) > 128 || fill >= 192) { best = rt; best_ks = ks; break; }
+    if (fill > best_fill) { best_fill = fill; best = rt; best_ks = ks; }
+  }
+  if (best) { rt_out = best; ks_out = best_ks; return; }
+  // more than one round even on 256-row blocks: the shape that wastes least of its last round, small blocks discounted for the
+  // dequantisation they repeat (Qwen3-4B gate_up 1024 rows: 304 blocks of 256 rows = 1.19 rounds 147 us, 1216 of 64 rows 129 us)
+  best = 8;
+  double best_eff = 0.0;
+  for (int rt = 8; rt >= rt_min; rt /= 2) {
+    const double w = (double)wgs(rt), eff = w / (double)(((int64_t)(w + 255) / 256) * 256) * (rt == 8 ? 1.0 : (rt == 4 ? 0.95 : 0.85));
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = rt; }
+  }
+  rt_out = best;
+  ks_out = 1;
+}
+int gemm4_row_tiles(const paro_linear_t* L, int64_t rows) {
+  if (g4_tune) {
+    const int rt = g4_env("PARO_GEMM4_RT");
+    if (rt >= 2 && rt <= 8) return rt;
+  }
+  int rt, ks;
+  g4_shape(L, rows, rt, ks);
+  return rt;
+}
+int gemm4_ksplit(const paro_linear_t* L, int64_t rows) {
+  if (g4_tune) {
+    const int ks = g4_env("PARO_GEMM4_KS"), G = (int)(L->K / 128);
+    if (ks >= 1) return ks > G ? G : ks;
+  }
+  int rt, ks;
+  g4_shape(L, rows, rt, ks);
+  return ks;
 }
 }  // namespace paro
 
@@ -451,10 +515,8 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     return fail(PARO_ERR_INVALID, "variant must be 0 (auto), 1, 2 or 4 (got %d; 3 -- the round-1 256 x 256 kernel -- was removed in ABI v11)", variant);
   const bool f16in = L->act_dtype == PARO_DTYPE_F16;
   if (variant == 2 && !f16in) return fail(PARO_ERR_UNSUPPORTED, "GEMM variant 2 is fp16-only; bf16 runs variant 1 or 4");
-  // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) for 33..192 rows (64- .. 192-row
-  // blocks) and when there are >= 256 rows and enough 256 x 256 tiles to cover the CUs; fp16 below that -> 256 x 128 tile with a K-split at small M;
-  // bf16 below that -> the 128 x 128 kernel.
-  const int64_t wide_wgs = ((L->N + 255) / 256) * ((rows + 255) / 256);
+  // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) from 33 rows on (64- / 128- / 256-row blocks by
+  // gemm4_row_tiles); below that (the GEMV's range: only explicit calls get here) fp16 -> 256 x 128 tile with a K-split, bf16 -> the 128 x 128 kernel.
   const int qs = 128 / quant_group(L->group_size);
   if (qs == 2 && variant == 2)
     return fail(PARO_ERR_UNSUPPORTED, "group_size 64 runs GEMM variant 1 or 4 (variant 2 is built for group_size 128)");
@@ -463,12 +525,11 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     // 33..192 rows (batched decode, short prefill): variant 4 with 64- .. 192-row blocks (32-row steps) and a K-split -- 256-column
     // blocks halve the re-reads of the activation tile, no padding rows are staged or multiplied (Llama-3-8B gate_up
     // 64 rows: 67 -> 34 us, down 42 -> 30, qkv 128 rows: 42 -> 31)
-    if (rows >= 33 && rows <= 192) v = 4;
-    else if (rows >= 256 && wide_wgs >= 192) v = 4;
+    if (rows >= 33) v = 4;   // (round 6: with 64- / 128-row blocks variant 4 is ahead of the 256 x 128 kernel on narrow grids above 192 rows too -- gemm4_row_tiles)
     else if (f16in && rows > 16 && qs == 1) v = 2;
     else v = 1;
   }
-  const int rt4 = gemm4_row_tiles(rows);
+  const int rt4 = gemm4_row_tiles(L, rows);
   const int ksplit_req = v == 2 ? gemm_ksplit(L, rows) : (v == 4 && diag == 0 ? gemm4_ksplit(L, rows) : 1);
   const int64_t xrot_bytes = (int64_t)L->n_parts * rows * L->K * 2;
   const int64_t need = PARO_WS_COUNTER_BYTES + xrot_bytes + (ksplit_req > 1 ? 256 + (int64_t)ksplit_req * rows * L->N * 4 : 0);

@@ -679,6 +679,9 @@ def argmax_advance(workspace: torch.Tensor, vocab: int, token: torch.Tensor, pos
 _workspaces: dict = {}
 
 
+_retired_workspaces = []
+
+
 def get_workspace(device: torch.device, nbytes: int, stream=None) -> torch.Tensor:
     """Zero-initialised scratch shared by all layers that run on one (device, stream): split-K granules + arrival
     counters + status word, rotated activations of the unfused routes, fp32 partial tiles.
@@ -694,6 +697,10 @@ def get_workspace(device: torch.device, nbytes: int, stream=None) -> torch.Tenso
     key = (device.type, idx, None if stream is None else int(stream.cuda_stream))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            # a HIP graph captured earlier holds the OLD buffer's address: it stays allocated (replays keep writing their granules and
+            # rotated rows there), only new calls move to the larger one
+            _retired_workspaces.append(ws)
         ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device(device.type, idx))
         _workspaces[key] = ws
     return ws
