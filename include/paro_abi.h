@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PARO_ABI_VERSION 18
+#define PARO_ABI_VERSION 19
 
 /* element types of activations / rotation parameters */
 #define PARO_DTYPE_F32 0
@@ -413,6 +413,23 @@ int paro_attn_decode_split(const void* qkv, const float* qkv_parts, int64_t norm
                            float eps, float scale, int n_heads, int n_kv_heads, int head_dim, int max_positions, int act_dtype,
                            void* workspace, int64_t workspace_bytes, void* stream);
 int paro_attn_finish(const float* attn_parts, int n_heads, int head_dim, void* out, int act_dtype, void* stream);
+
+/* v19 -- the PROMPT pass of the decode harness: the element-wise work between a decoder layer's four fused linears at
+ * `rows` prompt positions, three launches instead of ~45 framework operators per layer.  The reference's prompt pass is HF's modelling
+ * code under generate() (transformers/generator.py:37-67); the harness folds the RMSNorm weights into the consumers' channel scales,
+ * which leaves the per-row scalar.  csrc/prompt.hip states the rounding points (those of the framework expressions they replace).
+ *   paro_prompt_row_rms    rs[t] = rsqrt(mean_k h[t][k]^2 + eps), fp32 [rows]; hidden a multiple of 8
+ *   paro_prompt_qkv_post   qkv [rows][(n_heads + 2 n_kv_heads) head_dim] = the merged projection's raw output; * rs[t] (NULL: 1), q / k
+ *                          per-head RMSNorm with q_norm_w / k_norm_w [head_dim] (NULL: none), rotary embedding of positions pos0 + t from
+ *                          rope fp32 [max_positions][head_dim] (cos | sin halves) -> q_out [rows][n_heads][head_dim], k_out / v_out
+ *                          [rows][n_kv_heads][head_dim] AND the decode caches kcache [n_kv_heads][max_positions][head_dim], vcache
+ *                          [n_kv_heads][head_dim][max_positions] (paro_attn_decode's layouts); head_dim even, <= 128
+ *   paro_prompt_silu_mul   out[t][i] = silu(g) * u,  g / u = gate_up[t][i | inter + i] * rs[t] (NULL: 1); inter a multiple of 8 */
+int paro_prompt_row_rms(const void* h, float* rs, int64_t rows, int64_t hidden, float eps, int act_dtype, void* stream);
+int paro_prompt_qkv_post(const void* qkv, const float* rs, const void* q_norm_w, const void* k_norm_w, const float* rope,
+                         void* q_out, void* k_out, void* v_out, void* kcache, void* vcache, int64_t rows, int pos0,
+                         int n_heads, int n_kv_heads, int head_dim, int max_positions, float eps, int act_dtype, void* stream);
+int paro_prompt_silu_mul(const void* gate_up, const float* rs, void* out, int64_t rows, int64_t inter, int act_dtype, void* stream);
 
 
 /* Qwen3.5 in the decode harness (v13; BASELINE configs 3 and 5): the hybrid decoder's token mixers at batch 1, following transformers'

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void
 
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's runtime
 
-PARO_ABI_VERSION = 18
+PARO_ABI_VERSION = 19
 PARO_MAX_PARTS = 8
 PARO_WS_COUNTER_BYTES = 16384
 PARO_WS_STATUS_OFFSET = PARO_WS_COUNTER_BYTES - 4
@@ -60,6 +60,9 @@ EXPORTS = (
     "paro_gemv_parts_count",
     "paro_attn_tail_supported",
     "paro_parts_finish",
+    "paro_prompt_row_rms",
+    "paro_prompt_qkv_post",
+    "paro_prompt_silu_mul",
     "paro_allreduce_buffer_bytes",
     "paro_allreduce_buffer_create",
     "paro_allreduce_buffer_open",
@@ -265,6 +268,13 @@ def load() -> ctypes.CDLL:
     lib.paro_gemv_parts_count.argtypes = [POINTER(ParoLinearDesc)]
     lib.paro_attn_tail_supported.restype = c_int
     lib.paro_attn_tail_supported.argtypes = [POINTER(ParoLinearDesc), c_int, c_int, c_int, c_int]
+    lib.paro_prompt_row_rms.restype = c_int
+    lib.paro_prompt_row_rms.argtypes = [c_void_p, c_void_p, c_int64, c_int64, ctypes.c_float, c_int, c_void_p]
+    lib.paro_prompt_qkv_post.restype = c_int
+    lib.paro_prompt_qkv_post.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int64, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p]
+    lib.paro_prompt_silu_mul.restype = c_int
+    lib.paro_prompt_silu_mul.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]
     lib.paro_parts_finish.restype = c_int
     lib.paro_parts_finish.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]
     lib.paro_allreduce_buffer_bytes.restype = c_int64

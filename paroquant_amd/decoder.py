@@ -489,6 +489,24 @@ class ParoDecoderLM:
         def headnorm(x, w):
             return x if w is None else ((x.float() * rs(x)).to(dt) * w)
 
+        # The element-wise work between the linears: three launches per layer (csrc/prompt.hip, ABI v19 -- row RMS, qkv post-processing
+        # into the attention's inputs and the decode caches, SiLU * up) instead of ~45 framework operators, which at 128 rows cost more
+        # than the linears (Qwen3-4B time to first token 16.8 -> profiles/NOTES.md 6.10).  PARO_PROMPT_TORCH=1: the framework expressions.
+        if c.head_dim <= 128 and os.environ.get("PARO_PROMPT_TORCH", "0") != "1":
+            sdpa = torch.nn.functional.scaled_dot_product_attention
+            for L in self.layers:
+                q, k, v = ops.prompt_qkv_post(L.qkv.apply(h), ops.prompt_row_rms(h, c.rms_eps), self.rope, L.kcache, L.vcache, self.nh, self.nkv,
+                                              c.head_dim, L.q_norm, L.k_norm, c.rms_eps)
+                att = sdpa(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None], is_causal=True,
+                           enable_gqa=self.nh != self.nkv)[0].transpose(0, 1).reshape(T, -1)
+                h = h + reduce_rows(L.o.apply(att.contiguous()))
+                act = ops.prompt_silu_mul(L.gate_up.apply(h), ops.prompt_row_rms(h, c.rms_eps))
+                h = h + reduce_rows(L.down.apply(act))
+            logits = torch.matmul(self._final_norm(h[-1:]), self.lm_head.t())
+            self.out_tokens[:T] = ids.to(self.device)
+            self.tok.copy_(torch.argmax(logits, dim=-1))
+            self.pos.fill_(T)
+            return logits
         for L in self.layers:
             qkv = (L.qkv.apply(h).float() * rs(h)).to(dt)          # norm weight is folded into the channel scales
             q, k, v = qkv.split([self.nh * c.head_dim, self.nkv * c.head_dim, self.nkv * c.head_dim], dim=-1)   # this rank's heads

@@ -594,6 +594,66 @@ def attn_finish(attn_parts: torch.Tensor, n_heads: int, head_dim: int, dtype: to
     return y
 
 
+# ---- prompt pass of the decode harness (ABI v19, csrc/prompt.hip): the element-wise work between a layer's four fused linears at T rows
+
+def prompt_row_rms(h: torch.Tensor, eps: float) -> torch.Tensor:
+    """``rs[t] = rsqrt(mean(h[t]^2) + eps)``, float32 ``[T]`` (``paro_prompt_row_rms``): the scalar an RMSNorm leaves once its weight is
+    folded into the consumer's channel scales."""
+    if h.dim() != 2 or not h.is_contiguous() or h.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("h must be a contiguous [T, hidden] fp16 / bf16 tensor")
+    rs = torch.empty(h.size(0), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        nat.check(nat.load().paro_prompt_row_rms(h.data_ptr(), rs.data_ptr(), int(h.size(0)), int(h.size(1)), float(eps), nat.dtype_code(h.dtype),
+                                                 nat.current_stream_ptr(h.device)))
+    return rs
+
+
+def prompt_qkv_post(qkv: torch.Tensor, rs: Optional[torch.Tensor], rope: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor,
+                    n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6, pos0: int = 0):
+    """The merged qkv projection's raw output ``[T, (n_heads + 2 n_kv_heads) head_dim]`` -> row scale, q / k head RMSNorm, rotary embedding of
+    positions ``pos0 + t`` -> ``(q [T, n_heads, hd], k [T, n_kv_heads, hd], v [T, n_kv_heads, hd])`` and the decode caches
+    (``kcache [n_kv_heads, T_max, hd]``, ``vcache [n_kv_heads, hd, T_max]``) in one launch (``paro_prompt_qkv_post``)."""
+    T = int(qkv.size(0))
+    dt = qkv.dtype
+    if qkv.dim() != 2 or not qkv.is_contiguous() or qkv.size(1) != (n_heads + 2 * n_kv_heads) * head_dim or dt not in (torch.float16, torch.bfloat16):
+        raise ValueError("qkv must be a contiguous [T, (n_heads + 2 n_kv_heads) head_dim] fp16 / bf16 tensor")
+    T_max = int(kcache.size(1))
+    if tuple(kcache.shape) != (n_kv_heads, T_max, head_dim) or tuple(vcache.shape) != (n_kv_heads, head_dim, T_max) or kcache.dtype != dt \
+            or vcache.dtype != dt or not kcache.is_contiguous() or not vcache.is_contiguous():
+        raise ValueError("kcache [n_kv_heads, T_max, head_dim] / vcache [n_kv_heads, head_dim, T_max] must be contiguous tensors of qkv's dtype")
+    if rope.dtype != torch.float32 or not rope.is_contiguous() or rope.dim() != 2 or rope.size(1) != head_dim or rope.size(0) < pos0 + T:
+        raise ValueError("rope must be a contiguous float32 [positions, head_dim] table (cos | sin halves) covering pos0 + T")
+    for w in (q_norm_w, k_norm_w):
+        if w is not None and (w.dtype != dt or w.numel() != head_dim or not w.is_contiguous()):
+            raise ValueError("q_norm_w / k_norm_w must be contiguous [head_dim] tensors of qkv's dtype")
+    if rs is not None and (rs.dtype != torch.float32 or rs.numel() != T or not rs.is_contiguous()):
+        raise ValueError("rs must be a contiguous float32 [T] tensor")
+    q = torch.empty(T, n_heads, head_dim, dtype=dt, device=qkv.device)
+    k = torch.empty(T, n_kv_heads, head_dim, dtype=dt, device=qkv.device)
+    v = torch.empty(T, n_kv_heads, head_dim, dtype=dt, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        nat.check(nat.load().paro_prompt_qkv_post(qkv.data_ptr(), rs.data_ptr() if rs is not None else None,
+                                                  q_norm_w.data_ptr() if q_norm_w is not None else None,
+                                                  k_norm_w.data_ptr() if k_norm_w is not None else None, rope.data_ptr(), q.data_ptr(), k.data_ptr(),
+                                                  v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), T, int(pos0), int(n_heads), int(n_kv_heads),
+                                                  int(head_dim), T_max, float(eps), nat.dtype_code(dt), nat.current_stream_ptr(qkv.device)))
+    return q, k, v
+
+
+def prompt_silu_mul(gate_up: torch.Tensor, rs: Optional[torch.Tensor]) -> torch.Tensor:
+    """``silu(gate * rs) * (up * rs)`` of the merged gate_up projection's raw output ``[T, 2 I]`` -> ``[T, I]`` (``paro_prompt_silu_mul``)."""
+    if gate_up.dim() != 2 or not gate_up.is_contiguous() or gate_up.size(1) % 16 or gate_up.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("gate_up must be a contiguous [T, 2 I] fp16 / bf16 tensor, I a multiple of 8")
+    T, I = int(gate_up.size(0)), int(gate_up.size(1)) // 2
+    if rs is not None and (rs.dtype != torch.float32 or rs.numel() != T or not rs.is_contiguous()):
+        raise ValueError("rs must be a contiguous float32 [T] tensor")
+    out = torch.empty(T, I, dtype=gate_up.dtype, device=gate_up.device)
+    with torch.cuda.device(gate_up.device):
+        nat.check(nat.load().paro_prompt_silu_mul(gate_up.data_ptr(), rs.data_ptr() if rs is not None else None, out.data_ptr(), T, I,
+                                                  nat.dtype_code(gate_up.dtype), nat.current_stream_ptr(gate_up.device)))
+    return out
+
+
 def attn_decode(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, rope: torch.Tensor,
                 n_heads: int, n_kv_heads: int, head_dim: int, q_norm_w=None, k_norm_w=None, eps: float = 1e-6,
                 out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, norm_dim: int = 0,

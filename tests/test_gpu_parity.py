@@ -1716,3 +1716,50 @@ def _overlap_checks(dev, pk, x, sample, ideal, y_single):
     for _ in range(3):
         y2 = pk.apply(x)
     assert torch.equal(y2, y_eager)
+
+
+# ---------------------------------------------------------------- prompt pass of the decode harness (ABI v19, csrc/prompt.hip)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("T,nh,nkv,hd,qk_norm,pos0", [(1, 4, 2, 128, True, 0), (37, 8, 2, 128, True, 5), (128, 6, 3, 64, False, 0), (9, 5, 1, 32, True, 100)])
+def test_prompt_pass_kernels_match_framework_expressions(dev, dtype, tol, T, nh, nkv, hd, qk_norm, pos0):
+    """paro_prompt_row_rms / paro_prompt_qkv_post / paro_prompt_silu_mul against the framework expressions they replace in
+    `ParoDecoderLM.prefill` (themselves HF's prompt pass with the RMSNorm weights folded away, transformers/generator.py:37-67): the row
+    scale, q / k head RMSNorm, rotary embedding, the attention's inputs and BOTH decode caches (K position-major, V position-contiguous);
+    SiLU * up.  Tolerance: two roundings of the activation type."""
+    from paroquant_amd import ops
+    gen = torch.Generator(device=dev); gen.manual_seed(T * 131 + hd)
+    hidden, inter, T_max, eps = 256, 384, 160, 1e-6
+    h = torch.randn(T, hidden, device=dev, generator=gen).to(dtype)
+    rs_ref = torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + eps)
+    rs = ops.prompt_row_rms(h, eps)
+    assert rs.shape == (T,) and torch.allclose(rs, rs_ref[:, 0], rtol=1e-5, atol=0)
+    raw = torch.randn(T, (nh + 2 * nkv) * hd, device=dev, generator=gen).to(dtype)
+    qn = (1.0 + 0.05 * torch.randn(hd, device=dev, generator=gen)).to(dtype) if qk_norm else None
+    kn = (1.0 + 0.05 * torch.randn(hd, device=dev, generator=gen)).to(dtype) if qk_norm else None
+    ang = torch.arange(T_max, dtype=torch.float32, device=dev)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, device=dev).float() / hd))[None, :]
+    rope = torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+    kc = torch.zeros(nkv, T_max, hd, dtype=dtype, device=dev)
+    vc = torch.zeros(nkv, hd, T_max, dtype=dtype, device=dev)
+    q, k, v = ops.prompt_qkv_post(raw, rs, rope, kc, vc, nh, nkv, hd, qn, kn, eps, pos0=pos0)
+    # the framework expressions (decoder.py, PARO_PROMPT_TORCH=1)
+    half = hd // 2
+    cos, sin = rope[pos0:pos0 + T, :half].to(dtype)[:, None, :], rope[pos0:pos0 + T, half:].to(dtype)[:, None, :]
+    rsx = lambda x: torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps)
+    rot = lambda x: torch.cat([x[..., :half] * cos - x[..., half:] * sin, x[..., half:] * cos + x[..., :half] * sin], dim=-1)
+    hn = lambda x, w: x if w is None else ((x.float() * rsx(x)).to(dtype) * w)
+    qkv = (raw.float() * rs_ref).to(dtype)
+    qr, kr, vr = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+    qr, kr, vr = rot(hn(qr.view(T, nh, hd), qn)), rot(hn(kr.view(T, nkv, hd), kn)), vr.view(T, nkv, hd)
+    close = lambda a, b: (a.float() - b.float()).abs().max().item() <= tol * max(b.float().abs().max().item(), 1e-6)
+    assert close(q, qr) and close(k, kr) and close(v, vr)
+    assert torch.equal(kc[:, pos0:pos0 + T], k.transpose(0, 1)) and torch.equal(vc[:, :, pos0:pos0 + T], v.permute(1, 2, 0))
+    assert not kc[:, :pos0].any() and not kc[:, pos0 + T:].any() and not vc[:, :, :pos0].any() and not vc[:, :, pos0 + T:].any()
+    gu = torch.randn(T, 2 * inter, device=dev, generator=gen).to(dtype)
+    act = ops.prompt_silu_mul(gu, rs)
+    gus = (gu.float() * rs_ref).to(dtype)
+    assert act.shape == (T, inter) and close(act, torch.nn.functional.silu(gus[:, :inter]) * gus[:, inter:])
+    with pytest.raises(RuntimeError, match="head_dim"):
+        ops.prompt_qkv_post(torch.zeros(1, 4 * 256, dtype=dtype, device=dev), None, torch.zeros(8, 256, device=dev), torch.zeros(1, 8, 256, dtype=dtype, device=dev),
+                            torch.zeros(1, 256, 8, dtype=dtype, device=dev), 2, 1, 256)
