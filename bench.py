@@ -506,6 +506,37 @@ def prefill_table(dev, rows: int = 65536, launches: int = 5):
     return out
 
 
+def mid_prefill_table(dev, model: str = "llama3-8b", row_counts=(128, 512, 2048), calls: int = 10):
+    """Medium prefill through the per-call operator (round 6, session 3): the prompt lengths a server actually sees.  Per linear of `model` and
+    row count: us per `PackedParoWeights.apply` call (rotation pre-pass + W4A16 MFMA GEMM on the block shape gemm.hip `g4_shape` picks),
+    events around `calls` back-to-back calls after two warm-ups, weights far past the caches between shapes.  The sweep behind the shapes:
+    tools/sweep_gemm4.py, profiles/r06_sweep_gemm4_*.jsonl."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    out = []
+    for name, K, sizes, _ in layer_shapes(model):
+        pk = synth_packed(K, sizes, dev, gen)
+        pk.prepare_prefill(torch.float16)
+        for rows in row_counts:
+            x = torch.randn(rows, K, device=dev, dtype=torch.float32, generator=gen).half()
+            for _ in range(2):
+                pk.apply(x)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(calls):
+                pk.apply(x)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / calls
+            out.append({"linear": f"{model} {name}", "M": rows, "K": K, "N": sum(sizes), "us_per_call": round(us, 2),
+                        "TFLOPs": round(2.0 * rows * K * sum(sizes) / us / 1e6, 1)})
+        del pk
+        torch.cuda.empty_cache()
+    return {"rows": out, "note": "same weights every call (cache-resident for the narrow linears): an upper bound of the call rate, for the shape rule's A/B see "
+                                 "profiles/r06_sweep_gemm4_*.jsonl (rotating weight copies).  Round 5's rule on the same protocol: profiles/r06_sweep_gemm4_llama3-8b_before.jsonl"}
+
+
 def batched_decode_steps(dev, model: str = "qwen3-4b", n_layers: int = 12, row_counts=(1, 2, 4, 8, 16, 32, 64), steps: int = 20, warmup: int = 3):
     """Batched decode THROUGH THE BOUNDARY (what a vLLM decode batch reaches: `ParoQuantLinearMethod.apply` is M-agnostic, vllm/plugin.py:281-311),
     driver-visible: the bench step of the headline workload's first `n_layers` layers at several row counts on the
@@ -1219,6 +1250,10 @@ def run(args, rank: int, local_rank: int, world: int):
                 ex["batched_decode"] = batched_decode_steps(dev)
             except Exception as e:
                 ex["batched_decode"] = {"error": f"{type(e).__name__}: {e}"}
+            try:       # medium prefill (128 / 512 / 2048 rows) per Llama-3-8B linear through the boundary
+                ex["mid_prefill"] = mid_prefill_table(dev)
+            except Exception as e:
+                ex["mid_prefill"] = {"error": f"{type(e).__name__}: {e}"}
             try:       # the launch shapes of the headline workload's layers, MEASURED (paroquant_amd/autotune.py), plus three shapes no sweep saw
                 from paroquant_amd import autotune as _at
                 rows_at = []
