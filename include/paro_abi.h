@@ -341,6 +341,10 @@ int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int6
  *       word is dequantised exactly once per workgroup), 32x32x16 MFMA, f16 and native bf16.
  * Every variant computes the same function; tests force each one at small sizes through this knob. */
 #define PARO_GEMM_AUTO 0
+/* v19: the block shape GEMM variant 4 runs `rows` rows of this layer with -- rows per block (64 / 128 / 256) and K-splits (csrc/gemm.hip
+ * g4_shape: one round of workgroups over the 256 CUs with as few fp32 partial tiles as possible) -- host-only, touches no device memory:
+ * for tooling, logs and tests of the rule, as paro_gemv_launch_shape is for the GEMV. */
+int paro_gemm_launch_shape(const paro_linear_t* L, int64_t rows, int* block_rows, int* ksplit);
 int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                     int64_t workspace_bytes, int variant, void* stream);
 

@@ -60,6 +60,7 @@ EXPORTS = (
     "paro_gemv_parts_count",
     "paro_attn_tail_supported",
     "paro_parts_finish",
+    "paro_gemm_launch_shape",
     "paro_prompt_row_rms",
     "paro_prompt_qkv_post",
     "paro_prompt_silu_mul",
@@ -268,6 +269,8 @@ def load() -> ctypes.CDLL:
     lib.paro_gemv_parts_count.argtypes = [POINTER(ParoLinearDesc)]
     lib.paro_attn_tail_supported.restype = c_int
     lib.paro_attn_tail_supported.argtypes = [POINTER(ParoLinearDesc), c_int, c_int, c_int, c_int]
+    lib.paro_gemm_launch_shape.restype = c_int
+    lib.paro_gemm_launch_shape.argtypes = [POINTER(ParoLinearDesc), c_int64, POINTER(c_int), POINTER(c_int)]
     lib.paro_prompt_row_rms.restype = c_int
     lib.paro_prompt_row_rms.argtypes = [c_void_p, c_void_p, c_int64, c_int64, ctypes.c_float, c_int, c_void_p]
     lib.paro_prompt_qkv_post.restype = c_int

@@ -498,6 +498,17 @@ int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, in
 
 }
 
+// host-only: the block shape variant 4 runs `rows` rows of this layer with (tooling, logs, tests of the rule)
+extern "C" int paro_gemm_launch_shape(const paro_linear_t* L, int64_t rows, int* block_rows, int* ksplit) {
+  using namespace paro;
+  int rc = validate_linear(L);
+  if (rc != PARO_OK) return rc;
+  if (rows < 1 || !block_rows || !ksplit) return fail(PARO_ERR_INVALID, "paro_gemm_launch_shape: bad arguments");
+  *block_rows = 32 * gemm4_row_tiles(L, rows);
+  *ksplit = gemm4_ksplit(L, rows);
+  return PARO_OK;
+}
+
 extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, int64_t rows, void* workspace,
                                int64_t workspace_bytes, int variant, void* stream) {
   using namespace paro;

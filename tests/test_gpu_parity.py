@@ -1763,3 +1763,30 @@ def test_prompt_pass_kernels_match_framework_expressions(dev, dtype, tol, T, nh,
     with pytest.raises(RuntimeError, match="head_dim"):
         ops.prompt_qkv_post(torch.zeros(1, 4 * 256, dtype=dtype, device=dev), None, torch.zeros(8, 256, device=dev), torch.zeros(1, 8, 256, dtype=dtype, device=dev),
                             torch.zeros(1, 256, 8, dtype=dtype, device=dev), 2, 1, 256)
+
+
+@pytest.mark.gpu
+def test_captured_graph_survives_workspace_growth(dev):
+    """A HIP graph holds the address of the workspace it was captured on; a later, larger call grows the shared workspace
+    (`ops.get_workspace`).  The old buffer must stay allocated: replays keep writing their K-split granules / rotated rows there
+    (round 6: it was dropped, and a replay wrote through a dangling pointer -- found by tools/sweep_gemm4.py as a GPU memory fault)."""
+    from paroquant_amd import ops
+    K, sizes = 4096, [2560]
+    L = po.make_layer(4242, K, sizes)
+    pk = _packed(L, dev)
+    x = torch.randn(24, K, device=dev, dtype=torch.float16)        # 17..32 rows: pre-pass into the workspace + K-split granules
+    y0 = pk.apply(x).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = pk.apply(x)
+    before = ops.get_workspace(dev, 1).data_ptr()
+    big = torch.randn(3000, K, device=dev, dtype=torch.float16)
+    ops.get_workspace(dev, ops.get_workspace(dev, 1).numel() * 2 + (64 << 20))     # force the growth, then use the new buffer
+    yb = pk.apply(big)
+    assert ops.get_workspace(dev, 1).data_ptr() != before and torch.isfinite(yb.float()).all()
+    junk = [torch.full((8 << 20,), 7, dtype=torch.int32, device=dev) for _ in range(4)]   # would land in a freed workspace
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and all(int(j[0]) == 7 and int(j[-1]) == 7 for j in junk)

@@ -295,6 +295,41 @@ def test_round3_launch_shape_heuristics():
     assert chain(*l8["gate_up_proj"], 16)[0] == 1          # wide outputs own whole column blocks, no split
 
 
+def test_gemm_block_shape_rule():
+    """The block shape GEMM variant 4 runs a call of 33..4095 rows with (csrc/gemm.hip g4_shape, round 6; calibrated with
+    tools/sweep_gemm4.py, profiles/r06_sweep_gemm4_*.jsonl: within 8.5 % of the best of 18 shapes on 56 points) -- host-only query."""
+    import bench
+    from paroquant_amd import _native as nat
+    lib = nat.load()
+
+    def shape(K, sizes, rows):
+        d = nat.ParoLinearDesc()
+        d.K, d.N, d.n_parts, d.krot, d.act_dtype, d.wq_order = K, sum(sizes), len(sizes), 8, nat.DTYPE_F16, 0
+        for i, s_ in enumerate(sizes):
+            d.part_cols[i] = s_
+        for f in ("wq", "sz", "rot", "pairs", "theta", "channel_scales"):
+            setattr(d, f, 0x1000)          # never dereferenced on the host
+        br, ks = ctypes.c_int(0), ctypes.c_int(0)
+        nat.check(lib.paro_gemm_launch_shape(ctypes.byref(d), rows, ctypes.byref(br), ctypes.byref(ks)))
+        return br.value, ks.value
+
+    by = {m: {n: (K, s) for n, K, s, _ in bench.layer_shapes(m)} for m in ("llama3-8b", "qwen3-4b")}
+    l8, q4 = by["llama3-8b"], by["qwen3-4b"]
+    # one round of ~192..256 workgroups from the smallest block: few K-splits (their fp32 partial tiles go through memory twice)
+    assert shape(*l8["qkv_proj"], 128) == (64, 4) and shape(*l8["qkv_proj"], 256) == (64, 2) and shape(*l8["qkv_proj"], 512) == (64, 1)
+    assert shape(*l8["qkv_proj"], 1024) == (128, 1) and shape(*l8["qkv_proj"], 2048) == (256, 1)
+    assert shape(*l8["o_proj"], 128) == (64, 4) and shape(*l8["o_proj"], 512) == (64, 2) and shape(*l8["o_proj"], 1024) == (64, 1) and shape(*l8["o_proj"], 2048) == (128, 1)
+    # an unsplit grid over more than half of the CUs beats a fuller split one; wide outputs take the block that keeps one round
+    assert shape(*q4["gate_up_proj"], 128) == (64, 1) and shape(*l8["gate_up_proj"], 256) == (128, 1) and shape(*l8["gate_up_proj"], 512) == (256, 1)
+    # deep K: more splits at few rows (capped at K / (4 rows): partial traffic <= ~4x the weight bytes), 128-row blocks above 256 rows
+    assert shape(*q4["down_proj"], 128) == (64, 8) and shape(*q4["down_proj"], 384) == (128, 6) and shape(*l8["down_proj"], 512) == (128, 4)
+    assert shape(*l8["down_proj"], 1024) == (128, 2) and shape(*l8["down_proj"], 2048) == (128, 1)
+    # more than one round even on 256-row blocks: the shape that wastes least of its last round (304 blocks of 256 rows = 1.19 rounds lose)
+    assert shape(*q4["gate_up_proj"], 1024) == (64, 1) and shape(*q4["gate_up_proj"], 2048) == (128, 1)
+    # the ends: 33..64 rows one 64-row block, prefill proper 256-row blocks unsplit
+    assert shape(*l8["gate_up_proj"], 40) == (64, 2) and shape(*l8["qkv_proj"], 65536) == (256, 1) and shape(*l8["o_proj"], 4096) == (256, 1)
+
+
 def test_gemv_launch_shape_heuristics():
     """The launch shapes the dispatcher picks for the Llama-3-8B / Qwen3-4B / Llama-3-70B linears (calibrated on
     MI355X with tools/sweep_gemv.py) -- host-only query, no device memory is touched."""
