@@ -339,7 +339,10 @@ int paro_w4a16_gemv_experts(const paro_linear_t* L, const void* x, void* y, int6
  *   (3 = the round-1 256x256 kernel: removed in v11, the value is refused);
  *   4 = 256x256 tile, 8 waves as 1 x 8 (every wave owns 32 distinct columns over all 256 rows: each INT4
  *       word is dequantised exactly once per workgroup), 32x32x16 MFMA, f16 and native bf16.
- * Every variant computes the same function; tests force each one at small sizes through this knob. */
+ * Every variant computes the same function; tests force each one at small sizes through this knob.
+ * (41..43: timing-only ablation builds of variant 4, wrong results.  44: EXPERIMENT -- the rotation fused into variant 4's LDS stage, one
+ * launch, no rotated copy of x; needs L->rmat, fp16, group_size 128; same bits as the pre-pass + variant 4 and 2.4..3.3x slower at
+ * M = 65536, profiles/NOTES.md 6.11 -- never selected automatically.) */
 #define PARO_GEMM_AUTO 0
 /* v19: the block shape GEMM variant 4 runs `rows` rows of this layer with -- rows per block (64 / 128 / 256) and K-splits (csrc/gemm.hip
  * g4_shape: one round of workgroups over the 256 CUs with as few fp32 partial tiles as possible) -- host-only, touches no device memory:

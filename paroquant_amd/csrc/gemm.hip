@@ -518,12 +518,14 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   if (rows < 0 || rows > 0x7fffffff) return fail(PARO_ERR_INVALID, "rows out of range");
   if (!x || !y) return fail(PARO_ERR_INVALID, "null pointer");
   int diag = 0;
-  if (variant >= 41 && variant <= 43) {   // ablation builds of variant 4 (wrong results; tools/bench_gemm.py)
+  if (variant >= 41 && variant <= 44) {   // ablation builds of variant 4 (41..43: wrong results; 44: the fused-rotation experiment, correct; tools/bench_gemm.py)
     diag = variant - 40;
     variant = 4;
   }
   if (variant < 0 || variant > 4 || variant == 3)
     return fail(PARO_ERR_INVALID, "variant must be 0 (auto), 1, 2 or 4 (got %d; 3 -- the round-1 256 x 256 kernel -- was removed in ABI v11)", variant);
+  if (diag == 4 && (!L->rmat || L->krot > 16))
+    return fail(PARO_ERR_INVALID, "GEMM variant 44 (rotation fused into the GEMM, experiment) needs the dense rotation matrices (paro_linear_t.rmat)");
   const bool f16in = L->act_dtype == PARO_DTYPE_F16;
   if (variant == 2 && !f16in) return fail(PARO_ERR_UNSUPPORTED, "GEMM variant 2 is fp16-only; bf16 runs variant 1 or 4");
   // ---- kernel choice.  Auto: variant 4 (256-column blocks, 1 x 8 waves, 32x32x16 MFMA) from 33 rows on (64- / 128- / 256-row blocks by
@@ -540,7 +542,7 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
     else if (f16in && rows > 16 && qs == 1) v = 2;
     else v = 1;
   }
-  const int rt4 = gemm4_row_tiles(L, rows);
+  const int rt4 = diag ? 8 : gemm4_row_tiles(L, rows);   // (the ablation / experiment builds exist for 256-row blocks)
   const int ksplit_req = v == 2 ? gemm_ksplit(L, rows) : (v == 4 && diag == 0 ? gemm4_ksplit(L, rows) : 1);
   const int64_t xrot_bytes = (int64_t)L->n_parts * rows * L->K * 2;
   const int64_t need = PARO_WS_COUNTER_BYTES + xrot_bytes + (ksplit_req > 1 ? 256 + (int64_t)ksplit_req * rows * L->N * 4 : 0);
@@ -552,7 +554,9 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   // overlap -- a GEMM workgroup holds 128 KB of LDS, a pre-pass workgroup 68 KB, a CU has 160 KB: profiles/r05_prefill_overlap.txt, NOTES 5.4;
   // the host branch was removed in round 6.)
   static const int env_sched = getenv("PARO_PREROT_SCHED") ? atoi(getenv("PARO_PREROT_SCHED")) : 1;   // 0: the stage kernel, as up to round 5 (A/B)
-  if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
+  if (diag == 4)                // variant 44: the rotation runs inside the GEMM on the un-rotated x -- no pre-pass, no rotated copy
+    rc = PARO_OK;
+  else if (L->rmat && rows >= 256)   // many rows: one dense 128x128 product per group on the matrix cores
     rc = launch_rotate_mfma(x, xrot, L->rmat, rows, L->K, L->n_parts, L->act_dtype, st);
   else if (L->rot && L->krot <= 8 && env_sched != 0)   // short prefill / batched decode: the schedule pre-pass (rotate.hip), plain rows
     rc = launch_prerot_sched(x, xrot, L->rot, L->channel_scales, rows, L->K, L->krot, L->n_parts, L->act_dtype, 0, st);
@@ -564,7 +568,8 @@ extern "C" int paro_w4a16_gemm(const paro_linear_t* L, const void* x, void* y, i
   a.wq = (const u32x4*)L->wq;
   a.sz = (const unsigned*)L->sz;
   a.bias = (const unsigned short*)L->bias;
-  a.xrot = xrot;
+  a.xrot = diag == 4 ? (const unsigned short*)x : xrot;
+  a.rmat = (const unsigned short*)L->rmat;
   a.y = (unsigned short*)y;
   a.K = (int)L->K;
   a.N = (int)L->N;

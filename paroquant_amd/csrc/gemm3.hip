@@ -143,6 +143,15 @@ struct Dequant<bf16> {
 // DIAG (energy / issue ablation on the power-limited chip, tools/bench_gemm.py --variants 41,42,43; wrong results):
 // 1 = no dequant (raw INT4 words as the weight operand), 2 = no fragment re-reads inside a group (the first
 // k-step's fragments are reused), 3 = both.  0 = the shipping kernel.
+// DIAG 4 (variant 44; CORRECT results, bit-identical to pre-pass + variant 4): the north star's FUSED form -- "stages tiles in LDS, applies
+// the pairwise rotation ..., then feeds MFMA" (BASELINE.json) -- built to be MEASURED against the two launches that
+// ship.  The LDS-DMA slab of group g lands UN-rotated; wave w rotates row tile w of it in place as one dense product per group on the
+// matrix cores, x_rot = x R'^T with the matrices of the pre-pass (rmat[p][g][n][k]: 4 channel tiles x 8 k-steps = 32 MFMAs of 32x32x16
+// per wave and group beside the 64 of the GEMM itself -- the rotation is per (partition, group), and inside the GEMM it is repeated in
+// every 256-column block), rounds once to the activation type as the pre-pass does, writes it back through the slab's swizzle; one more
+// barrier; then the unchanged k-loop.  No rotated copy of x in HBM, one launch -- and 2.5 .. 3.4x the time of the two launches at
+// M = 65536 (a second cut with the matrix brought by LDS-DMA into the CU's last 32 KB of LDS and two interleaved MFMA chains: 3.3 ..
+// 3.7x): profiles/NOTES.md 6.11, profiles/r06_fused_rot_gemm*.  Kept as an experiment variant, never selected.
 // QS: quantisation groups per 128-channel slab (1: group_size 128; 2: group_size 64 -- k-steps 0..3 and 4..7 of a
 // slab are dequantised with different (scale, zero) words).
 // RT: 32-row tiles of the workgroup's row block (8 = 256 rows, the prefill shape; 1 / 2 / 4 = 32 / 64 / 128 rows for
@@ -173,7 +182,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int ltile0 = (cb - a.pt.cb_start[p]) * 16 + wave * 2;   // the wave's two 16-column tiles
   const int tile0 = a.pt.tile_start[p] + ltile0;
   const int nt = max(0, min(2, a.pt.tile_start[p + 1] - tile0));
-  const unsigned short* xp = a.xrot + (int64_t)p * a.rows * a.K;
+  constexpr bool FROT = DIAG == 4;
+  const unsigned short* xp = FROT ? a.xrot : a.xrot + (int64_t)p * a.rows * a.K;   // (fused rotation: x itself, shared by the partitions)
 
   const int n32 = lane & 31, kh = lane >> 5;
   const int jt = n32 >> 4, n = n32 & 15;
@@ -263,6 +273,36 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     const int nbuf = (g + 1 - g0) & 1;
     if constexpr (MORE) load_b(g + 1);
     const unsigned char* abuf = lds + ((g - g0) & 1) * (BMR * 256);
+    if constexpr (FROT) {
+      static_assert(!FROT || RT == 8, "the fused rotation is built for 256-row blocks (wave w rotates row tile w)");
+      // B operand: this wave's 32 rows of the un-rotated slab, all eight k-steps (the same fragment reads as the k-loop's)
+      vec8 xb[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xb[s] = *(const vec8*)(abuf + (a0 ^ (unsigned)(s << 5)) + wave * 8192);
+      const unsigned short* rm = a.rmat + ((int64_t)(p * a.G + g) * 128) * 128;
+      unsigned char* wbuf = lds + ((g - g0) & 1) * (BMR * 256) + wave * 8192 + n32 * 256;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {          // 32 rotated channels at a time: A operand = 32 rows of R' (n) x 16 k
+        f32x16 r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const vec8 ra = *(const vec8*)(rm + (ct * 32 + n32) * 128 + 16 * s + 8 * kh);
+          r = Mma32<AT>::run(ra, xb[s], r);
+        }
+        // D[i][j]: this lane holds row m = n32 (column j) and channels ct*32 + 8 q + 4 kh + (0..3): one 8-byte piece per q of the
+        // 16-byte slot ct*4 + q, physical slot = logical ^ (row & 15)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2 o;
+          o[0] = (unsigned)A::from_f32(r[4 * q + 0]) | ((unsigned)A::from_f32(r[4 * q + 1]) << 16);
+          o[1] = (unsigned)A::from_f32(r[4 * q + 2]) | ((unsigned)A::from_f32(r[4 * q + 3]) << 16);
+          *(u32x2*)(wbuf + ((((ct * 4 + q) ^ (n32 & 15)) & 15) << 4) + 8 * kh) = o;
+        }
+      }
+      __syncthreads();     // every wave's row tile is rotated before anyone multiplies by it
+    }
     vec8 af[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) af[rt] = *(const vec8*)(abuf + a0 + rt * 8192);
@@ -360,7 +400,10 @@ int launch_gemm3(const GemmArgs& a, int act_dtype, dim3 grid, hipStream_t st, in
   if (diag != 0) {
     if (qs == 2 || rt != 8 || act_dtype != PARO_DTYPE_F16 || a.ksplit > 1)
       return fail(PARO_ERR_UNSUPPORTED, "the ablation builds of GEMM variant 4 exist for fp16, group_size 128, 256-row blocks, no K-split only");
-    if (diag == 1)
+    if (diag == 4) {
+      if (!a.rmat) return fail(PARO_ERR_INVALID, "GEMM variant 44 (fused rotation) needs paro_linear_t.rmat");
+      hipLaunchKernelGGL((gemm3_kernel<f16, 4>), grid, dim3(512), 0, st, a);
+    } else if (diag == 1)
       hipLaunchKernelGGL((gemm3_kernel<f16, 1>), grid, dim3(512), 0, st, a);
     else if (diag == 2)
       hipLaunchKernelGGL((gemm3_kernel<f16, 2>), grid, dim3(512), 0, st, a);

@@ -21,6 +21,9 @@ struct GemmArgs {
   long long wq_estride = 0, sz_estride = 0;   // u32x4 / u32 elements between consecutive experts' packed buffers
   int n_experts = 0;                          // block_expert entries outside [0, n_experts) are skipped on the device
   int cb0 = 0;                                // variant 4: first column block of this launch (per-partition launches of a merged projection)
+  // variant 44 (the north star's fused prefill form, an EXPERIMENT build -- gemm3.hip DIAG 4): `xrot` is the UN-rotated x [rows][K] and every
+  // workgroup rotates the slab it stages with the dense per-group matrices rmat[p][g][n][k] (paro_linear_t.rmat) on the matrix cores
+  const unsigned short* rmat = nullptr;
 };
 
 }  // namespace paro

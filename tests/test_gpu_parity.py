@@ -1790,3 +1790,23 @@ def test_captured_graph_survives_workspace_growth(dev):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, y0) and all(int(j[0]) == 7 and int(j[-1]) == 7 for j in junk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sizes,rows", [(1024, [512, 272], 300), (512, [256], 256), (2560, [1024, 256, 256], 700), (384, [4096], 1000)])
+def test_fused_rotation_gemm_experiment_matches_two_launches(dev, K, sizes, rows):
+    """GEMM variant 44 -- the north star's fused form (the rotation applied to the LDS-staged slab inside the GEMM, one launch, no rotated
+    copy of x; gemm3.hip DIAG 4) -- is an experiment that LOSES by 2.5 .. 3.4x (profiles/r06_fused_rot_gemm_*.jsonl, NOTES 6.11) and is never
+    selected; it stays correct: the bits of the rotation pre-pass + variant 4, within tolerance of the oracle (plugin.py:288-306 semantics:
+    one rotation per merged partition)."""
+    from paroquant_amd import ops
+    L = po.make_layer(K + rows, K, sizes, bias=True)
+    pk = _packed(L, dev, L["bias"])
+    x = np.random.default_rng(rows).standard_normal((rows, K)).astype(np.float16)
+    y44 = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, True, 44)
+    y4 = ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, True, 4)
+    assert torch.equal(y44, y4)
+    ideal = po.paro_linear_merged(x, L["qweight"], L["qzeros"], L["scales"], L["theta"], L["pairs"], L["channel_scales"], sizes, L["bias"], ideal=True)
+    assert po.rel_err(_np(y44), ideal) < TIGHT_F16
+    with pytest.raises(RuntimeError, match="rmat|rotation matrices"):
+        ops.w4a16_gemm_forced(_t(x, dev), pk, pk.bias, False, 44)

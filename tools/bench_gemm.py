@@ -45,7 +45,7 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     variants = [int(v) for v in args.variants.split(",")]
-    bad = [v for v in variants if v not in (0, 1, 2, 4)]       # (variant 3 was removed in ABI v11)
+    bad = [v for v in variants if v not in (0, 1, 2, 4, 41, 42, 43, 44)]       # (variant 3 was removed in ABI v11)
     if bad:
         raise SystemExit(f"--variants: unknown GEMM variant(s) {bad}; the library builds 0 (auto), 1, 2 and 4")
     import bench
