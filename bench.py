@@ -497,10 +497,15 @@ def prefill_table(dev, rows: int = 65536, launches: int = 5):
             return e0.elapsed_time(e1) / launches
         ms = timed(lambda: pk.apply(x))
         ms_pre = timed(lambda: ops.rotate_parts(x, pk, out=xr))
+        try:      # the north star's one-launch form (rotation inside the GEMM's LDS stage), experiment variant 44: same bits, measured beside it
+            ms_fused = round(timed(lambda: ops.w4a16_gemm_forced(x, pk, None, True, 44)), 4)
+        except Exception as e:
+            ms_fused = f"{type(e).__name__}: {e}"[:80]
         flops = 2.0 * rows * K * sum(sizes)
         out.append({"linear": name, "M": rows, "K": K, "N": sum(sizes), "P": len(sizes), "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1),
                     "mfma_util": round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4), "prepass_ms": round(ms_pre, 4),
-                    "prepass_share": round(ms_pre / ms, 4), "timed_calls": launches, "kernel_launches_per_call": 2})
+                    "prepass_share": round(ms_pre / ms, 4), "timed_calls": launches, "kernel_launches_per_call": 2,
+                    "fused_rotation_experiment_ms": ms_fused})
         del pk, x, xr
         torch.cuda.empty_cache()
     return out
@@ -1239,7 +1244,9 @@ def run(args, rank: int, local_rank: int, world: int):
             try:       # the north star's second metric, driver-visible: prefill MFMA utilisation at M = 32 x 2048
                 ex["prefill"] = {"rows": prefill_table(dev), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
                                  "note": "fused linear per operator call at M = 65536 (BASELINE config 3's batch-32 x seq-2048 prefill): rotation pre-pass on the "
-                                         "matrix cores + W4A16 MFMA GEMM; mfma_util = 2 M K N / time / dense fp16 peak; prepass_share = the pre-pass launch alone / the call"}
+                                         "matrix cores + W4A16 MFMA GEMM; mfma_util = 2 M K N / time / dense fp16 peak; prepass_share = the pre-pass launch alone / the call; "
+                                         "fused_rotation_experiment_ms = the same call as ONE launch with the rotation applied to the LDS-staged slab inside the GEMM "
+                                         "(north_star's wording; GEMM variant 44, same bits, profiles/NOTES.md 6.11) -- measured, slower, never selected"}
             except Exception as e:
                 ex["prefill"] = {"error": f"{type(e).__name__}: {e}"}
             try:       # BASELINE configs 1 and 2 (decode legs) next to the headline configuration
