@@ -957,6 +957,8 @@ def run(args, rank: int, local_rank: int, world: int):
     model = workload[:-3] if tp_mode else workload
     if model not in MODELS and model not in HYBRID:
         raise SystemExit(f"unknown workload {workload!r}; known models: {known_models()} (the dense ones also as <model>-tp)")
+    if args.rows > 16 and args.route == "auto":
+        args.route = "fused"      # above 16 rows only the per-call route exists (the chain family is a <= 16-row decode path)
     if not 1 <= args.rows <= (512 if args.route == "fused" else 16):
         raise SystemExit("--rows must be in 1..16 (--route fused, the per-call route: 1..512)")
     tp = world if tp_mode else 1
