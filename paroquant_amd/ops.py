@@ -761,6 +761,7 @@ def get_workspace(device: torch.device, nbytes: int, stream=None) -> torch.Tenso
             # a HIP graph captured earlier holds the OLD buffer's address: it stays allocated (replays keep writing their granules and
             # rotated rows there), only new calls move to the larger one
             _retired_workspaces.append(ws)
+            nbytes = max(int(nbytes), ws.numel() + ws.numel() // 2)     # grow geometrically: the retired buffers sum to < 3x the live one
         ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device(device.type, idx))
         _workspaces[key] = ws
     return ws
